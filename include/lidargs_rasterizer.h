@@ -1,0 +1,245 @@
+/*
+ * lidargs_rasterizer.h -- C ABI of the MI355X-native LiDAR Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native rasterizer core
+ *   CudaRasterizer::Rasterizer::{forward, backward, visible_filter, markVisible}
+ *   (/root/reference/submodules/diff_lidargs_rasterization/cuda_rasterizer/rasterizer.h:18-124,
+ *    "R3/cr/rasterizer.h" below).
+ * Every entry point takes plain device pointers and sizes (no torch / C++ types), the HIP
+ * stream to run on, and -- where the reference takes std::function<char*(size_t)> resizers
+ * (R3/cr/rasterizer.h:32-34) -- a C callback + user pointer, so the caller (torch, or any
+ * other allocator) owns the three opaque scratch buffers and keeps them alive until backward.
+ *
+ * Conventions shared by all entry points
+ *   - all array arguments are DEVICE pointers (gfx950 HBM), float32 / int32, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are only
+ *     enqueued on it, the single host wait is the 4-byte instance-count read in forward;
+ *   - return value: >= 0 on success, one of LIDARGS_ERR_* (< 0) on failure, with a message
+ *     available from lidargs_last_error() (thread-local);
+ *   - argument order and meaning mirror the reference signatures line by line; arguments the
+ *     reference's LiDAR path accepts but never reads (D, M, shs, projmatrix, cam_pos,
+ *     prefiltered, tan_fov*) are accepted and ignored here too.
+ *
+ * The three scratch buffers are opaque: their layout, the meaning of the int returned by
+ * lidargs_forward ("num_rendered" = number of (Gaussian, 16xTH-tile) instances this
+ * implementation binned, NOT the reference's 16x1 count) and the per-pixel contributor
+ * counts are private to this library and only consumed by lidargs_backward, exactly as
+ * geomBuffer/binningBuffer/imgBuffer are private to the reference's backward
+ * (R3/cr/rasterizer_impl.cu:469-471).
+ */
+#ifndef LIDARGS_RASTERIZER_H
+#define LIDARGS_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIDARGS_ABI_VERSION 1
+#define LIDARGS_NUM_CHANNELS 2 /* R3/cr/config.h:15 NUM_CHANNELS (intensity, ray-drop) */
+
+enum {
+    LIDARGS_OK = 0,
+    LIDARGS_ERR_INVALID_ARGUMENT = -1, /* bad sizes / NULL required pointer            */
+    LIDARGS_ERR_NO_COLORS = -2,        /* colors_precomp == NULL, R3/cr/rasterizer_impl.cu:249-252 */
+    LIDARGS_ERR_ALLOC = -3,            /* an allocator callback returned NULL           */
+    LIDARGS_ERR_HIP = -4,              /* a HIP runtime call or kernel launch failed    */
+    LIDARGS_ERR_STATE = -5,            /* backward: buffers do not match (P, R, W*H)    */
+    LIDARGS_ERR_NO_DEVICE = -6         /* no gfx950 device / HIP runtime unavailable    */
+};
+
+/* Replaces std::function<char*(size_t N)> (R3/cr/rasterizer.h:32-34; the torch-side lambda is
+ * R3/rasterize_points.cu:27-33).  Must return a device pointer to at least `bytes` bytes,
+ * 128-byte aligned, valid until the matching backward has run.  Called at most once per
+ * buffer per lidargs_forward / lidargs_visible_filter call. */
+typedef char* (*lidargs_alloc_fn)(void* user, size_t bytes);
+
+int lidargs_abi_version(void);
+const char* lidargs_last_error(void);
+
+/* Rasterizer::forward -- R3/cr/rasterizer.h:31-58, R3/cr/rasterizer_impl.cu:202-359.
+ * Outputs (caller-allocated, R3/rasterize_points.cu:71-75): out_color f32[2*H*W],
+ * out_depth f32[H*W], out_occ f32[H*W], radii i32[P], radii_xy i32[2P].
+ * Returns num_rendered (>= 0) to be passed back to lidargs_backward as R. */
+int lidargs_forward(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* opacities,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    const float* beam_inclinations,
+    int prefiltered,
+    int lidar_far,
+    int lidar_near,
+    float* out_color,
+    float* out_depth,
+    float* out_occ,
+    int* radii,
+    int* radii_xy,
+    int debug,
+    void* stream);
+
+/* Rasterizer::backward -- R3/cr/rasterizer.h:86-122, R3/cr/rasterizer_impl.cu:431-549.
+ * All dL_d* outputs are caller-allocated and ZERO-INITIALISED (R3/rasterize_points.cu:163-175):
+ * dL_dmean2D f32[4P], dL_dconic f32[4P], dL_dopacity f32[P], dL_dcolor f32[2P],
+ * dL_ddepths f32[P], dL_dmean3D f32[3P], dL_dsphere_means3D f32[3P], dL_dbasis_u1 f32[3P],
+ * dL_dbasis_u2 f32[3P], dL_dcov3D f32[6P], dL_dsh (untouched), dL_dscale f32[3P], dL_drot f32[4P]. */
+int lidargs_backward(
+    int P, int D, int M, int R,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* campos,
+    const float* beam_inclinations,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    char* geom_buffer,
+    char* binning_buffer,
+    char* image_buffer,
+    const float* dL_dpix,
+    const float* dL_dout_depth,
+    const float* dL_dout_occ,
+    float* dL_dmean2D,
+    float* dL_dconic,
+    float* dL_dopacity,
+    float* dL_dcolor,
+    float* dL_ddepths,
+    float* dL_dmean3D,
+    float* dL_dsphere_means3D,
+    float* dL_dbasis_u1,
+    float* dL_dbasis_u2,
+    float* dL_dcov3D,
+    float* dL_dsh,
+    float* dL_dscale,
+    float* dL_drot,
+    int debug,
+    void* stream);
+
+/* Rasterizer::visible_filter -- R3/cr/rasterizer.h:60-84, R3/cr/rasterizer_impl.cu:362-426.
+ * Only radii / radii_xy are produced; the allocators may be NULL (no scratch is needed here,
+ * the reference allocates and discards it). */
+int lidargs_visible_filter(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, int M,
+    int width, int height,
+    const float* means3D,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    const float* beam_inclinations,
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    int lidar_far,
+    int lidar_near,
+    int* radii,
+    int* radii_xy,
+    int debug,
+    void* stream);
+
+/* Rasterizer::markVisible -- R3/cr/rasterizer.h:21-29, R3/cr/rasterizer_impl.cu:142-154.
+ * present: bool (1 byte) [P]. */
+int lidargs_mark_visible(
+    int P,
+    const float* means3D,
+    const float* viewmatrix,
+    const float* projmatrix,
+    unsigned char* present,
+    void* stream);
+
+/* ---- multi-GPU range-shell variants (no reference counterpart) -------
+ * A rank owns the Gaussians whose range lies in [shell_lo, shell_hi) (on top of the reference's
+ * integer near/far cull), so every pixel's depth-sorted list is the concatenation of the ranks'
+ * lists and per-Gaussian work and gradients stay local to one rank.
+ *
+ *   lidargs_forward_shell   preprocess + bin this shell, then composite it starting from
+ *                           T_in f32[H*W] (NULL = 1).  transmittance_pass != 0 is phase 1 of the
+ *                           two-phase render: only T_out f32[H*W] is produced, = the transmittance
+ *                           this shell hands to the shells behind it (if the reference's
+ *                           T < 1e-4 early-out fires inside the shell, the value that tripped it).
+ *   lidargs_render_shell    phase 2: composite the already-binned shell again, now from the true
+ *                           T_in = product of the nearer shells' T_out.  Outputs are this shell's
+ *                           own partial sums, already weighted by the global transmittance
+ *                           (pass background = NULL and add T_final*bg after the reduction).
+ *   lidargs_backward_shell  like lidargs_backward, seeded with what lies BEHIND the shell:
+ *                           behind f32[3*H*W] = (colour0, colour1, depth) partial sums of all
+ *                           farther shells; T_final_global f32[H*W].
+ */
+int lidargs_forward_shell(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, const float* background, int width, int height,
+    const float* means3D, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* beam_inclinations,
+    int lidar_far, int lidar_near, float shell_lo, float shell_hi,
+    const float* T_in, int transmittance_pass,
+    float* out_color, float* out_depth, float* out_occ, float* T_out,
+    int* radii, int* radii_xy, int debug, void* stream);
+
+int lidargs_render_shell(
+    int P, int R, const float* background, int width, int height,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* T_in, int transmittance_pass,
+    float* out_color, float* out_depth, float* out_occ, float* T_out,
+    int debug, void* stream);
+
+int lidargs_backward_shell(
+    int P, int R, const float* background, int width, int height,
+    const float* means3D, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* beam_inclinations,
+    const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* behind, const float* T_final_global,
+    const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ,
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths,
+    float* dL_dmean3D, float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2,
+    float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug, void* stream);
+
+/* ---- introspection used by bench.py / tests (no reference counterpart) ---------------------
+ * Per-stage HIP-event timing on the op's own stream.  When enabled, every forward/backward
+ * records an event pair around each stage; lidargs_profile_read() synchronises the LAST call's
+ * events and returns elapsed milliseconds per stage. */
+#define LIDARGS_MAX_STAGES 24
+void lidargs_profile_enable(int on);
+int lidargs_profile_read(float* ms_out, int max_stages);      /* returns #stages written     */
+const char* lidargs_profile_stage_name(int stage);            /* NULL past the last stage    */
+
+/* Counters of the last forward on this thread: [0]=P, [1]=visible Gaussians V,
+ * [2]=instances binned by this library (num_rendered), [3]=R_ref = sum of the reference's
+ * 16x1 tiles_touched (what SURVEY.md 8d's byte formula is written in), [4]=tile rows TH,
+ * [5]=number of tiles.  Values [1] and [3] are read back from the device on demand. */
+int lidargs_last_counters(long long* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARGS_RASTERIZER_H */

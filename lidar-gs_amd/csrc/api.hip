@@ -1,0 +1,416 @@
+// api.hip -- extern "C" entry points of include/lidargs_rasterizer.h and the host-side
+// stage sequence (the counterpart of CudaRasterizer::Rasterizer::{forward,backward,...},
+// R3/cr/rasterizer_impl.cu:202-549).
+//
+// Differences from the reference's host sequence, all behind the same interface:
+//   - everything is enqueued on the caller's stream; there is no device-wide synchronise
+//     (the reference calls cudaDeviceSynchronize after most kernels, R3/cr/forward.cu:682,:753,
+//     R3/cr/rasterizer_impl.cu:311, R3/cr/backward.cu:843,:870,:932);
+//   - the single host wait is the 16-byte read-back of the instance count needed to size the
+//     binning buffer (the reference's blocking cudaMemcpy, R3/cr/rasterizer_impl.cu:292);
+//   - errors are returned as negative codes instead of printf-and-continue.
+#include "lidargs_common.h"
+#include "../../include/lidargs_rasterizer.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits>
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local long long g_counters[6] = {0, 0, 0, 0, 0, 0};
+thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals
+thread_local hipStream_t g_last_stream = nullptr;
+
+int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+
+#define LG_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(LIDARGS_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+int check_launch(hipStream_t s, int debug, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(s);       // CHECK_CUDA(.., debug), R3/cr/auxiliary.h:202-209
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+        return LIDARGS_ERR_HIP;
+    }
+    return 0;
+}
+#define LG_STAGE_CHECK(what)                                  \
+    do {                                                      \
+        int rc_ = check_launch(stream, debug, what);          \
+        if (rc_) return rc_;                                  \
+    } while (0)
+
+int tile_rows() {
+    static int th = [] {
+        const char* e = getenv("LIDARGS_TILE_ROWS");
+        int v = e ? atoi(e) : 4;
+        if (v != 4 && v != 8 && v != 16 && v != 32) v = 4;
+        return v;
+    }();
+    return th;
+}
+
+int ceil_log2(uint32_t n) {
+    int b = 0;
+    while ((1u << b) < n && b < 31) b++;
+    return b;
+}
+
+// ---- per-stage event timing -------------------------------------------------------------------
+struct Profiler {
+    bool enabled = false;
+    int n = 0;
+    const char* names[LIDARGS_MAX_STAGES];
+    hipEvent_t ev[LIDARGS_MAX_STAGES + 1];
+    bool created = false;
+    void begin(hipStream_t s) {
+        n = 0;
+        if (!enabled) return;
+        if (!created) { for (auto& e : ev) (void)hipEventCreate(&e); created = true; }
+        (void)hipEventRecord(ev[0], s);
+    }
+    void mark(const char* name, hipStream_t s) {
+        if (!enabled || n >= LIDARGS_MAX_STAGES) return;
+        names[n] = name;
+        (void)hipEventRecord(ev[n + 1], s);
+        n++;
+    }
+};
+thread_local Profiler g_prof;
+
+struct Common {
+    int P, W, H;
+    lg::TileGrid grid;
+};
+
+int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                 lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
+                 const float* means3D, const float* colors_precomp, const float* opacities, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* beams, float near_f, float far_f, float shell_lo, float shell_hi, const float* T_in,
+                 int transmittance_pass, float* out_color, float* out_depth, float* out_occ, float* T_out, int* radii,
+                 int* radii_xy, int debug, hipStream_t stream) {
+    if (P < 0 || width <= 0 || height <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: bad sizes%s");
+    if (height < 2) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: need at least 2 beams%s");
+    if (height > 65535 || width > 65535 * 16) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: image too large%s");
+    if (colors_precomp == nullptr) return fail(LIDARGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!%s");
+    if (!means3D || !opacities || !viewmatrix || !beams || !out_color || !out_depth || !out_occ || !radii || !radii_xy)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: NULL required pointer%s");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: need scales+rotations or cov3D_precomp%s");
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: NULL allocator%s");
+    if (P == 0) return 0;   // R3/rasterize_points.cu:87: outputs stay as the caller initialised them
+
+    const int TH = tile_rows();
+    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    g_prof.begin(stream);
+
+    char* geom_p = geometry_alloc(geometry_user, lg::geom_carve(nullptr, (size_t)P, nullptr));
+    if (!geom_p) return fail(LIDARGS_ERR_ALLOC, "geometry allocator returned NULL%s");
+    char* img_p = image_alloc(image_user, lg::img_carve(nullptr, width, height, grid.num_tiles(), nullptr));
+    if (!img_p) return fail(LIDARGS_ERR_ALLOC, "image allocator returned NULL%s");
+    lg::GeomView geom; lg::geom_carve(geom_p, (size_t)P, &geom);
+    lg::ImgView img; lg::img_carve(img_p, width, height, grid.num_tiles(), &img);
+
+    lg::PreprocessParams pp;
+    pp.P = P; pp.W = width; pp.H = height; pp.TH = TH; pp.tiles_x = grid.tiles_x; pp.tiles_y = grid.tiles_y;
+    pp.scale_modifier = scale_modifier;
+    pp.near_f = near_f; pp.far_f = far_f; pp.shell_lo = shell_lo; pp.shell_hi = shell_hi;
+    const float pi_f = 3.14159265358979323846f;
+    pp.col_step = 2 * pi_f / width;                                    // R3/cr/forward.cu:334
+    pp.tan_col_step = tanf(2 * pi_f / width);                          // R3/cr/forward.cu:362
+    pp.view = viewmatrix;
+
+    lg::launch_setup_tables(beams, width, height, img, stream);
+    lg::launch_preprocess(pp, means3D, scales, rotations, opacities, colors_precomp, cov3D_precomp, beams, radii, radii_xy,
+                          geom, false, stream);
+    LG_STAGE_CHECK("preprocess");
+    g_prof.mark("preprocess", stream);
+
+    // 1. range sort of the Gaussians (31 significant bits: ranges are positive floats; culled = 0xFFFFFFFF)
+    const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 32, geom.scratch, stream);
+    const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
+    LG_STAGE_CHECK("range sort");
+    g_prof.mark("range_sort", stream);
+
+    // 2. instance offsets in range order, total -> host
+    lg::launch_gather_counts(ids_sorted, geom.tcount, geom.cnt_sorted, (size_t)P, stream);
+    uint32_t* scan_scratch = geom.scratch + lg::sort_scratch_words((size_t)P);
+    lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
+    LG_STAGE_CHECK("instance scan");
+    uint32_t totals_h[4] = {0, 0, 0, 0};
+    LG_HIP(hipMemcpyAsync(totals_h, geom.totals, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LG_HIP(hipStreamSynchronize(stream));                              // the one host wait (R3/cr/rasterizer_impl.cu:292)
+    const size_t R = totals_h[0];
+    if (R > (size_t)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
+    g_prof.mark("scan+readback", stream);
+
+    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, nullptr));
+    if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
+    lg::BinView bin; lg::bin_carve(bin_p, R, &bin);
+
+    // 3. emit instances in range order, bin them by tile (stable)
+    const uint32_t* point_list = bin.val_a;
+    if (R) {
+        lg::launch_emit_instances(ids_sorted, geom.cnt_sorted, geom.off_sorted, geom.rowspan, geom.xspan, (size_t)P, grid,
+                                  bin.tile_a, bin.val_a, stream);
+        LG_STAGE_CHECK("emit");
+        g_prof.mark("emit", stream);
+        const int bits = ceil_log2((uint32_t)grid.num_tiles());
+        const int bside = lg::launch_radix_sort_pairs(bin.tile_a, bin.tile_b, bin.val_a, bin.val_b, R, bits, bin.scratch, stream);
+        if (bside) {   // keep the backward's view independent of the pass count: result always in (tile_a, val_a)
+            LG_HIP(hipMemcpyAsync(bin.tile_a, bin.tile_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            LG_HIP(hipMemcpyAsync(bin.val_a, bin.val_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        }
+        LG_STAGE_CHECK("tile bin");
+        g_prof.mark("tile_bin", stream);
+    }
+    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream);
+    LG_STAGE_CHECK("tile ranges");
+    g_prof.mark("ranges", stream);
+
+    lg::RenderFwdArgs ra;
+    ra.grid = grid; ra.ranges = img.ranges; ra.point_list = point_list; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
+    ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
+    ra.final_T = img.final_T; ra.n_contrib = img.n_contrib; ra.T_pass = T_out;
+    ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
+    ra.transmittance_only = transmittance_pass;
+    lg::launch_render_forward(ra, stream);
+    LG_STAGE_CHECK("render forward");
+    g_prof.mark("render_fwd", stream);
+
+    g_counters[0] = P; g_counters[1] = -1; g_counters[2] = (long long)R; g_counters[3] = -1; g_counters[4] = TH;
+    g_counters[5] = grid.num_tiles();
+    g_last_totals_dev = geom.ref_tiles;   // R_ref / V are reduced lazily in lidargs_last_counters
+    g_last_stream = stream;
+    return (int)R;
+}
+
+int backward_impl(int P, int R, const float* background, int width, int height, const float* means3D,
+                  const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                  const float* cov3D_precomp, const float* viewmatrix, const float* beams, const int* radii, char* geom_buffer,
+                  char* binning_buffer, char* image_buffer, const float* behind, const float* T_final_global,
+                  const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ, float* dL_dmean2D,
+                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths, float* dL_dmean3D,
+                  float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2, float* dL_dcov3D, float* dL_dscale,
+                  float* dL_drot, int debug, hipStream_t stream) {
+    (void)colors_precomp; (void)beams;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: bad sizes%s");
+    if (P == 0) return 0;   // R3/rasterize_points.cu:177
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "backward: missing forward buffers%s");
+    if (!means3D || !viewmatrix || !radii || !dL_dpix || !dL_dout_depth || !dL_dout_occ || !dL_dmean2D || !dL_dconic ||
+        !dL_dopacity || !dL_dcolor || !dL_ddepths || !dL_dmean3D || !dL_dsphere_means3D || !dL_dbasis_u1 || !dL_dbasis_u2 ||
+        !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: NULL required pointer%s");
+
+    const int TH = tile_rows();
+    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
+    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, &bin);
+    lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
+    g_prof.begin(stream);
+
+    LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
+    g_prof.mark("bwd_zero", stream);
+
+    lg::RenderBwdArgs rb;
+    rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
+    rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T; rb.n_contrib = img.n_contrib;
+    rb.T_final_global = T_final_global; rb.behind = behind;
+    rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
+    if (R) lg::launch_render_backward(rb, stream);
+    LG_STAGE_CHECK("render backward");
+    g_prof.mark("render_bwd", stream);
+
+    lg::GaussBwdArgs gb;
+    gb.P = P; gb.scale_modifier = scale_modifier;
+    gb.view = viewmatrix;
+    gb.means3D = means3D; gb.scales = scales; gb.rotations = rotations; gb.cov3D_precomp = cov3D_precomp; gb.radii = radii;
+    gb.gacc = geom.gacc;
+    gb.dL_dmean2D = dL_dmean2D; gb.dL_dconic = dL_dconic; gb.dL_dopacity = dL_dopacity; gb.dL_dcolor = dL_dcolor;
+    gb.dL_ddepths = dL_ddepths; gb.dL_dbasis_u1 = dL_dbasis_u1; gb.dL_dbasis_u2 = dL_dbasis_u2;
+    gb.dL_dsphere = dL_dsphere_means3D; gb.dL_dmean3D = dL_dmean3D; gb.dL_dcov3D = dL_dcov3D; gb.dL_dscale = dL_dscale;
+    gb.dL_drot = dL_drot;
+    lg::launch_gaussian_backward(gb, stream);
+    LG_STAGE_CHECK("gaussian backward");
+    g_prof.mark("gaussian_bwd", stream);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lidargs_abi_version(void) { return LIDARGS_ABI_VERSION; }
+const char* lidargs_last_error(void) { return g_err; }
+
+int lidargs_forward(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                    lidargs_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                    int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const float* beam_inclinations,
+                    int prefiltered, int lidar_far, int lidar_near, float* out_color, float* out_depth, float* out_occ,
+                    int* radii, int* radii_xy, int debug, void* stream) {
+    (void)D; (void)M; (void)shs; (void)projmatrix; (void)cam_pos; (void)prefiltered;
+    const float inf = std::numeric_limits<float>::infinity();
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
+                        height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        beam_inclinations, (float)lidar_near, (float)lidar_far, -inf, inf, nullptr, 0, out_color, out_depth,
+                        out_occ, nullptr, radii, radii_xy, debug, (hipStream_t)stream);
+}
+
+int lidargs_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                     const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                     const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                     const float* campos, const float* beam_inclinations, float tan_fovx, float tan_fovy, const int* radii,
+                     char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                     const float* dL_dout_depth, const float* dL_dout_occ, float* dL_dmean2D, float* dL_dconic,
+                     float* dL_dopacity, float* dL_dcolor, float* dL_ddepths, float* dL_dmean3D, float* dL_dsphere_means3D,
+                     float* dL_dbasis_u1, float* dL_dbasis_u2, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                     int debug, void* stream) {
+    (void)D; (void)M; (void)shs; (void)projmatrix; (void)campos; (void)tan_fovx; (void)tan_fovy; (void)dL_dsh;
+    return backward_impl(P, R, background, width, height, means3D, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, nullptr, nullptr, dL_dpix,
+                         dL_dout_depth, dL_dout_occ, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepths, dL_dmean3D,
+                         dL_dsphere_means3D, dL_dbasis_u1, dL_dbasis_u2, dL_dcov3D, dL_dscale, dL_drot, debug, (hipStream_t)stream);
+}
+
+int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                           lidargs_alloc_fn image_alloc, void* image_user, int P, int M, int width, int height,
+                           const float* means3D, const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                           const float* beam_inclinations, float tan_fovx, float tan_fovy, int prefiltered, int lidar_far,
+                           int lidar_near, int* radii, int* radii_xy, int debug, void* stream_) {
+    (void)geometry_alloc; (void)geometry_user; (void)binning_alloc; (void)binning_user; (void)image_alloc; (void)image_user;
+    (void)M; (void)projmatrix; (void)cam_pos; (void)tan_fovx; (void)tan_fovy; (void)prefiltered;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || height < 2) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "visible_filter: bad sizes%s");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !beam_inclinations || !radii || !radii_xy)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "visible_filter: NULL required pointer%s");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "visible_filter: need scales+rotations or cov3D_precomp%s");
+    const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());
+    lg::PreprocessParams pp;
+    pp.P = P; pp.W = width; pp.H = height; pp.TH = grid.TH; pp.tiles_x = grid.tiles_x; pp.tiles_y = grid.tiles_y;
+    pp.scale_modifier = scale_modifier;
+    pp.near_f = (float)lidar_near; pp.far_f = (float)lidar_far;
+    pp.shell_lo = -std::numeric_limits<float>::infinity(); pp.shell_hi = std::numeric_limits<float>::infinity();
+    const float pi_f = 3.14159265358979323846f;
+    pp.col_step = 2 * pi_f / width;
+    pp.tan_col_step = tanf(2 * pi_f / width);
+    pp.view = viewmatrix;
+    lg::GeomView none; memset(&none, 0, sizeof none);
+    lg::launch_preprocess(pp, means3D, scales, rotations, nullptr, nullptr, cov3D_precomp, beam_inclinations, radii, radii_xy, none,
+                          true, stream);
+    LG_STAGE_CHECK("filter preprocess");
+    return 0;
+}
+
+int lidargs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, unsigned char* present,
+                         void* stream_) {
+    (void)projmatrix;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    if (P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "mark_visible: bad size%s");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "mark_visible: NULL required pointer%s");
+    lg::launch_mark_visible(P, means3D, viewmatrix, present, stream);
+    LG_STAGE_CHECK("mark visible");
+    return 0;
+}
+
+int lidargs_forward_shell(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                          lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
+                          const float* means3D, const float* colors_precomp, const float* opacities, const float* scales,
+                          float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                          const float* beam_inclinations, int lidar_far, int lidar_near, float shell_lo, float shell_hi,
+                          const float* T_in, int transmittance_pass, float* out_color, float* out_depth, float* out_occ,
+                          float* T_out, int* radii, int* radii_xy, int debug, void* stream) {
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
+                        height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        beam_inclinations, (float)lidar_near, (float)lidar_far, shell_lo, shell_hi, T_in, transmittance_pass,
+                        out_color, out_depth, out_occ, T_out, radii, radii_xy, debug, (hipStream_t)stream);
+}
+
+int lidargs_render_shell(int P, int R, const float* background, int width, int height, char* geom_buffer, char* binning_buffer,
+                         char* image_buffer, const float* T_in, int transmittance_pass, float* out_color, float* out_depth,
+                         float* out_occ, float* T_out, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "render_shell: missing forward buffers%s");
+    const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());
+    lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
+    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, &bin);
+    lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
+    lg::RenderFwdArgs ra;
+    ra.grid = grid; ra.ranges = img.ranges; ra.point_list = bin.val_a; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
+    ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
+    ra.final_T = img.final_T; ra.n_contrib = img.n_contrib; ra.T_pass = T_out;
+    ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
+    ra.transmittance_only = transmittance_pass;
+    if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
+    lg::launch_render_forward(ra, stream);
+    LG_STAGE_CHECK("render shell");
+    return 0;
+}
+
+int lidargs_backward_shell(int P, int R, const float* background, int width, int height, const float* means3D,
+                           const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* beam_inclinations, const int* radii,
+                           char* geom_buffer, char* binning_buffer, char* image_buffer, const float* behind,
+                           const float* T_final_global, const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ,
+                           float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths,
+                           float* dL_dmean3D, float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2,
+                           float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug, void* stream) {
+    return backward_impl(P, R, background, width, height, means3D, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, behind, T_final_global,
+                         dL_dpix, dL_dout_depth, dL_dout_occ, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepths, dL_dmean3D,
+                         dL_dsphere_means3D, dL_dbasis_u1, dL_dbasis_u2, dL_dcov3D, dL_dscale, dL_drot, debug, (hipStream_t)stream);
+}
+
+void lidargs_profile_enable(int on) { g_prof.enabled = on != 0; }
+
+int lidargs_profile_read(float* ms_out, int max_stages) {
+    if (!g_prof.enabled || g_prof.n == 0) return 0;
+    (void)hipEventSynchronize(g_prof.ev[g_prof.n]);
+    int k = 0;
+    for (; k < g_prof.n && k < max_stages; k++) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, g_prof.ev[k], g_prof.ev[k + 1]);
+        ms_out[k] = ms;
+    }
+    return k;
+}
+
+const char* lidargs_profile_stage_name(int stage) {
+    if (stage < 0 || stage >= g_prof.n) return nullptr;
+    return g_prof.names[stage];
+}
+
+int lidargs_last_counters(long long* out, int n) {
+    if (g_counters[1] < 0 && g_last_totals_dev && g_counters[0] > 0) {
+        // reduce ref_tiles on the host (diagnostics path, not on any timed path)
+        const size_t P = (size_t)g_counters[0];
+        uint32_t* h = (uint32_t*)malloc(P * sizeof(uint32_t));
+        if (h && hipMemcpy(h, g_last_totals_dev, P * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            long long v = 0, r = 0;
+            for (size_t i = 0; i < P; i++) { if (h[i]) v++; r += h[i]; }
+            g_counters[1] = v; g_counters[3] = r;
+        }
+        free(h);
+    }
+    int k = 0;
+    for (; k < n && k < 6; k++) out[k] = g_counters[k];
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+// binning.hip -- range sort + per-tile radix bin (gfx950), replacing the reference's
+// scan -> duplicateWithKeys -> cub::DeviceRadixSort::SortPairs(64-bit) -> identifyTileRanges
+// chain (R3/cr/rasterizer_impl.cu:288-332).
+//
+// The reference sorts R_ref = sum(16x1 tiles touched) 64-bit (tile|range) keys -- its largest
+// pure-bandwidth stage.  Here the same ordering (tile, range bits, id)
+// is produced in two much smaller steps:
+//   1. stable LSD radix sort of the P Gaussians by their 32-bit range key (ties keep id order);
+//   2. instances are EMITTED IN RANGE ORDER, one per (Gaussian, 16xTH tile), and a stable LSD
+//      radix sort on the tile id only (ceil(log2(tiles)) bits, 1-2 passes) bins them.
+// A stable bin of a range-ordered stream leaves every tile's list ordered by (range, id): the
+// cub sort's tie-break (R3/cr/rasterizer_impl.cu:317-322, stable on identical keys).
+//
+// Kernels: one wave64 per block, no cross-wave traffic.  Ranks inside a wave come from
+// ballot-matching the digit bits (wave-wide match-any), so every pass is stable by construction.
+#include "lidargs_common.h"
+
+namespace lg {
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan (u32), three small kernels: block reduce -> serial-ish scan of partials -> block scan.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t ws[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// single block: exclusive scan of `nb` partials in place, grand total -> *total_out (may be null)
+__global__ void __launch_bounds__(1024) k_scan_partials(uint32_t* __restrict__ partial, size_t nb, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < nb; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? partial[i] : 0;
+        const uint32_t inc = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int k = 0; k < w; k++) off += wsum[k];
+        if (i < nb) partial[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+// `in` may alias `out` (in-place scan of the radix histograms): each thread reads its own 4 words first.
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t* in, uint32_t* out, size_t n,
+                                                     const uint32_t* __restrict__ partial) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // blocked arrangement: thread t owns 4 consecutive elements
+    const size_t i0 = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+    const uint32_t inc = wave_incl_scan(tsum, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t off = partial[blockIdx.x] + inc - tsum;
+    for (int k = 0; k < w; k++) off += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (i0 + k < n) out[i0 + k] = off;
+        off += v[k];
+    }
+}
+
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s) {
+    if (n == 0) {
+        if (total_out) hipMemsetAsync(total_out, 0, sizeof(uint32_t), s);
+        return;
+    }
+    const size_t nb = scan_blocks(n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, s, in, n, scratch);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, scratch, nb, total_out);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, in, out, n, scratch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSD radix sort pass, one wave per block, SORT_CHUNK consecutive keys per block.
+// hist layout: [digit][block]  (digit-major, so one exclusive scan yields global bucket bases)
+template <int BITS>
+__global__ void __launch_bounds__(64) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, int shift,
+                                                   uint32_t* __restrict__ hist, unsigned nblocks) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t cnt[BINS];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < BINS; d += 64) cnt[d] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        const size_t i = base + (size_t)r * 64 + lane;
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int d = lane; d < BINS; d += 64) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
+}
+
+template <int BITS>
+__global__ void __launch_bounds__(64) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                      size_t n, int shift, const uint32_t* __restrict__ bases, unsigned nblocks) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t run[BINS];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < BINS; d += 64) run[d] = bases[(size_t)d * nblocks + blockIdx.x];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        const size_t i = base + (size_t)r * 64 + lane;
+        if (base + (size_t)r * 64 >= n) break;                      // wave-uniform
+        const bool valid = i < n;
+        const uint32_t k = valid ? keys_in[i] : 0u;
+        const uint32_t v = valid ? vals_in[i] : 0u;
+        const uint32_t d = (k >> shift) & (BINS - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        const uint32_t pos = run[d] + rank;
+        __syncthreads();                                              // all reads of run[] before the leaders update it
+        if (valid && rank == 0) run[d] += (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) { keys_out[pos] = k; vals_out[pos] = v; }
+    }
+}
+
+template <int BITS>
+static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, int shift,
+                       uint32_t* scratch, hipStream_t s) {
+    const unsigned nb = (unsigned)sort_blocks(n);
+    const size_t hwords = (size_t)(1 << BITS) * nb;
+    uint32_t* hist = scratch;
+    uint32_t* scan_scratch = scratch + (size_t)SORT_BINS * nb;       // after the largest possible histogram
+    hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(64), 0, s, kin, n, shift, hist, nb);
+    launch_exclusive_scan(hist, hist, hwords, nullptr, scan_scratch, s);
+    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(64), 0, s, kin, vin, kout, vout, n, shift, hist, nb);
+}
+
+int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
+                            uint32_t* scratch, hipStream_t s) {
+    if (n == 0 || end_bit <= 0) return 0;
+    int cur = 0;
+    int shift = 0;
+    while (shift < end_bit) {
+        const int left = end_bit - shift;
+        uint32_t* kin = cur ? key_b : key_a; uint32_t* vin = cur ? val_b : val_a;
+        uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
+        // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4)
+        const int passes_left = (left + SORT_RADIX_BITS - 1) / SORT_RADIX_BITS;
+        const int bits = (left + passes_left - 1) / passes_left;
+        switch (bits) {
+            case 1: radix_pass<1>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 2: radix_pass<2>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 3: radix_pass<3>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 4: radix_pass<4>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 5: radix_pass<5>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 6: radix_pass<6>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 7: radix_pass<7>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            default: radix_pass<8>(kin, vin, kout, vout, n, shift, scratch, s); break;
+        }
+        shift += bits;
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_counts(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ tcount,
+                                                       uint32_t* __restrict__ cnt_sorted, size_t P) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < P) cnt_sorted[i] = tcount[ids_sorted[i]];
+}
+
+void launch_gather_counts(const uint32_t* ids_sorted, const uint32_t* tcount, uint32_t* cnt_sorted, size_t P, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, tcount, cnt_sorted, P);
+}
+
+// Load-balanced expansion: each wave owns 64 range-consecutive Gaussians and writes their
+// instances cooperatively, 64 consecutive output slots per step (coalesced 256-B stores),
+// instead of one thread looping over its own rect (the reference's duplicateWithKeys,
+// R3/cr/rasterizer_impl.cu:70-112, whose per-thread trip count varies 1..100s).
+__global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ cnt_sorted,
+                                                        const uint32_t* __restrict__ off_sorted, const uint32_t* __restrict__ rowspan,
+                                                        const uint32_t* __restrict__ xspan, size_t P, int TH, int tiles_x,
+                                                        uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val) {
+    const int lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t cnt = 0, off = 0, g = 0, nx = 1, x0 = 0, ty0 = 0;
+    if (i < P) {
+        cnt = cnt_sorted[i];
+        off = off_sorted[i];
+        if (cnt) {
+            g = ids_sorted[i];
+            const uint32_t xs = xspan[g], rs = rowspan[g];
+            x0 = xs & 0xFFFFu; nx = (xs >> 16) - x0;
+            ty0 = (rs & 0xFFFFu) / (uint32_t)TH;
+        }
+    }
+    const uint32_t wave_base = __shfl(off, 0);
+    const uint32_t wave_total = __shfl(off + cnt, 63) - wave_base;    // offsets are exclusive and monotone
+    const uint32_t lo = off - wave_base;                              // local exclusive prefix
+    const uint32_t t_end = (wave_total + 63u) & ~63u;                 // every lane takes part in the shuffles
+    for (uint32_t t = lane; t < t_end; t += 64) {
+        // owner = largest lane L with lo_L <= t  (zero-count lanes share their successor's lo and lose)
+        int a = 0, b = 63;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (a + b + 1) >> 1;
+            const uint32_t v = __shfl(lo, mid);
+            if (v <= t) a = mid; else b = mid - 1;
+        }
+        const uint32_t o_lo = __shfl(lo, a), o_g = __shfl(g, a), o_nx = __shfl(nx, a), o_x0 = __shfl(x0, a), o_ty0 = __shfl(ty0, a);
+        if (t < wave_total) {
+            const uint32_t j = t - o_lo;
+            const uint32_t ry = j / o_nx, rx = j - ry * o_nx;
+            inst_tile[(size_t)wave_base + t] = (o_ty0 + ry) * (uint32_t)tiles_x + o_x0 + rx;
+            inst_val[(size_t)wave_base + t] = o_g;
+        }
+    }
+}
+
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* cnt_sorted, const uint32_t* off_sorted,
+                           const uint32_t* rowspan, const uint32_t* xspan, size_t P, TileGrid grid,
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s) {
+    hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, cnt_sorted, off_sorted,
+                       rowspan, xspan, P, grid.TH, grid.tiles_x, inst_tile, inst_val);
+}
+
+// R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys; ranges pre-zeroed (:324)
+__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ tile_sorted, size_t R, uint2* __restrict__ ranges) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t cur = tile_sorted[i];
+    if (i == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = tile_sorted[i - 1];
+        if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
+    }
+    if (i == R - 1) ranges[cur].y = (uint32_t)R;
+}
+
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s) {
+    hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
+    if (R) hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, ranges);
+}
+
+}  // namespace lg

@@ -1,0 +1,222 @@
+// lidargs_common.h -- shared declarations of the gfx950 LiDAR Gaussian rasterizer.
+//
+// Data layout in HBM (all private to this library; the reference's counterpart is the
+// GeometryState / BinningState / ImageState carving of R3/cr/rasterizer_impl.h:21-76):
+//
+//   geometry buffer  (sized by P)
+//     rec      float4[4P]  one 64-byte "splat record" per Gaussian, written once by preprocess and
+//                          gathered as one aligned 64-B segment per (tile, Gaussian) instance:
+//                            rec[0] = (s.x, s.y, s.z, range)       s = p_view/|p_view|
+//                            rec[1] = (u1'.x, u1'.y, u1'.z, A)     u1' = u1/(u1.u1), conic A
+//                            rec[2] = (u2'.x, u2'.y, u2'.z, B)     u2' = u2/(u2.u2), conic B
+//                            rec[3] = (C, opacity, colour0, colour1)
+//     rowspan  u32[P]      ymin | ymax<<16 of the reference's pixel-row rect (R3/cr/auxiliary.h:80-92)
+//     xspan    u32[P]      xmin | xmax<<16 of the same rect, in 16-pixel tile columns
+//     key_a    u32[P]      float bits of the range (sort key), 0xFFFFFFFF when culled
+//     tcount   u32[P]      #(16 x TH) tiles touched
+//     ref_tiles u32[P]     the reference's 16x1 tiles_touched (statistics only: R_ref)
+//     sort ping/pong, sorted ids, per-sorted-Gaussian instance offsets, scan/sort scratch
+//   binning buffer   (sized by R = #instances)
+//     tile keys ping/pong u32[R], Gaussian ids ping/pong u32[R], sort scratch
+//     -> point_list u32[R]: Gaussian ids sorted by (tile, range, id)
+//   image buffer     (sized by W*H)
+//     final_T f32[N], n_contrib u32[N], ranges uint2[tiles], per-row / per-column ray tables
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define LG_TILE_W 16          // = the reference's BLOCK_X (R3/cr/config.h:16); rect x-units are shared
+#define LG_WAVE_ROWS 4        // one wave64 = 16 columns x 4 rows of pixels
+#define LG_CHANNELS 2
+
+namespace lg {
+
+struct Carver {
+    char* p;
+    explicit Carver(char* base) : p(base) {}
+    template <typename T> T* take(size_t n) {
+        uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 127) & ~uintptr_t(127);
+        T* r = reinterpret_cast<T*>(a);
+        p = reinterpret_cast<char*>(a) + n * sizeof(T);
+        return r;
+    }
+};
+
+// ---- radix sort / scan scratch sizing (binning.hip) --------------------------------------------
+constexpr int SORT_ITEMS = 16;                  // rounds of 64 keys per wave-block
+constexpr int SORT_CHUNK = 64 * SORT_ITEMS;     // keys per block
+constexpr int SORT_RADIX_BITS = 8;
+constexpr int SORT_BINS = 1 << SORT_RADIX_BITS;
+constexpr int SCAN_BLOCK = 1024;                // elements per scan block (256 threads x 4)
+
+inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
+inline size_t scan_blocks(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
+// u32 words of scratch needed to sort n pairs: digit histogram [BINS x blocks] + scan partials
+inline size_t sort_scratch_words(size_t n) {
+    size_t h = (size_t)SORT_BINS * sort_blocks(n);
+    return h + scan_blocks(h) + 64;
+}
+inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
+
+struct GeomView {
+    float4* rec;
+    uint32_t* rowspan;
+    uint32_t* xspan;
+    uint32_t* tcount;
+    uint32_t* ref_tiles;
+    uint32_t* key_a; uint32_t* key_b;   // range keys ping/pong
+    uint32_t* id_a; uint32_t* id_b;     // Gaussian ids ping/pong (id_sorted ends in id_a)
+    uint32_t* cnt_sorted;               // tcount gathered in range order
+    uint32_t* off_sorted;               // exclusive scan of cnt_sorted
+    uint32_t* totals;                   // [0]=#instances, [1]=#visible, [2..3]=R_ref (u64)
+    float* gacc;                        // [16P] packed per-Gaussian gradient accumulators (backward)
+    uint32_t* scratch;                  // sort + scan scratch
+    size_t scratch_words;
+};
+
+inline size_t geom_carve(char* base, size_t P, GeomView* v) {
+    Carver c(base);
+    GeomView g;
+    g.rec = c.take<float4>(4 * P);
+    g.rowspan = c.take<uint32_t>(P);
+    g.xspan = c.take<uint32_t>(P);
+    g.tcount = c.take<uint32_t>(P);
+    g.ref_tiles = c.take<uint32_t>(P);
+    g.key_a = c.take<uint32_t>(P); g.key_b = c.take<uint32_t>(P);
+    g.id_a = c.take<uint32_t>(P); g.id_b = c.take<uint32_t>(P);
+    g.cnt_sorted = c.take<uint32_t>(P);
+    g.off_sorted = c.take<uint32_t>(P);
+    g.totals = c.take<uint32_t>(32);
+    g.gacc = c.take<float>(16 * P);
+    g.scratch_words = sort_scratch_words(P) + scan_scratch_words(P);
+    g.scratch = c.take<uint32_t>(g.scratch_words);
+    if (v) *v = g;
+    return (size_t)(c.p - base) + 128;
+}
+
+struct BinView {
+    uint32_t* tile_a; uint32_t* tile_b;
+    uint32_t* val_a; uint32_t* val_b;
+    uint32_t* scratch;
+    size_t scratch_words;
+};
+
+inline size_t bin_carve(char* base, size_t R, BinView* v) {
+    Carver c(base);
+    BinView b;
+    size_t n = R ? R : 1;
+    b.tile_a = c.take<uint32_t>(n); b.tile_b = c.take<uint32_t>(n);
+    b.val_a = c.take<uint32_t>(n); b.val_b = c.take<uint32_t>(n);
+    b.scratch_words = sort_scratch_words(n);
+    b.scratch = c.take<uint32_t>(b.scratch_words);
+    if (v) *v = b;
+    return (size_t)(c.p - base) + 128;
+}
+
+struct ImgView {
+    float* final_T;       // T at the end of this call's list (after early-out)
+    uint32_t* n_contrib;  // entries of the tile list consumed up to the last blended one
+    float* T_pass;        // transmittance handed to the next range shell (multi-GPU only)
+    uint2* ranges;        // [tiles]
+    float2* coltab;       // [W]  (cos beta, sin beta)
+    float2* rowtab;       // [H]  (cos alpha, sin alpha) of pixel row y
+};
+
+inline size_t img_carve(char* base, int W, int H, int tiles, ImgView* v) {
+    Carver c(base);
+    ImgView m;
+    size_t N = (size_t)W * H;
+    m.final_T = c.take<float>(N);
+    m.n_contrib = c.take<uint32_t>(N);
+    m.T_pass = c.take<float>(N);
+    m.ranges = c.take<uint2>(tiles);
+    m.coltab = c.take<float2>(W);
+    m.rowtab = c.take<float2>(H);
+    if (v) *v = m;
+    return (size_t)(c.p - base) + 128;
+}
+
+// Tile grid: 16 columns x TH rows (TH multiple of 4); each tile is rendered by TH/4 waves.
+struct TileGrid {
+    int W, H, TH;
+    int tiles_x, tiles_y;   // list tiles
+    int ref_tiles_x;        // == tiles_x (16-wide), reference grid.x
+    int waves_per_tile;
+    int num_tiles() const { return tiles_x * tiles_y; }
+};
+
+inline TileGrid make_grid(int W, int H, int TH) {
+    TileGrid g;
+    g.W = W; g.H = H; g.TH = TH;
+    g.tiles_x = (W + LG_TILE_W - 1) / LG_TILE_W;
+    g.tiles_y = (H + TH - 1) / TH;
+    g.ref_tiles_x = g.tiles_x;
+    g.waves_per_tile = TH / LG_WAVE_ROWS;
+    return g;
+}
+
+struct PreprocessParams {
+    int P, W, H, TH, tiles_x, tiles_y;
+    float scale_modifier;
+    float near_f, far_f;        // reference int near/far converted to float (R3/cr/forward.cu:304)
+    float shell_lo, shell_hi;   // extra float range shell: keep lo <= range < hi (multi-GPU); +-inf otherwise
+    float col_step;             // 2*pi/W        (float, as the reference evaluates it)
+    float tan_col_step;         // tanf(2*pi/W)  (host libm)
+    const float* view;          // DEVICE pointer to the 16 floats (wave-uniform -> scalar loads)
+};
+
+// kernels / launchers (defined in the .hip files)
+void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);
+void launch_preprocess(const PreprocessParams& pp, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* colors, const float* cov3D_precomp, const float* beams,
+                       int* radii, int* radii_xy, GeomView g, bool filter_only, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
+
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s);
+// sorts (key,val) pairs on key bits [0,end_bit); result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
+int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
+                            uint32_t* scratch, hipStream_t s);
+void launch_gather_counts(const uint32_t* ids_sorted, const uint32_t* tcount, uint32_t* cnt_sorted, size_t P, hipStream_t s);
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* cnt_sorted, const uint32_t* off_sorted,
+                           const uint32_t* rowspan, const uint32_t* xspan, size_t P, TileGrid grid,
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s);
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s);
+
+struct RenderFwdArgs {
+    TileGrid grid;
+    const uint2* ranges; const uint32_t* point_list; const float4* rec; const uint32_t* rowspan;
+    const float2* coltab; const float2* rowtab;
+    const float* bg;          // device [2] or nullptr (= 0)
+    const float* T_in;        // nullptr = 1
+    float* final_T; uint32_t* n_contrib; float* T_pass;
+    float* out_color; float* out_depth; float* out_occ;
+    int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
+};
+void launch_render_forward(const RenderFwdArgs& a, hipStream_t s);
+
+struct RenderBwdArgs {
+    TileGrid grid;
+    const uint2* ranges; const uint32_t* point_list; const float4* rec; const uint32_t* rowspan;
+    const float2* coltab; const float2* rowtab;
+    const float* bg;
+    const float* final_T; const uint32_t* n_contrib;
+    const float* T_final_global;   // nullptr = final_T (single GPU)
+    const float* behind;           // nullptr or f32[3*N]: colour0, colour1, depth sums of farther shells
+    const float* dL_dpix; const float* dL_ddepth; const float* dL_docc;
+    float* gacc;                   // [16P], zeroed: slots 0-2 mean2D.xyz, 3-5 conic A,B,C, 6 opacity, 7-8 colour,
+                                   //               9 range, 10-12 du1, 13-15 du2
+};
+void launch_render_backward(const RenderBwdArgs& a, hipStream_t s);
+
+struct GaussBwdArgs {
+    int P; float scale_modifier; const float* view;   // device pointer
+    const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const int* radii;
+    const float* gacc;             // packed sums from the backward blend
+    float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepths;
+    float* dL_dbasis_u1; float* dL_dbasis_u2;
+    float* dL_dsphere; float* dL_dmean3D; float* dL_dcov3D; float* dL_dscale; float* dL_drot;
+};
+void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s);
+
+}  // namespace lg

@@ -1,0 +1,404 @@
+// preprocess.hip -- per-Gaussian streaming kernels (gfx950).
+//
+//   k_setup_tables      per-row / per-column ray tables
+//   k_preprocess        K1 (R3/cr/forward.cu:256-384) and, with FILTER, K2 (:388-497)
+//   k_mark_visible      K11 (R3/cr/rasterizer_impl.cu:54-66)
+//   k_gaussian_backward K9 + K10 fused (R3/cr/backward.cu:157-382, :453-532, :385-448)
+//
+// All of them are one-thread-per-Gaussian HBM streams: 44 B in, <= 100 B out per Gaussian for
+// preprocess.  The arithmetic is a re-derivation (vector form), not a transcription: the
+// reference builds GLM 3x3 matrices T = W*P and T^T Sigma T; here the 2x2 footprint is
+// t_i^T Sigma t_j with t_i = Rv^T u_i the world-space tangent directions (two symmetric
+// mat-vecs and three dots), and the backward is written as vector-Jacobian products.
+#include "lidargs_common.h"
+
+namespace lg {
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 scale3(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 add3(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+
+// A v with A[r][k] = view[4r+k]  (= Rv^T v: view-space direction -> world space)
+__device__ __forceinline__ float3 view_to_world(const float* vm, float3 v) {
+    return f3(vm[0] * v.x + vm[1] * v.y + vm[2] * v.z,
+              vm[4] * v.x + vm[5] * v.y + vm[6] * v.z,
+              vm[8] * v.x + vm[9] * v.y + vm[10] * v.z);
+}
+// A^T v (world -> view rotation)
+__device__ __forceinline__ float3 world_to_view_dir(const float* vm, float3 v) {
+    return f3(vm[0] * v.x + vm[4] * v.y + vm[8] * v.z,
+              vm[1] * v.x + vm[5] * v.y + vm[9] * v.z,
+              vm[2] * v.x + vm[6] * v.y + vm[10] * v.z);
+}
+
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+__device__ __forceinline__ float3 symmul(const Sym3& S, float3 v) {
+    return f3(S.xx * v.x + S.xy * v.y + S.xz * v.z,
+              S.xy * v.x + S.yy * v.y + S.yz * v.z,
+              S.xz * v.x + S.yz * v.y + S.zz * v.z);
+}
+
+// Columns r_k of the standard rotation matrix of quaternion (r,x,y,z); NOT normalised, as the
+// reference (R3/cr/forward.cu:228).  Sigma = sum_k s_k^2 r_k r_k^T.
+__device__ __forceinline__ void quat_columns(float4 q, float3& c0, float3& c1, float3& c2) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    c0 = f3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + r * z), 2.f * (x * z - r * y));
+    c1 = f3(2.f * (x * y - r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + r * x));
+    c2 = f3(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+__device__ __forceinline__ Sym3 covariance_world(float3 s, float4 q) {
+    float3 c0, c1, c2;
+    quat_columns(q, c0, c1, c2);
+    // rows of M = S R^T are m_k = s_k r_k ; Sigma_ij = sum_k m_k[i] m_k[j]
+    float3 m0 = scale3(c0, s.x), m1 = scale3(c1, s.y), m2 = scale3(c2, s.z);
+    Sym3 S;
+    S.xx = m0.x * m0.x + m1.x * m1.x + m2.x * m2.x;
+    S.xy = m0.x * m0.y + m1.x * m1.y + m2.x * m2.y;
+    S.xz = m0.x * m0.z + m1.x * m1.z + m2.x * m2.z;
+    S.yy = m0.y * m0.y + m1.y * m1.y + m2.y * m2.y;
+    S.yz = m0.y * m0.z + m1.y * m1.z + m2.y * m2.z;
+    S.zz = m0.z * m0.z + m1.z * m1.z + m2.z * m2.z;
+    return S;
+}
+
+// Tangent basis at dir (R3/cr/forward.cu:95-119): u1 = normalize(dir.y,-dir.x,0), u2 = dir x u1.
+// A zero vector stays zero (poles).
+__device__ __forceinline__ void tangent_basis(float3 dir, float3& u1, float3& u2) {
+    u1 = f3(dir.y, -dir.x, 0.f);
+    float l = sqrtf(u1.x * u1.x + u1.y * u1.y);
+    if (l > 0.f) { u1.x /= l; u1.y /= l; }
+    u2 = f3(dir.y * u1.z - dir.z * u1.y, dir.z * u1.x - dir.x * u1.z, dir.x * u1.y - dir.y * u1.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_setup_tables(const float* __restrict__ beams, int W, int H,
+                               float2* __restrict__ coltab, float2* __restrict__ rowtab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float pi_f = 3.14159265358979323846f;
+    if (i < W) {
+        // R3/cr/forward.cu:590: evaluated in double, rounded to float, then float cos/sin
+        const double b = -((double)(float)i - (double)(float)W / 2.0) / (double)(float)W * 2.0 * (double)pi_f;
+        const float beta = (float)b;
+        coltab[i] = make_float2(cosf(beta), sinf(beta));
+    }
+    if (i < H) {
+        const float alp = beams[H - 1 - i];     // R3/cr/forward.cu:589
+        rowtab[i] = make_float2(cosf(alp), sinf(alp));
+    }
+}
+
+void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s) {
+    const int n = W > H ? W : H;
+    hipLaunchKernelGGL(k_setup_tables, dim3((n + 255) / 256), dim3(256), 0, s, beams, W, H, img.coltab, img.rowtab);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PreKernelArgs {
+    PreprocessParams pp;
+    const float* means3D; const float* scales; const float* rotations; const float* opacities;
+    const float* colors; const float* cov3D_precomp; const float* beams;
+    int* radii; int* radii_xy;
+    float4* rec; uint32_t* rowspan; uint32_t* xspan; uint32_t* dkey; uint32_t* ids; uint32_t* tcount; uint32_t* ref_tiles;
+};
+
+template <bool FILTER>
+__global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const PreprocessParams& pp = a.pp;
+    if (idx >= pp.P) return;
+
+    int out_radius = 0, rx = 0, ry = 0;
+    uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0;
+    float4 r0, r1, r2, r3;
+    bool live = false;
+
+    do {
+        const float3 pw = f3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        const float* vm = pp.view;
+        const float3 p = f3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12],
+                            vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+                            vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+        const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+        if (dist >= pp.far_f || dist <= pp.near_f) break;            // R3/cr/forward.cu:304
+        if (!(dist >= pp.shell_lo && dist < pp.shell_hi)) break;     // range shell (multi-GPU only)
+
+        Sym3 S;
+        if (a.cov3D_precomp) {
+            const float* c = a.cov3D_precomp + 6 * (size_t)idx;
+            S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
+        } else {
+            const float m = pp.scale_modifier;
+            const float3 sc = f3(m * a.scales[3 * idx], m * a.scales[3 * idx + 1], m * a.scales[3 * idx + 2]);
+            const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+            S = covariance_world(sc, q);
+        }
+
+        const float3 dir = f3(p.x / dist, p.y / dist, p.z / dist);
+        float3 u1, u2;
+        tangent_basis(dir, u1, u2);
+        // footprint in the tangent plane: cov_ij = t_i^T Sigma t_j, t_i = world-space tangent
+        const float3 t1 = view_to_world(vm, u1), t2 = view_to_world(vm, u2);
+        const float3 St1 = symmul(S, t1), St2 = symmul(S, t2);
+        const float d2 = dist * dist;
+        const float ca = (dot3(t1, St1) + 0.01f) / d2;               // :165-166 low-pass, :319-321 /dist^2
+        const float cb = dot3(t1, St2) / d2;
+        const float cc = (dot3(t2, St2) + 0.01f) / d2;
+        // keep the two cancellation-prone expressions un-contracted so they round as written
+        const float det = __fsub_rn(__fmul_rn(ca, cc), __fmul_rn(cb, cb));
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float conA = cc * det_inv, conB = -cb * det_inv, conC = ca * det_inv;
+        const float mid = 0.5f * (ca + cc);
+        // :328-330 double max / sqrt (the 1e-9 floor is almost always the active branch)
+        const double disc = sqrt(fmax(1e-9, (double)__fsub_rn(__fmul_rn(mid, mid), det)));
+        const float lambda1 = (float)((double)mid + disc);
+        const float lambda2 = (float)((double)mid - disc);
+        const float my_radius = (float)sqrt(fmax(1e-9, (double)fmaxf(lambda1, lambda2)));
+
+        const float pi_f = 3.14159265358979323846f;
+        const float p_c = (pi_f - atan2f(p.y, p.x)) / pp.col_step;  // :333-334
+        float alpha;
+        if (!FILTER) alpha = atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y));                                           // :336
+        else alpha = (float)atan2((double)p.z, sqrt(fmax(1e-9, (double)(p.x * p.x + p.y * p.y))));                // :456
+
+        // beam row: clamp at the ends, else first beam >= alpha (R3/cr/auxiliary.h:41-63)
+        const int H = pp.H;
+        int bi;
+        if (alpha >= a.beams[H - 1]) bi = H - 1;
+        else if (alpha <= a.beams[0]) bi = 0;
+        else {
+            int lo = 0, hi = H;
+            while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] < alpha) lo = md + 1; else hi = md; }
+            bi = lo;
+        }
+        float before, after, p_r;
+        const float guard = 0.002f * 2;                                // Ray_Divergence_Angle*2, :22/:347/:356
+        if (bi > 0) {
+            before = a.beams[bi - 1]; after = a.beams[bi];
+            p_r = (float)(bi - 1) + (alpha - before) / (after - before);
+            if (alpha > (after + guard)) break;
+        } else {
+            before = a.beams[0]; after = a.beams[1];
+            p_r = (float)(bi + 1) + (alpha - after) / (after - before);
+            if (alpha < (before - guard)) break;
+        }
+        p_r = (float)H - p_r - 1.f;                                    // :359
+
+        ry = (int)ceilf(3.f * my_radius / tanf(fabsf(after - before)));   // :361
+        rx = (int)ceilf(3.f * my_radius / pp.tan_col_step);            // :362
+
+        // reference rect in 16x1 tiles (R3/cr/auxiliary.h:80-92); x truncates, y rounds
+        const int gx = pp.tiles_x, gy = H;
+        const int xmin = min(gx, max(0, (int)((p_c - (float)rx) / 16.f)));
+        const int xmax = min(gx, max(0, (int)((p_c + (float)rx + 15.f) / 16.f)));
+        const int ymin = min(gy, max(0, (int)roundf(p_r - (float)ry)));
+        const int ymax = min(gy, max(0, (int)fmaxf(roundf(p_r + (float)ry), roundf(p_r) + 1.f)));
+        if ((xmax - xmin) * (ymax - ymin) == 0) break;
+
+        live = true;
+        out_radius = max(rx, ry);
+        if (FILTER) break;
+
+        reftiles = (uint32_t)((xmax - xmin) * (ymax - ymin));
+        const int ty0 = ymin / pp.TH, ty1 = (ymax - 1) / pp.TH;
+        tiles = (uint32_t)((xmax - xmin) * (ty1 - ty0 + 1));
+        rspan = (uint32_t)ymin | ((uint32_t)ymax << 16);
+        xsp = (uint32_t)xmin | ((uint32_t)xmax << 16);
+        key = __float_as_uint(dist);
+
+        // scaled bases: d.x = delta.u1 / (u1.u1) == delta.u1'  (R3/cr/forward.cu:593-597)
+        const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
+        const float i1 = uu1 > 0.f ? 1.f / uu1 : 0.f, i2 = uu2 > 0.f ? 1.f / uu2 : 0.f;
+        r0 = make_float4(dir.x, dir.y, dir.z, dist);
+        r1 = make_float4(u1.x * i1, u1.y * i1, u1.z * i1, conA);
+        r2 = make_float4(u2.x * i2, u2.y * i2, u2.z * i2, conB);
+        r3 = make_float4(conC, a.opacities[idx], a.colors[2 * idx], a.colors[2 * idx + 1]);
+    } while (false);
+
+    a.radii[idx] = out_radius;
+    if (live) { a.radii_xy[2 * idx] = rx; a.radii_xy[2 * idx + 1] = ry; }
+    if (FILTER) return;
+    a.dkey[idx] = key;
+    a.ids[idx] = (uint32_t)idx;
+    a.tcount[idx] = tiles;
+    a.ref_tiles[idx] = reftiles;
+    if (live) {
+        a.rowspan[idx] = rspan;
+        a.xspan[idx] = xsp;
+        float4* r = a.rec + 4 * (size_t)idx;
+        r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+    }
+}
+
+void launch_preprocess(const PreprocessParams& pp, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* colors, const float* cov3D_precomp, const float* beams,
+                       int* radii, int* radii_xy, GeomView g, bool filter_only, hipStream_t s) {
+    PreKernelArgs a;
+    a.pp = pp;
+    a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.colors = colors;
+    a.cov3D_precomp = cov3D_precomp; a.beams = beams; a.radii = radii; a.radii_xy = radii_xy;
+    a.rec = g.rec; a.rowspan = g.rowspan; a.xspan = g.xspan; a.dkey = g.key_a; a.ids = g.id_a; a.tcount = g.tcount;
+    a.ref_tiles = g.ref_tiles;
+    const dim3 grid((pp.P + 255) / 256), block(256);
+    if (filter_only) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict__ vm, unsigned char* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    const float vz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+    present[i] = (vz <= 0.2f) ? 0 : 1;      // R3/cr/auxiliary.h:190
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 + K10 fused.  Inputs are the per-Gaussian sums the backward blend produced (gacc, 64 B per
+// Gaussian): dL/dconic (A,B,C), dL/du1, dL/du2 (direct part), (gx,gy) = dL/dmean2D.xy, dL/drange,
+// dL/dopacity, dL/dcolour.  dL/dsphere is NOT accumulated per pixel: by linearity it equals
+//   gx*u1' + gy*u2' (R3/cr/backward.cu:759-777 sums exactly these per-pixel terms).
+__global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    const float* vm = a.view;
+
+    const float3 pw = f3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const float3 d = f3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12],
+                        vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+                        vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+    const float n2 = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float dist = sqrtf(n2);
+    if (dist <= 0.f) return;                                          // R3/cr/backward.cu:488
+    const float3 dir = f3(d.x / dist, d.y / dist, d.z / dist);
+    float3 u1, u2;
+    tangent_basis(dir, u1, u2);
+
+    Sym3 S;
+    float3 sc = f3(0, 0, 0); float4 q = make_float4(1, 0, 0, 0);
+    const bool have_sr = (a.cov3D_precomp == nullptr);
+    if (!have_sr) {
+        const float* c = a.cov3D_precomp + 6 * (size_t)idx;
+        S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
+    } else {
+        const float m = a.scale_modifier;
+        sc = f3(m * a.scales[3 * idx], m * a.scales[3 * idx + 1], m * a.scales[3 * idx + 2]);
+        q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+        S = covariance_world(sc, q);
+    }
+    const float3 t1 = view_to_world(vm, u1), t2 = view_to_world(vm, u2);
+    const float3 St1 = symmul(S, t1), St2 = symmul(S, t2);
+    const float _a = dot3(t1, St1) + 0.01f, _b = dot3(t1, St2), _c = dot3(t2, St2) + 0.01f;
+    const float inv_d2 = 1.f / (dist * dist);
+    const float ca = inv_d2 * _a, cb = inv_d2 * _b, cc = inv_d2 * _c;
+
+    // unpack the blend kernel's packed sums into the caller's arrays (the reference accumulates
+    // straight into them with atomics, R3/cr/backward.cu:702-788)
+    const float4* acc = reinterpret_cast<const float4*>(a.gacc) + 4 * (size_t)idx;
+    const float4 q0 = acc[0], q1 = acc[1], q2 = acc[2], q3 = acc[3];
+    const float gx = q0.x, gy = q0.y;
+    const float gA = q0.w, gB = q1.x, gC = q1.y;
+    const float gdep = q2.y;
+    const float3 du1 = f3(q2.z, q2.w, q3.x), du2 = f3(q3.y, q3.z, q3.w);
+    a.dL_dmean2D[4 * idx] = gx; a.dL_dmean2D[4 * idx + 1] = gy; a.dL_dmean2D[4 * idx + 2] = q0.z; a.dL_dmean2D[4 * idx + 3] = 0.f;
+    a.dL_dconic[4 * idx] = gA; a.dL_dconic[4 * idx + 1] = gB; a.dL_dconic[4 * idx + 2] = 0.f; a.dL_dconic[4 * idx + 3] = gC;
+    a.dL_dopacity[idx] = q1.z;
+    a.dL_dcolor[2 * idx] = q1.w; a.dL_dcolor[2 * idx + 1] = q2.x;
+    a.dL_ddepths[idx] = gdep;
+    a.dL_dbasis_u1[3 * idx] = du1.x; a.dL_dbasis_u1[3 * idx + 1] = du1.y; a.dL_dbasis_u1[3 * idx + 2] = du1.z;
+    a.dL_dbasis_u2[3 * idx] = du2.x; a.dL_dbasis_u2[3 * idx + 1] = du2.y; a.dL_dbasis_u2[3 * idx + 2] = du2.z;
+
+    // conic -> covariance, with the reference's 1/(denom^2 + 1e-7) damping (R3/cr/backward.cu:237)
+    const float denom = __fsub_rn(__fmul_rn(ca, cc), __fmul_rn(cb, cb));
+    const float k = 1.0f / ((denom * denom) + 0.0000001f);
+    float da = k * (-cc * cc * gA + 2.f * cb * cc * gB + (denom - ca * cc) * gC);
+    float dc = k * (-ca * ca * gC + 2.f * ca * cb * gB + (denom - ca * cc) * gA);
+    float db = k * 2.f * (cb * cc * gA - (denom + 2.f * cb * cb) * gB + ca * cb * gC);
+    // range dependence of the /dist^2 factor (:249-252)
+    const float dist4 = n2 * n2;
+    const float wsum = -2.f * (da * _a + db * _b + dc * _c) / dist4;
+    float3 g_mean = f3(wsum * d.x, wsum * d.y, wsum * d.z);
+    da *= inv_d2; dc *= inv_d2; db *= inv_d2;                         // :254-256
+
+    // dL/dSigma, packed upper triangle with doubled off-diagonals (:262-272)
+    float* gS = a.dL_dcov3D + 6 * (size_t)idx;
+    const float S00 = t1.x * t1.x * da + t1.x * t2.x * db + t2.x * t2.x * dc;
+    const float S11 = t1.y * t1.y * da + t1.y * t2.y * db + t2.y * t2.y * dc;
+    const float S22 = t1.z * t1.z * da + t1.z * t2.z * db + t2.z * t2.z * dc;
+    const float S01 = 2.f * t1.x * t1.y * da + (t1.x * t2.y + t1.y * t2.x) * db + 2.f * t2.x * t2.y * dc;
+    const float S02 = 2.f * t1.x * t1.z * da + (t1.x * t2.z + t1.z * t2.x) * db + 2.f * t2.x * t2.z * dc;
+    const float S12 = 2.f * t1.z * t1.y * da + (t1.y * t2.z + t1.z * t2.y) * db + 2.f * t2.y * t2.z * dc;
+    gS[0] = S00; gS[1] = S01; gS[2] = S02; gS[3] = S11; gS[4] = S12; gS[5] = S22;
+
+    // dL/dt_i = 2 (Sigma t_i) d{a,c} + (Sigma t_j) db ; dL/du_i = A^T dL/dt_i + direct part (:281-307)
+    const float3 gt1 = add3(scale3(St1, 2.f * da), scale3(St2, db));
+    const float3 gt2 = add3(scale3(St2, 2.f * dc), scale3(St1, db));
+    float3 gu1 = world_to_view_dir(vm, gt1), gu2 = world_to_view_dir(vm, gt2);
+    gu1.x += du1.x; gu1.y += du1.y;
+    gu2.x += du2.x; gu2.y += du2.y; gu2.z += du2.z;
+
+    // basis -> dir, with the reference's double epsilons (:336-354)
+    const float rho2 = dir.x * dir.x + dir.y * dir.y;
+    const float i32 = (float)(1.0f / ((double)sqrtf(rho2 * rho2 * rho2) + 1e-9));
+    const float irho = (float)(1.0 / ((double)sqrtf(rho2) + 1e-9));
+    float3 gdir;
+    gdir.x = i32 * (-dir.y * dir.x * gu1.x - dir.y * dir.y * gu1.y + dir.z * dir.y * dir.y * gu2.x - dir.x * dir.y * dir.z * gu2.y) - dir.x * irho * gu2.z;
+    gdir.y = i32 * (dir.x * dir.x * gu1.x + dir.x * dir.y * gu1.y - dir.x * dir.y * dir.z * gu2.x + dir.z * dir.x * dir.x * gu2.y) - dir.y * irho * gu2.z;
+    gdir.z = irho * (dir.x * gu2.x + dir.y * gu2.y);
+    // dir -> d : (|d|^2 I - d d^T) / (|d|^3 + 1e-9)  (:312-333)
+    const float id3e = (float)(1.0f / ((double)sqrtf(n2 * n2 * n2) + 1e-9));
+    const float dg = dot3(d, gdir);
+    g_mean = add3(g_mean, scale3(f3(n2 * gdir.x - d.x * dg, n2 * gdir.y - d.y * dg, n2 * gdir.z - d.z * dg), id3e));
+
+    // K10: sphere-mean and range terms (R3/cr/backward.cu:490-522)
+    const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
+    const float i1 = uu1 > 0.f ? 1.f / uu1 : 0.f, i2 = uu2 > 0.f ? 1.f / uu2 : 0.f;
+    const float3 gs = add3(scale3(u1, gx * i1), scale3(u2, gy * i2));
+    a.dL_dsphere[3 * idx] = gs.x; a.dL_dsphere[3 * idx + 1] = gs.y; a.dL_dsphere[3 * idx + 2] = gs.z;
+    const float id3 = 1.0f / sqrtf(n2 * n2 * n2);
+    const float dgs = dot3(d, gs);
+    float3 v;
+    v.x = g_mean.x + (n2 * gs.x - d.x * dgs) * id3 + gdep * dir.x;
+    v.y = g_mean.y + (n2 * gs.y - d.y * dgs) * id3 + gdep * dir.y;
+    v.z = g_mean.z + (n2 * gs.z - d.z * dgs) * id3 + gdep * dir.z;
+    const float3 gw = view_to_world(vm, v);                            // transformVec4x3Transpose (:525)
+    a.dL_dmean3D[3 * idx] = gw.x; a.dL_dmean3D[3 * idx + 1] = gw.y; a.dL_dmean3D[3 * idx + 2] = gw.z;
+
+    if (a.scales) {
+        // Sigma = sum_k s_k^2 r_k r_k^T, G = symmetric gradient (off-diagonals halved, :415-419)
+        if (!have_sr) {
+            const float m = a.scale_modifier;
+            sc = f3(m * a.scales[3 * idx], m * a.scales[3 * idx + 1], m * a.scales[3 * idx + 2]);
+            q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+        }
+        Sym3 G; G.xx = S00; G.xy = 0.5f * S01; G.xz = 0.5f * S02; G.yy = S11; G.yz = 0.5f * S12; G.zz = S22;
+        float3 c0, c1, c2;
+        quat_columns(q, c0, c1, c2);
+        const float3 h0 = symmul(G, c0), h1 = symmul(G, c1), h2 = symmul(G, c2);
+        // dL/ds_k = 2 s_k r_k^T G r_k  (w.r.t. the MODIFIED scale, as the reference, :428-432)
+        a.dL_dscale[3 * idx] = 2.f * sc.x * dot3(c0, h0);
+        a.dL_dscale[3 * idx + 1] = 2.f * sc.y * dot3(c1, h1);
+        a.dL_dscale[3 * idx + 2] = 2.f * sc.z * dot3(c2, h2);
+        // F[k][c] = dL/dR[c][k] = 2 s_k^2 (G r_k)[c]
+        const float3 F0 = scale3(h0, 2.f * sc.x * sc.x), F1 = scale3(h1, 2.f * sc.y * sc.y), F2 = scale3(h2, 2.f * sc.z * sc.z);
+        const float F00 = F0.x, F01 = F0.y, F02 = F0.z, F10 = F1.x, F11 = F1.y, F12 = F1.z, F20 = F2.x, F21 = F2.y, F22 = F2.z;
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        float* gq = a.dL_drot + 4 * (size_t)idx;                      // :440-447, no normalisation Jacobian
+        gq[0] = 2.f * z * (F01 - F10) + 2.f * y * (F20 - F02) + 2.f * x * (F12 - F21);
+        gq[1] = 2.f * y * (F10 + F01) + 2.f * z * (F20 + F02) + 2.f * r * (F12 - F21) - 4.f * x * (F22 + F11);
+        gq[2] = 2.f * x * (F10 + F01) + 2.f * r * (F20 - F02) + 2.f * z * (F12 + F21) - 4.f * y * (F22 + F00);
+        gq[3] = 2.f * r * (F01 - F10) + 2.f * x * (F20 + F02) + 2.f * y * (F12 + F21) - 4.f * z * (F11 + F00);
+    }
+}
+
+void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_gaussian_backward, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace lg

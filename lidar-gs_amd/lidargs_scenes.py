@@ -1,0 +1,122 @@
+"""Synthetic LiDAR Gaussian scenes.  numpy only, seeded, deterministic.
+
+No dataset ships with the reference (its .gitignore excludes `data`), so every parity case
+and bench workload is generated here.  Conventions follow the reference's call site
+gaussian_renderer/__init__.py:145-179: colours [P,2] (intensity, ray-drop), opacities [P,1],
+scales [P,3], unit quaternions [P,4] as (r,x,y,z), viewmatrix = TRANSPOSED world->lidar 4x4
+(scene/cameras.py:56), beam_inclinations ascending radians, lidar_far=80, lidar_near=0.
+"""
+import numpy as np
+
+BASELINE_CONFIGS = {
+    # name: (scene kind, P, H, W, seed)  -- BASELINE.json `configs`, SURVEY.md section 8 sizes
+    "cfg1": ("shell", 10_000, 16, 512, 1),
+    "cfg2": ("street", 500_000, 64, 2650, 2),
+    "cfg3": ("street", 2_000_000, 64, 2650, 3),
+    "cfg4": ("shell", 8_000_000, 128, 4096, 4),
+}
+
+
+def beam_inclinations(H, lo_deg=-17.6, hi_deg=2.4):
+    """Waymo-top-like vertical FOV, ascending radians (R3/cr/forward.cu:337 needs ascending)."""
+    return np.deg2rad(np.linspace(lo_deg, hi_deg, H)).astype(np.float32)
+
+
+def _rand_quat(rng, n):
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q
+
+
+def _quat_mul(a, b):
+    ar, ax, ay, az = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    br, bx, by, bz = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    return np.stack([ar * br - ax * bx - ay * by - az * bz,
+                     ar * bx + ax * br + ay * bz - az * by,
+                     ar * by - ax * bz + ay * br + az * bx,
+                     ar * bz + ax * by - ay * bx + az * br], axis=1)
+
+
+def rigid_viewmatrix(rng=None, max_angle=0.3, max_shift=1.0):
+    """[4,4] float32 transposed world->lidar matrix; identity when rng is None."""
+    V = np.eye(4, dtype=np.float64)
+    if rng is not None:
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(-max_angle, max_angle)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        t = rng.uniform(-max_shift, max_shift, size=3)
+        V[:3, :3] = R.T       # row-vector convention: p_view = [p,1] @ V
+        V[3, :3] = t
+    return V.astype(np.float32)
+
+
+def shell_scene(P, H, seed):
+    """Isotropic 'shell': r~U(5,60), azimuth U(-pi,pi), elevation inside the beam fan."""
+    rng = np.random.default_rng(seed)
+    beams = beam_inclinations(H)
+    r = rng.uniform(5.0, 60.0, P)
+    az = rng.uniform(-np.pi, np.pi, P)
+    el = rng.uniform(float(beams[0]), float(beams[-1]), P)
+    xyz = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], axis=1)
+    scales = 0.1 * np.exp(0.5 * rng.normal(size=(P, 3)))
+    rots = _rand_quat(rng, P)
+    return _pack(rng, xyz, scales, rots, beams)
+
+
+def street_scene(P, H, seed):
+    """Waymo-static stand-in: 70% ground z=-2 (r<75), 25% two walls y=+-12, 5% clutter;
+    flat surfels (0.15,0.15,0.02)*lognormal(0.4) aligned with the surface normal."""
+    rng = np.random.default_rng(seed)
+    beams = beam_inclinations(H)
+    n_g = int(0.70 * P); n_w = int(0.25 * P); n_c = P - n_g - n_w
+    # ground: uniform in area inside a 75 m disc
+    rg = 75.0 * np.sqrt(rng.uniform(0.0, 1.0, n_g)); ag = rng.uniform(-np.pi, np.pi, n_g)
+    ground = np.stack([rg * np.cos(ag), rg * np.sin(ag), np.full(n_g, -2.0)], axis=1)
+    qg = np.stack([np.cos(ag * 0.5), np.zeros(n_g), np.zeros(n_g), np.sin(ag * 0.5)], axis=1)  # yaw only
+    # walls: y = +-12, x in [-75,75], z in [-2,6]; local z -> world y (rotate 90deg about x), random spin
+    side = rng.choice([-1.0, 1.0], n_w)
+    walls = np.stack([rng.uniform(-75.0, 75.0, n_w), 12.0 * side, rng.uniform(-2.0, 6.0, n_w)], axis=1)
+    spin = rng.uniform(-np.pi, np.pi, n_w)
+    q_spin = np.stack([np.cos(spin * 0.5), np.zeros(n_w), np.zeros(n_w), np.sin(spin * 0.5)], axis=1)
+    q_tilt = np.tile(np.array([[np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]]), (n_w, 1))
+    qw = _quat_mul(q_tilt, q_spin)
+    # clutter: isotropic blobs
+    rc = rng.uniform(5.0, 60.0, n_c); ac = rng.uniform(-np.pi, np.pi, n_c)
+    ec = rng.uniform(float(beams[0]), float(beams[-1]), n_c)
+    clutter = np.stack([rc * np.cos(ec) * np.cos(ac), rc * np.cos(ec) * np.sin(ac), rc * np.sin(ec)], axis=1)
+    qc = _rand_quat(rng, n_c)
+    xyz = np.concatenate([ground, walls, clutter], axis=0)
+    rots = np.concatenate([qg, qw, qc], axis=0)
+    scales = np.array([[0.15, 0.15, 0.02]]) * np.exp(0.4 * rng.normal(size=(P, 3)))
+    perm = rng.permutation(P)
+    return _pack(rng, xyz[perm], scales[perm], rots[perm], beams)
+
+
+def _pack(rng, xyz, scales, rots, beams):
+    P = xyz.shape[0]
+    return dict(
+        means3D=xyz.astype(np.float32),
+        scales=scales.astype(np.float32),
+        rotations=rots.astype(np.float32),
+        opacities=rng.uniform(0.1, 1.0, (P, 1)).astype(np.float32),
+        colors=rng.uniform(0.0, 1.0, (P, 2)).astype(np.float32),
+        beams=beams,
+        bg=np.zeros(2, np.float32),
+        viewmatrix=rigid_viewmatrix(None),
+    )
+
+
+def make_scene(kind, P, H, seed, random_view=False):
+    s = shell_scene(P, H, seed) if kind == "shell" else street_scene(P, H, seed)
+    if random_view:
+        s["viewmatrix"] = rigid_viewmatrix(np.random.default_rng(seed + 7))
+    return s
+
+
+def upstream_grads(H, W, seed):
+    """N(0,1) upstream gradients for (color[2,H,W], depth[1,H,W], occ[1,H,W]); seed+100 rule."""
+    rng = np.random.default_rng(seed + 100)
+    return (rng.normal(size=(2, H, W)).astype(np.float32),
+            rng.normal(size=(1, H, W)).astype(np.float32),
+            rng.normal(size=(1, H, W)).astype(np.float32))

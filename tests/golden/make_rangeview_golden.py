@@ -1,0 +1,68 @@
+"""Generate tests/golden/rangeview_golden.npz by EXECUTING the reference's own numpy range-view code.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_rangeview_golden.py
+
+The reference module utils/lidar_utils.py cannot be imported (its import builds
+extern/chamfer3D into the read-only reference tree), so the five pure
+numpy functions are pulled out of the file's AST at generation time and exec'd in a scratch
+namespace.  Nothing of the reference's source text is written to this repository: the .npz
+holds inputs and outputs only.
+
+Functions executed (reference file:line):
+  find_closest_label               utils/lidar_utils.py:33-49
+  lidar_to_pano_with_intensities   utils/lidar_utils.py:51-110
+  pano_to_lidar_with_intensities   utils/lidar_utils.py:171-214
+  pano_to_lidar                    utils/lidar_utils.py:216-232
+  get_beam_inclinations            utils/lidar_utils.py:296-299
+"""
+import ast
+import os
+
+import numpy as np
+
+REF = "/root/reference/utils/lidar_utils.py"
+WANTED = ["find_closest_label", "lidar_to_pano_with_intensities", "pano_to_lidar_with_intensities",
+          "pano_to_lidar", "get_beam_inclinations"]
+
+
+def load_reference_functions():
+    tree = ast.parse(open(REF).read(), REF)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in WANTED]
+    assert sorted(n.name for n in body) == sorted(WANTED), [n.name for n in body]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), REF, "exec"), ns)
+    return ns
+
+
+def main():
+    ns = load_reference_functions()
+    out = {}
+    for tag, (H, W, N, seed) in {"a": (16, 512, 3000, 11), "b": (64, 2650, 4000, 12)}.items():
+        rng = np.random.default_rng(seed)
+        if tag == "a":
+            beams = ns["get_beam_inclinations"](2.4, 20.0, H)                     # reference's own beam table
+        else:
+            beams = np.deg2rad(np.linspace(-17.6, 2.4, H)).astype(np.float32)
+        beams = np.ascontiguousarray(beams)
+        r = rng.uniform(3.0, 95.0, N)               # some beyond max_depth=80
+        az = rng.uniform(-np.pi, np.pi, N)
+        el = rng.uniform(float(beams[0]) - 0.05, float(beams[-1]) + 0.05, N)
+        pts = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el),
+                        rng.uniform(0, 1, N)], axis=1).astype(np.float32)
+        pano, inten = ns["lidar_to_pano_with_intensities"](pts, H, W, beam_inclinations=beams, max_depth=80)
+        back = ns["pano_to_lidar_with_intensities"](pano, inten, beam_inclinations=beams)
+        # every pixel of a constant-range pano -> one point per pixel (pixel -> ray convention)
+        rays = ns["pano_to_lidar"](np.full((H, W), 10.0), beam_inclinations=beams)
+        labels = np.array([ns["find_closest_label"](beams, a) for a in el], dtype=np.int64)
+        out.update({f"{tag}_H": H, f"{tag}_W": W, f"{tag}_beams": beams, f"{tag}_points": pts,
+                    f"{tag}_elev": el, f"{tag}_labels": labels, f"{tag}_pano": pano, f"{tag}_intensities": inten,
+                    f"{tag}_back": back, f"{tag}_rays": rays})
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rangeview_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()

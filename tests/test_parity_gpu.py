@@ -1,0 +1,163 @@
+"""GPU parity tests: the HIP path (through the drop-in package and the C ABI) against the CPU oracle
+on identical seeded inputs.  Sizes are chosen so that the oracle finishes in seconds.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import lidargs_scenes as sc
+from util import GRAD_KEYS_SR, hip_forward_backward, oracle_forward_backward, parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_radii(hip, ref):
+    """Integer outputs: bit-exact, except for Gaussians within an ulp of a ceil()/round() boundary
+    (device atan2f/tanf vs host libm); those are counted and must stay below 1e-4 of P (min 1)."""
+    mism = int((hip != ref).sum())
+    allowed = max(1, int(1e-4 * ref.size))
+    print(f"[parity] radii mismatches: {mism} of {ref.size} (allowed {allowed})")
+    assert mism <= allowed
+    assert ((hip > 0) != (ref > 0)).sum() <= allowed
+
+
+def _compare_all(hip, ref, keys):
+    _check_radii(hip["radii"], ref["radii"])
+    parity("color", hip["color"], ref["color"])
+    parity("depth", hip["depth"], ref["depth"])
+    parity("occ", hip["occ"], ref["occ"])
+    for k in keys:
+        parity(k, hip[k], ref[k])
+
+
+CASES = [
+    # name, kind, P, H, W, seed, random_view, bg
+    ("cfg1_shell", "shell", 10_000, 16, 512, 1, False, (0.0, 0.0)),
+    ("cfg1_view", "shell", 10_000, 16, 512, 1, True, (0.0, 0.0)),
+    ("street_bg", "street", 20_000, 16, 512, 2, True, (0.3, 0.7)),
+    ("ragged", "shell", 6_000, 18, 500, 3, True, (0.1, 0.0)),      # W % 16 != 0, H % 4 != 0
+    ("dense64", "street", 60_000, 64, 1000, 4, False, (0.0, 0.0)),  # long per-tile lists, early-out active
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_forward_backward_matches_oracle(case, hip_lib_built):
+    name, kind, P, H, W, seed, rv, bg = case
+    scene = sc.make_scene(kind, P, H, seed, random_view=rv)
+    scene["bg"] = np.array(bg, np.float32)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    hip = hip_forward_backward(scene, W, H, grads)
+    _compare_all(hip, ref, GRAD_KEYS_SR)
+
+
+def test_cov3d_precomp_path(hip_lib_built):
+    """cov3D_precomp instead of scales/rotations (R3/cr/forward.cu:307-310, backward :520)."""
+    P, H, W, seed = 5_000, 16, 512, 5
+    scene = sc.make_scene("shell", P, H, seed, random_view=True)
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(P, 3, 3)) * 0.1
+    S = A @ np.transpose(A, (0, 2, 1)) + 1e-3 * np.eye(3)
+    cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1).astype(np.float32)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads, cov3D_precomp=cov)
+    hip = hip_forward_backward(scene, W, H, grads, cov3D_precomp=cov)
+    _compare_all(hip, ref, ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D"))
+
+
+def test_scale_modifier_and_range_cull(hip_lib_built):
+    P, H, W, seed = 8_000, 16, 512, 6
+    scene = sc.make_scene("shell", P, H, seed)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads, far=40, near=10, scale_modifier=1.7)
+    hip = hip_forward_backward(scene, W, H, grads, far=40, near=10, scale_modifier=1.7)
+    assert (ref["radii"] == 0).sum() > 0.3 * P      # the cull is exercised
+    _compare_all(hip, ref, GRAD_KEYS_SR)
+
+
+def test_visible_filter_and_mark_visible(hip_lib_built):
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from oracle import lgo
+    from util import make_settings, to_torch
+    P, H, W, seed = 20_000, 64, 2650, 7
+    scene = sc.make_scene("street", P, H, seed, random_view=True)
+    st = to_torch(scene)
+    rast = GaussianRasterizer(make_settings(st, W, H))
+    radii = rast.visible_filter(means3D=st["means3D"], scales=st["scales"], rotations=st["rotations"]).cpu().numpy()
+    ref = lgo.visible_filter(scene["means3D"], scene["scales"], scene["rotations"], scene["viewmatrix"], scene["beams"], W, H)
+    _check_radii(radii, ref)
+    vis = rast.markVisible(st["means3D"]).cpu().numpy()
+    assert vis.dtype == np.bool_
+    np.testing.assert_array_equal(vis, lgo.mark_visible(scene["means3D"], scene["viewmatrix"]))
+
+
+def test_empty_and_all_culled(hip_lib_built):
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import make_settings, to_torch
+    H, W = 16, 512
+    scene = sc.make_scene("shell", 100, H, 8)
+    scene["bg"] = np.array([0.25, 0.5], np.float32)
+    st = to_torch(scene)
+    rast = GaussianRasterizer(make_settings(st, W, H))
+    # P == 0: outputs are all zeros, even with a background (R3/rasterize_points.cu:87)
+    e = lambda *s: torch.zeros(s, device="cuda")
+    c, d, o, r = rast(means3D=e(0, 3), means2D=e(0, 4), opacities=e(0, 1), colors_precomp=e(0, 2), scales=e(0, 3), rotations=e(0, 4))
+    assert c.shape == (2, H, W) and float(c.abs().max()) == 0.0 and r.numel() == 0
+    # everything beyond lidar_far: background only
+    far_scene = dict(st)
+    far_scene["means3D"] = st["means3D"] * 100.0
+    c, d, o, r = rast(means3D=far_scene["means3D"], means2D=e(100, 4), opacities=st["opacities"], colors_precomp=st["colors"],
+                      scales=st["scales"], rotations=st["rotations"])
+    assert int((r > 0).sum()) == 0
+    np.testing.assert_allclose(c[0].cpu().numpy(), 0.25)
+    np.testing.assert_allclose(c[1].cpu().numpy(), 0.5)
+    assert float(d.abs().max()) == 0.0 and float(o.abs().max()) == 0.0
+
+
+def test_argument_errors(hip_lib_built):
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import make_settings, to_torch
+    scene = sc.make_scene("shell", 10, 16, 9)
+    st = to_torch(scene)
+    rast = GaussianRasterizer(make_settings(st, 512, 16))
+    m2 = torch.zeros(10, 4, device="cuda")
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(means3D=st["means3D"], means2D=m2, opacities=st["opacities"], scales=st["scales"], rotations=st["rotations"])
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=st["means3D"], means2D=m2, opacities=st["opacities"], colors_precomp=st["colors"])
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        rast(means3D=st["means3D"][:, :2], means2D=m2, opacities=st["opacities"], colors_precomp=st["colors"],
+             scales=st["scales"], rotations=st["rotations"])
+    with pytest.raises(RuntimeError, match="precomputed Gaussian colors"):
+        # SHs without precomputed colours: the LiDAR build has NUM_CHANNELS != 3 (R3/cr/rasterizer_impl.cu:249-252)
+        rast(means3D=st["means3D"], means2D=m2, opacities=st["opacities"], shs=torch.zeros(10, 4, 3, device="cuda"),
+             scales=st["scales"], rotations=st["rotations"])
+
+
+@pytest.mark.parametrize("tile_rows", [8, 16])
+def test_tile_height_variants(tile_rows, hip_lib_built):
+    """The list-tile height (LIDARGS_TILE_ROWS) is an internal choice: results must not depend on it."""
+    import os, subprocess, sys, json, tempfile
+    code = r"""
+import sys, json, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import lidargs_scenes as sc
+from util import hip_forward_backward, oracle_forward_backward, parity, GRAD_KEYS_SR
+scene = sc.make_scene("street", 30000, 32, 10, random_view=True)
+grads = sc.upstream_grads(32, 800, 10)
+ref = oracle_forward_backward(scene, 800, 32, grads)
+hip = hip_forward_backward(scene, 800, 32, grads)
+for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+    parity(k, hip[k], ref[k])
+print("OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "lidar-gs_amd"), os.path.join(root, "tests"))
+    env = dict(os.environ, LIDARGS_TILE_ROWS=str(tile_rows))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "OK" in r.stdout
