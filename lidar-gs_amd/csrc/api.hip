@@ -21,9 +21,9 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local long long g_counters[6] = {0, 0, 0, 0, 0, 0};
-thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals
-thread_local hipStream_t g_last_stream = nullptr;
+long long g_counters[6] = {0, 0, 0, 0, 0, 0};
+uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals
+hipStream_t g_last_stream = nullptr;
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -87,7 +87,7 @@ struct Profiler {
         n++;
     }
 };
-thread_local Profiler g_prof;
+Profiler g_prof;   // process-wide: autograd runs backward on its own thread
 
 struct Common {
     int P, W, H;

@@ -228,9 +228,13 @@ __global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restri
             ty0 = (rs & 0xFFFFu) / (uint32_t)TH;
         }
     }
-    const uint32_t wave_base = __shfl(off, 0);
-    const uint32_t wave_total = __shfl(off + cnt, 63) - wave_base;    // offsets are exclusive and monotone
-    const uint32_t lo = off - wave_base;                              // local exclusive prefix
+    const bool valid = i < P;
+    const uint32_t wave_base = __shfl(off, 0);                        // lane 0 invalid => whole wave invalid => total 0
+    uint32_t wave_end = valid ? off + cnt : 0u;                       // offsets are exclusive and monotone
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_end = max(wave_end, (uint32_t)__shfl_xor((int)wave_end, o));
+    const uint32_t wave_total = wave_end > wave_base ? wave_end - wave_base : 0u;
+    const uint32_t lo = valid ? off - wave_base : 0xFFFFFFFFu;        // local exclusive prefix (+inf past the end)
     const uint32_t t_end = (wave_total + 63u) & ~63u;                 // every lane takes part in the shuffles
     for (uint32_t t = lane; t < t_end; t += 64) {
         // owner = largest lane L with lo_L <= t  (zero-count lanes share their successor's lo and lose)

@@ -81,11 +81,14 @@ __global__ void k_setup_tables(const float* __restrict__ beams, int W, int H,
         // R3/cr/forward.cu:590: evaluated in double, rounded to float, then float cos/sin
         const double b = -((double)(float)i - (double)(float)W / 2.0) / (double)(float)W * 2.0 * (double)pi_f;
         const float beta = (float)b;
-        coltab[i] = make_float2(cosf(beta), sinf(beta));
+        // float cos/sin of the float angle, evaluated through double so the result is the correctly
+        // rounded one (what a good libm returns); the blend differences s - q cancel ~3 digits, so a
+        // 1-ulp wobble here is a 1e-5 relative wobble of every per-pair quantity.
+        coltab[i] = make_float2((float)cos((double)beta), (float)sin((double)beta));
     }
     if (i < H) {
         const float alp = beams[H - 1 - i];     // R3/cr/forward.cu:589
-        rowtab[i] = make_float2(cosf(alp), sinf(alp));
+        rowtab[i] = make_float2((float)cos((double)alp), (float)sin((double)alp));
     }
 }
 

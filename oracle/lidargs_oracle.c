@@ -193,6 +193,11 @@ enum {
 };
 
 static char lgo_err[256] = "";
+/* Test knob: traverse pixels in reverse raster order in the backward blend.  The reference sums
+ * per-Gaussian gradients with float atomicAdd in scheduling order (R3/cr/backward.cu:702-788), so
+ * its own result is only defined up to summation order; tests use this knob to measure that band. */
+static int lgo_reverse_pixel_order = 0;
+void lgo_set_reverse_pixel_order(int on) { lgo_reverse_pixel_order = on; }
 const char* lgo_last_error(void) { return lgo_err; }
 
 void lgo_free(void* h) {
@@ -691,8 +696,9 @@ int lgo_backward(const void* h, int P, int D, int M, int R, const float* backgro
     const long long N = (long long)W * H;
 
     /* K8: cr/backward.cu:535-791 renderCUDA, per pixel, back to front */
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
+    for (int yy = 0; yy < H; yy++)
+        for (int xx = 0; xx < W; xx++) {
+            const int y = lgo_reverse_pixel_order ? H - 1 - yy : yy, x = lgo_reverse_pixel_order ? W - 1 - xx : xx;
             const uint32_t tile = (uint32_t)(y / LGO_BLOCK_Y) * s->gx + (uint32_t)(x / LGO_BLOCK_X);
             const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
             const long long pix = (long long)W * y + x;
