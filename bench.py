@@ -1,0 +1,179 @@
+"""bench.py -- LiDAR range-view frames/s (forward+backward) of the MI355X-native rasterizer.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one frame: GaussianRasterizer.forward + .backward with non-zero upstream gradients on
+colour, depth and occupancy, inputs already resident in HBM (BASELINE.json metric).
+N = 1: the whole scene on one GPU.  N > 1: the SAME scene (strong scaling), Gaussians sharded by
+range shell across the ranks, RCCL all-gather of the per-shell transmittance plane, all-reduce of
+the W x H x C partial range images and all-gather of the per-Gaussian gradient rows (lidargs_dist.py).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     for the dominant kernel (the backward blend): ALGORITHMIC bytes per launch
+               (68*R_ref + 24*N + 84*V, SURVEY.md 8d / DESIGN.md section 5) / its mean launch duration,
+               measured with HIP events on the op's own stream inside the timed region, vs 8 TB/s HBM.
+  cpu_baseline the CPU oracle (oracle/lidargs_oracle.c, 1 thread) on a bounded sample of the same
+               workload, timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(P, V, R_ref, N, T):
+    """SURVEY.md 8d compact form; returns (fwd, bwd, bwd_blend_kernel) bytes per frame."""
+    fwd = 48 * P + 112 * V + 112 * R_ref + 8 * T + 24 * N
+    bwd = 112 * P + 192 * V + 68 * R_ref + 24 * N
+    blend_bwd = 68 * R_ref + 24 * N + 84 * V
+    return fwd, bwd, blend_bwd
+
+
+def cpu_baseline(kind, P_full, H, W, seed, budget_s=20.0):
+    """Oracle (single thread) forward+backward on a P/20 sample of the workload, same image size."""
+    import lidargs_scenes as sc
+    from oracle import lgo
+    lgo.build()
+    P = max(1000, P_full // 20)
+    scene = sc.make_scene(kind, P, H, seed)
+    grads = sc.upstream_grads(H, W, seed)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        f = lgo.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
+                        scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"])
+        lgo.backward(f, *grads)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.5 or frames >= 8:
+            break
+    fps = frames / el
+    return {
+        "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{frames} fwd+bwd frames of a {P}-Gaussian (1/20) {kind} scene at {H}x{W}, oracle/lidargs_oracle.c, "
+                  f"1 thread of {os.cpu_count()} host cores; linear-in-P estimate for the full workload: {fps * P / P_full:.4f} frames/s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import lidargs_scenes as sc
+    kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from diff_lidargs_rasterization import GaussianRasterizer, _C
+    from util import make_settings, to_torch
+
+    scene = sc.make_scene(kind, P, H, seed)
+    st = to_torch(scene, dev)
+    gc, gd, go = (torch.from_numpy(g).to(dev) for g in sc.upstream_grads(H, W, seed))
+    settings = make_settings(st, W, H)
+    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((P, 4), dtype=torch.float32, device=dev, requires_grad=True)
+
+    if world == 1:
+        rast = GaussianRasterizer(settings)
+
+        def step():
+            for t in list(leaves.values()) + [means2D]:
+                t.grad = None
+            color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                            colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+            torch.autograd.backward([color, depth, occ], [gc, gd, go])
+    else:
+        import lidargs_dist
+        rast = lidargs_dist.ShellRasterizer(settings, lidargs_dist.TorchDistComm())
+
+        def step():
+            for t in list(leaves.values()) + [means2D]:
+                t.grad = None
+            color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                            colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+            torch.autograd.backward([color, depth, occ], [gc, gd, go])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _C.profile_enable(True)             # events only, no host waits (lidargs_profile_summary reads them afterwards)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _C.profile_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    stages = _C.profile_summary()
+    cnt = _C.last_counters()
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        N_pix, T_ref = H * W, H * ((W + 15) // 16)
+        fwd_b, bwd_b, blend_b = algorithmic_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
+        blend_ms = stages.get("render_bwd", (0.0, 0))[0]
+        achieved = blend_b / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+        out = {
+            "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, "
+                                   f"lidar_far=80 lidar_near=0, bg=0",
+                       "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
+                       "tile_rows": cnt["tile_rows"], "sharding": "single GPU" if world == 1 else f"{world} range shells"},
+            "roofline": {"bound": "hbm", "kernel": "k_render_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": blend_b, "kernel_ms": blend_ms,
+                         "frame_algorithmic_bytes": fwd_b + bwd_b,
+                         "frame_achieved_GBs": (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9},
+            "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kind, P, H, W, seed)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

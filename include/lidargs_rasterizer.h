@@ -225,13 +225,16 @@ int lidargs_backward_shell(
     float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug, void* stream);
 
 /* ---- introspection used by bench.py / tests (no reference counterpart) ---------------------
- * Per-stage HIP-event timing on the op's own stream.  When enabled, every forward/backward
- * records an event pair around each stage; lidargs_profile_read() synchronises the LAST call's
- * events and returns elapsed milliseconds per stage. */
+ * Per-stage HIP-event timing on the op's own stream.  While enabled, every forward/backward call
+ * records one event per stage boundary (no host wait); lidargs_profile_read() synchronises the
+ * LAST call's events and returns elapsed milliseconds per stage. */
 #define LIDARGS_MAX_STAGES 24
 void lidargs_profile_enable(int on);
 int lidargs_profile_read(float* ms_out, int max_stages);      /* returns #stages written     */
 const char* lidargs_profile_stage_name(int stage);            /* NULL past the last stage    */
+/* Aggregate of all calls recorded since lidargs_profile_enable(1) (up to 512): per distinct stage
+ * name the summed milliseconds and sample count; returns the number of names written. */
+int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* count_out, int max_stages);
 
 /* Counters of the last forward on this thread: [0]=P, [1]=visible Gaussians V,
  * [2]=instances binned by this library (num_rendered), [3]=R_ref = sum of the reference's

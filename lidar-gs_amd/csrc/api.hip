@@ -68,23 +68,30 @@ int ceil_log2(uint32_t n) {
 }
 
 // ---- per-stage event timing -------------------------------------------------------------------
+// While enabled, every forward/backward call records one HIP event per stage boundary on the op's
+// own stream into a fresh slot; nothing is waited for until lidargs_profile_read()/summary().
 struct Profiler {
+    static constexpr int MAX_CALLS = 512;
+    struct Call { int n = 0; const char* names[LIDARGS_MAX_STAGES]; hipEvent_t ev[LIDARGS_MAX_STAGES + 1]; bool created = false; };
     bool enabled = false;
-    int n = 0;
-    const char* names[LIDARGS_MAX_STAGES];
-    hipEvent_t ev[LIDARGS_MAX_STAGES + 1];
-    bool created = false;
+    int ncalls = 0;          // calls recorded since enable
+    Call* calls = nullptr;
+    Call* cur = nullptr;
     void begin(hipStream_t s) {
-        n = 0;
+        cur = nullptr;
         if (!enabled) return;
-        if (!created) { for (auto& e : ev) (void)hipEventCreate(&e); created = true; }
-        (void)hipEventRecord(ev[0], s);
+        if (!calls) calls = new Call[MAX_CALLS];
+        cur = &calls[ncalls % MAX_CALLS];
+        ncalls++;
+        if (!cur->created) { for (auto& e : cur->ev) (void)hipEventCreate(&e); cur->created = true; }
+        cur->n = 0;
+        (void)hipEventRecord(cur->ev[0], s);
     }
     void mark(const char* name, hipStream_t s) {
-        if (!enabled || n >= LIDARGS_MAX_STAGES) return;
-        names[n] = name;
-        (void)hipEventRecord(ev[n + 1], s);
-        n++;
+        if (!cur || cur->n >= LIDARGS_MAX_STAGES) return;
+        cur->names[cur->n] = name;
+        (void)hipEventRecord(cur->ev[cur->n + 1], s);
+        cur->n++;
     }
 };
 Profiler g_prof;   // process-wide: autograd runs backward on its own thread
@@ -377,23 +384,56 @@ int lidargs_backward_shell(int P, int R, const float* background, int width, int
                          dL_dsphere_means3D, dL_dbasis_u1, dL_dbasis_u2, dL_dcov3D, dL_dscale, dL_drot, debug, (hipStream_t)stream);
 }
 
-void lidargs_profile_enable(int on) { g_prof.enabled = on != 0; }
+void lidargs_profile_enable(int on) {
+    g_prof.enabled = on != 0;
+    if (on) g_prof.ncalls = 0;
+}
 
+// stages of the most recent recorded call
 int lidargs_profile_read(float* ms_out, int max_stages) {
-    if (!g_prof.enabled || g_prof.n == 0) return 0;
-    (void)hipEventSynchronize(g_prof.ev[g_prof.n]);
+    if (!g_prof.calls || g_prof.ncalls == 0) return 0;
+    Profiler::Call& c = g_prof.calls[(g_prof.ncalls - 1) % Profiler::MAX_CALLS];
+    if (c.n == 0) return 0;
+    (void)hipEventSynchronize(c.ev[c.n]);
     int k = 0;
-    for (; k < g_prof.n && k < max_stages; k++) {
+    for (; k < c.n && k < max_stages; k++) {
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, g_prof.ev[k], g_prof.ev[k + 1]);
+        (void)hipEventElapsedTime(&ms, c.ev[k], c.ev[k + 1]);
         ms_out[k] = ms;
     }
     return k;
 }
 
 const char* lidargs_profile_stage_name(int stage) {
-    if (stage < 0 || stage >= g_prof.n) return nullptr;
-    return g_prof.names[stage];
+    if (!g_prof.calls || g_prof.ncalls == 0) return nullptr;
+    Profiler::Call& c = g_prof.calls[(g_prof.ncalls - 1) % Profiler::MAX_CALLS];
+    if (stage < 0 || stage >= c.n) return nullptr;
+    return c.names[stage];
+}
+
+// Aggregate over every call recorded since lidargs_profile_enable(1): per distinct stage name the
+// summed milliseconds and the number of samples.  names_out receives pointers to static strings.
+int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* count_out, int max_stages) {
+    if (!g_prof.calls) return 0;
+    int nnames = 0;
+    const int ncalls = g_prof.ncalls < Profiler::MAX_CALLS ? g_prof.ncalls : Profiler::MAX_CALLS;
+    for (int ci = 0; ci < ncalls; ci++) {
+        Profiler::Call& c = g_prof.calls[ci];
+        if (c.n == 0) continue;
+        (void)hipEventSynchronize(c.ev[c.n]);
+        for (int k = 0; k < c.n; k++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c.ev[k], c.ev[k + 1]) != hipSuccess) continue;
+            int j = 0;
+            for (; j < nnames; j++) if (strcmp(names_out[j], c.names[k]) == 0) break;
+            if (j == nnames) {
+                if (nnames >= max_stages) continue;
+                names_out[j] = c.names[k]; total_ms_out[j] = 0.f; count_out[j] = 0; nnames++;
+            }
+            total_ms_out[j] += ms; count_out[j]++;
+        }
+    }
+    return nnames;
 }
 
 int lidargs_last_counters(long long* out, int n) {

@@ -205,11 +205,53 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         if (FILTER) break;
 
         reftiles = (uint32_t)((xmax - xmin) * (ymax - ymin));
-        const int ty0 = ymin / pp.TH, ty1 = (ymax - 1) / pp.TH;
-        tiles = (uint32_t)((xmax - xmin) * (ty1 - ty0 + 1));
-        rspan = (uint32_t)ymin | ((uint32_t)ymax << 16);
-        xsp = (uint32_t)xmin | ((uint32_t)xmax << 16);
         key = __float_as_uint(dist);
+
+        // ---- conservative footprint pruning ------------------------------------------------------
+        // The reference rect is 3*sqrt(lambda) with lambda floored at mid + sqrt(1e-9) (:328-330), which
+        // inflates far/small Gaussians 2-3x per axis.  A pixel inside that rect still SKIPS the Gaussian
+        // unless alpha = opacity*exp(power) >= 1/255 (:606).  With an (almost) orthonormal tangent basis
+        // |d| = sin(theta), theta = angle(pixel ray, centre), and power <= -|d|^2 / (2 lambda_max), so
+        // alpha >= 1/255 needs sin^2(theta) <= 2 ln(255 opacity) lambda_max.  Tiles/rows beyond that
+        // angle can be dropped from the lists without changing any pixel; margins cover float rounding.
+        int tx0 = xmin, tx1 = xmax, ty_lo = ymin, ty_hi = ymax;
+        const float op = a.opacities[idx];
+        if (!(op * 255.f >= 1.f)) { tx1 = tx0; }                       // can never reach 1/255
+        else {
+            const float tau = logf(255.f * op) + 0.02f;
+            const float lam = (mid + sqrtf(fmaxf(0.f, mid * mid - det))) * 1.002f;
+            const float s2 = 2.f * tau * lam;
+            if (s2 < 0.25f) {                                          // theta < 30 deg: worth bounding
+                const float theta = asinf(sqrtf(s2)) * 1.002f + 2e-5f;
+                // rows: |beam elevation - centre elevation| <= theta
+                const float e_lo = alpha - theta, e_hi = alpha + theta;
+                int lo = 0, hi = H;                                    // first beam >= e_lo
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] < e_lo) lo = md + 1; else hi = md; }
+                const int i_lo = lo;
+                lo = 0; hi = H;                                        // first beam > e_hi
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] <= e_hi) lo = md + 1; else hi = md; }
+                const int i_hi = lo;                                   // beams [i_lo, i_hi) are in reach
+                ty_lo = max(ty_lo, H - i_hi);                          // pixel row y = H-1-i
+                ty_hi = min(ty_hi, H - i_lo);
+                // columns: chord^2 >= 4 cos(a_pix) cos(a_g) sin^2(dbeta/2)
+                const float cmin = fminf(cosf(fminf(fabsf(e_lo), 1.5f)), cosf(fminf(fabsf(e_hi), 1.5f)));
+                const float den = sqrtf(fmaxf(cmin * cosf(alpha), 1e-6f));
+                const float t = sinf(0.5f * theta) / den;
+                if (t < 0.7f) {
+                    const float dbeta = 2.f * asinf(t) * 1.002f + 2e-5f;
+                    const float dcol = dbeta / pp.col_step + 1.0f;     // +1 px slack
+                    tx0 = max(tx0, (int)floorf((p_c - dcol) / 16.f));
+                    tx1 = min(tx1, (int)floorf((p_c + dcol) / 16.f) + 1);
+                }
+            }
+        }
+        if (tx1 <= tx0 || ty_hi <= ty_lo) { tiles = 0; tx0 = tx1 = xmin; ty_lo = ty_hi = ymin; }
+        else {
+            const int ty0 = ty_lo / pp.TH, ty1 = (ty_hi - 1) / pp.TH;
+            tiles = (uint32_t)((tx1 - tx0) * (ty1 - ty0 + 1));
+        }
+        rspan = (uint32_t)ty_lo | ((uint32_t)ty_hi << 16);
+        xsp = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
 
         // scaled bases: d.x = delta.u1 / (u1.u1) == delta.u1'  (R3/cr/forward.cu:593-597)
         const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);

@@ -31,7 +31,7 @@ _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib.lidargs_last_error.restype = C.c_char_p
 for _name in ("lidargs_forward", "lidargs_backward", "lidargs_visible_filter", "lidargs_mark_visible",
               "lidargs_forward_shell", "lidargs_render_shell", "lidargs_backward_shell", "lidargs_abi_version",
-              "lidargs_profile_read", "lidargs_last_counters"):
+              "lidargs_profile_read", "lidargs_profile_summary", "lidargs_last_counters"):
     getattr(_lib, _name).restype = C.c_int
 _lib.lidargs_profile_stage_name.restype = C.c_char_p
 _lib.lidargs_profile_enable.restype = None
@@ -231,6 +231,15 @@ def profile_read():
     buf = (C.c_float * 24)()
     n = _lib.lidargs_profile_read(buf, C.c_int(24))
     return [(_lib.lidargs_profile_stage_name(C.c_int(i)).decode(), float(buf[i])) for i in range(n)]
+
+
+def profile_summary():
+    """{stage name: (mean milliseconds, samples)} over every call recorded since profile_enable(True)."""
+    names = (C.c_char_p * 48)()
+    tot = (C.c_float * 48)()
+    cnt = (C.c_int * 48)()
+    n = _lib.lidargs_profile_summary(names, tot, cnt, C.c_int(48))
+    return {names[i].decode(): (float(tot[i]) / max(1, cnt[i]), int(cnt[i])) for i in range(n)}
 
 
 def last_counters():
