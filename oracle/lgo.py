@@ -62,10 +62,12 @@ class ForwardResult:
         self._h = handle
         self.color, self.depth, self.occ, self.radii = color, depth, occ, radii
         self.inputs = inputs
-        self.num_rendered = lib().lgo_num_rendered(C.c_void_p(handle))
+        self.num_rendered = lib().lgo_num_rendered(C.c_void_p(handle)) if handle else 0
 
     def array(self, name):
         which, dt = _ARRAYS[name]
+        if not self._h:
+            return np.zeros(0, dtype=dt)
         n = C.c_longlong(0)
         ptr = lib().lgo_state_array(C.c_void_p(self._h), which, C.byref(n))
         if n.value == 0:
@@ -90,6 +92,11 @@ def forward(means3D, colors, opacities, scales, rotations, viewmatrix, beams, W,
     color = np.zeros((2, H, W), np.float32); depth = np.zeros((1, H, W), np.float32)
     occ = np.zeros((1, H, W), np.float32); radii = np.zeros(P, np.int32)
     zero3 = np.zeros(16, np.float32)
+    inputs = dict(means3D=means3D, colors=colors, opacities=opacities, scales=scales, rotations=rotations,
+                  vm=vm, beams=beams, bg=bg, W=W, H=H, scale_modifier=scale_modifier,
+                  cov3D_precomp=cov3D_precomp, far=far, near=near)
+    if P == 0:      # the reference BINDING never enters the core for P == 0 (R3/rasterize_points.cu:87): all-zero outputs
+        return ForwardResult(None, color, depth, occ, radii, inputs)
     h = lib().lgo_forward(
         C.c_int(P), C.c_int(1), C.c_int(0), _p(bg), C.c_int(W), C.c_int(H),
         _p(means3D), None, _p(colors), _p(opacities), _p(scales), C.c_float(scale_modifier), _p(rotations),
@@ -97,9 +104,6 @@ def forward(means3D, colors, opacities, scales, rotations, viewmatrix, beams, W,
         _p(color), _p(depth), _p(occ), _p(radii) if P else None)
     if not h:
         raise RuntimeError(lib().lgo_last_error().decode())
-    inputs = dict(means3D=means3D, colors=colors, opacities=opacities, scales=scales, rotations=rotations,
-                  vm=vm, beams=beams, bg=bg, W=W, H=H, scale_modifier=scale_modifier,
-                  cov3D_precomp=cov3D_precomp, far=far, near=near)
     return ForwardResult(h, color, depth, occ, radii, inputs)
 
 
@@ -117,6 +121,8 @@ def backward(fwd, dL_dcolor, dL_ddepth, dL_docc):
              dL_dmeans3D=z(P, 3), dL_dsphere=z(P, 3), dL_dbasis_u1=z(P, 3), dL_dbasis_u2=z(P, 3),
              dL_dcov3D=z(P, 6), dL_dsh=z(P, 0, 3), dL_dscales=z(P, 3), dL_drotations=z(P, 4))
     zero3 = np.zeros(16, np.float32)
+    if P == 0:      # R3/rasterize_points.cu:177
+        return g
     rc = lib().lgo_backward(
         C.c_void_p(fwd._h), C.c_int(P), C.c_int(1), C.c_int(0), C.c_int(fwd.num_rendered), _p(i["bg"]),
         C.c_int(W), C.c_int(H), _p(i["means3D"]), None, _p(i["colors"]), _p(i["scales"]),
@@ -144,6 +150,19 @@ def visible_filter(means3D, scales, rotations, viewmatrix, beams, W, H, scale_mo
                              _p(beams), C.c_float(1.0), C.c_float(1.0), C.c_int(0), C.c_int(far), C.c_int(near),
                              _p(radii))
     return radii
+
+
+def pixel_dirs(W, H, beams):
+    """[H,W,3] unit ray of every pixel as the blend kernels evaluate it (R3/cr/forward.cu:589-591)."""
+    beams = _f32(beams)
+    out = np.zeros((H, W, 3), np.float32)
+    tmp = np.zeros(3, np.float32)
+    L = lib()
+    for y in range(H):
+        for x in range(W):
+            L.lgo_pixel_dir(C.c_int(x), C.c_int(y), C.c_int(W), C.c_int(H), _p(beams), _p(tmp))
+            out[y, x] = tmp
+    return out
 
 
 def mark_visible(means3D, viewmatrix):

@@ -357,6 +357,12 @@ static f3 pixel_dir(int x, int y, int W, int H, const float* beams) {
     return q;
 }
 
+/* test accessor for pixel_dir() */
+void lgo_pixel_dir(int x, int y, int W, int H, const float* beams, float* out3) {
+    f3 q = pixel_dir(x, y, W, H, beams);
+    out3[0] = q.x; out3[1] = q.y; out3[2] = q.z;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Forward: cr/rasterizer_impl.cu:202-359 (K1 -> scan -> duplicateWithKeys -> sort -> ranges -> K7)
  * Arguments mirror CudaRasterizer::Rasterizer::forward (cr/rasterizer.h:31-58); D, M, shs,

@@ -1,0 +1,259 @@
+"""CPU tests (no GPU): the oracle against the reference-generated golden vectors, and the oracle's
+own invariants / edge cases.  These pin what CAN be pinned here: the range-view geometry conventions
+(executed reference numpy code -> tests/golden/rangeview_golden.npz) and internal consistency.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import lidargs_scenes as sc
+from oracle import lgo, range_view
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rangeview_golden.npz"))
+
+
+# ---- golden vectors produced by the reference's numpy projector -------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_rangeview_restatement_matches_reference_fixture(tag):
+    H, W = int(GOLD[f"{tag}_H"]), int(GOLD[f"{tag}_W"])
+    beams, pts = GOLD[f"{tag}_beams"], GOLD[f"{tag}_points"]
+    pano, inten = range_view.points_to_pano(pts, H, W, beams, max_depth=80)
+    np.testing.assert_array_equal(pano, GOLD[f"{tag}_pano"])
+    np.testing.assert_array_equal(inten, GOLD[f"{tag}_intensities"])
+    back = range_view.pano_to_points(pano, inten, beams)
+    np.testing.assert_array_equal(back, GOLD[f"{tag}_back"])
+    labels = np.array([range_view.nearest_beam(beams, a) for a in GOLD[f"{tag}_elev"]])
+    np.testing.assert_array_equal(labels, GOLD[f"{tag}_labels"])
+    rays = range_view.pixel_rays(H, W, beams).reshape(-1, 3).astype(np.float64) * 10.0   # float32 dirs x float64 pano
+    np.testing.assert_array_equal(rays, GOLD[f"{tag}_rays"])
+
+
+def test_beam_table_restatement():
+    # a_beams was produced by the reference's get_beam_inclinations(2.4, 20, 16)
+    np.testing.assert_array_equal(range_view.fov_beam_table(2.4, 20.0, 16), GOLD["a_beams"])
+    assert np.all(np.diff(GOLD["a_beams"]) > 0)          # ascending, as R3/cr/forward.cu:337 needs
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_pixel_rays_match_reference_rays(tag):
+    """The blend kernels' pixel->ray rule (R3/cr/forward.cu:589-591) == the reference's pano_to_lidar rays."""
+    H, W = int(GOLD[f"{tag}_H"]), int(GOLD[f"{tag}_W"])
+    if tag == "b":
+        pytest.skip("covered by tag a; 64x2650 per-pixel ctypes loop is slow")
+    q = lgo.pixel_dirs(W, H, GOLD[f"{tag}_beams"]).reshape(-1, 3).astype(np.float64)
+    ref = GOLD[f"{tag}_rays"] / 10.0
+    np.testing.assert_allclose(q, ref, atol=3e-7)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_projection_inverts_reference_rays(tag):
+    """K1's (column,row) of a point on the reference ray of pixel (x,y) is (x,y) (R3/cr/forward.cu:333-359)."""
+    H, W = int(GOLD[f"{tag}_H"]), int(GOLD[f"{tag}_W"])
+    beams = GOLD[f"{tag}_beams"]
+    pts = GOLD[f"{tag}_rays"].astype(np.float32)            # one point per pixel, row-major, range 10 m
+    step = 1 if tag == "a" else 13
+    idx = np.arange(0, pts.shape[0], step)
+    P = idx.size
+    f = lgo.forward(pts[idx], np.ones((P, 2), np.float32), np.full((P, 1), 0.5, np.float32),
+                    np.full((P, 3), 0.01, np.float32), np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1)),
+                    np.eye(4, dtype=np.float32), beams, W, H)
+    m2 = f.array("means2D").reshape(P, 2)
+    vis = f.radii > 0
+    assert vis.mean() > 0.99
+    ys, xs = np.divmod(idx, W)
+    # column 0 sits exactly on the +-pi azimuth seam: float sin(pi) < 0 sends it to column W (the reference
+    # has no wrap-around, R3/cr/auxiliary.h:80-92), so it is excluded here
+    vis &= xs > 0
+    # interior pixels: exact up to float round-off of atan2 (columns) and of the beam interpolation (rows)
+    np.testing.assert_allclose(m2[vis, 0], xs[vis], atol=2e-3)
+    np.testing.assert_allclose(m2[vis, 1], ys[vis], atol=2e-3)
+
+
+# ---- oracle invariants -------------------------------------------------------------------------------------------
+def _run(scene, W, H, **kw):
+    return lgo.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
+                       scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"], **kw)
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    kind, P, H, W, seed = sc.BASELINE_CONFIGS["cfg1"]
+    scene = sc.make_scene(kind, P, H, seed)
+    return scene, W, H, _run(scene, W, H)
+
+
+def test_cfg1_sizing_matches_survey(cfg1):
+    """SURVEY.md Appendix D ran the verbatim reference kernels: P=10k, 16x512 -> R ~ 43k, all visible,
+    mean radius ~2.86 px (different RNG, same distribution)."""
+    scene, W, H, f = cfg1
+    assert (f.radii > 0).sum() == 10_000
+    assert 40_000 < f.num_rendered < 46_000
+    assert 2.7 < f.radii.mean() < 3.0
+
+
+def test_binning_invariants(cfg1):
+    scene, W, H, f = cfg1
+    keys, plist, ranges = f.array("keys"), f.array("point_list"), f.array("ranges").reshape(-1, 2)
+    tt, off = f.array("tiles_touched"), f.array("point_offsets")
+    assert int(tt.sum()) == f.num_rendered == keys.size
+    np.testing.assert_array_equal(np.cumsum(tt, dtype=np.uint32), off)
+    assert np.all(np.diff(keys.astype(np.int64) >> 32) >= 0)              # tile-major
+    same_tile = (keys[1:] >> 32) == (keys[:-1] >> 32)
+    d = keys & 0xFFFFFFFF
+    assert np.all(d[1:][same_tile] >= d[:-1][same_tile])                  # then by range bits
+    tie = same_tile & (d[1:] == d[:-1])
+    assert np.all(plist[1:][tie] > plist[:-1][tie])                       # stable: ties keep Gaussian order
+    lens = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
+    assert lens.sum() == f.num_rendered
+    tiles = (keys >> 32).astype(np.int64)
+    np.testing.assert_array_equal(np.bincount(tiles, minlength=ranges.shape[0]), lens)
+    depth_of = f.array("depths")[plist]
+    np.testing.assert_array_equal(depth_of.view(np.uint32), d.astype(np.uint32))
+
+
+def test_forward_identities(cfg1):
+    scene, W, H, f = cfg1
+    T = f.array("final_T").reshape(H, W)
+    np.testing.assert_array_equal(f.occ[0], 1 - T)
+    assert T.min() >= 1e-4 - 1e-9 and T.max() <= 1.0
+    # background enters as C + T*bg (R3/cr/forward.cu:637); depth/occ ignore it
+    s2 = dict(scene); s2["bg"] = np.array([0.3, 0.7], np.float32)
+    f2 = _run(s2, W, H)
+    np.testing.assert_allclose(f2.color[0] - f.color[0], T * np.float32(0.3), atol=1e-6)
+    np.testing.assert_allclose(f2.color[1] - f.color[1], T * np.float32(0.7), atol=1e-6)
+    np.testing.assert_array_equal(f2.depth, f.depth)
+    # colour channels are linear in the colours; depth does not depend on them
+    rng = np.random.default_rng(0)
+    s3 = dict(scene); s3["colors"] = rng.uniform(0, 1, scene["colors"].shape).astype(np.float32)
+    s4 = dict(scene); s4["colors"] = scene["colors"] + s3["colors"]
+    f3, f4 = _run(s3, W, H), _run(s4, W, H)
+    np.testing.assert_allclose(f4.color, f.color + f3.color, rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(f3.depth, f.depth)
+
+
+def test_colour_gradient_is_the_exact_adjoint(cfg1):
+    """The forward is linear in the colours, so <g, J d> must equal <dL/dcolors, d> (R3/cr/backward.cu:702)."""
+    scene, W, H, f = cfg1
+    gc, gd, go = sc.upstream_grads(H, W, 1)
+    g = lgo.backward(f, gc, gd, go)
+    rng = np.random.default_rng(1)
+    d = rng.normal(size=scene["colors"].shape).astype(np.float32)
+    s2 = dict(scene); s2["colors"] = d
+    Jd = _run(s2, W, H).color                                 # bg = 0 -> purely linear
+    lhs = float((gc.astype(np.float64) * Jd).sum())
+    rhs = float((g["dL_dcolors"].astype(np.float64) * d).sum())
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+    # same for the range channel: out_depth is linear in the per-Gaussian ranges, whose adjoint is dL_ddepths
+    w = f.array("depths").astype(np.float64)
+    lhs_d = float((gd[0].astype(np.float64) * f.depth[0]).sum())
+    rhs_d = float((g["dL_ddepths"][:, 0].astype(np.float64) * w).sum())
+    assert abs(lhs_d - rhs_d) <= 2e-5 * max(abs(lhs_d), 1.0)
+
+
+def test_opacity_gradient_matches_finite_differences():
+    """dL/dopacity is a true gradient in the reference (R3/cr/backward.cu:688-727,:788) EXCEPT for the
+    boundary term of the alpha >= 1/255 truncation (pairs crossing the threshold when the opacity moves),
+    which finite differences see and the analytic formula omits.  So this is a sign/scale sanity check
+    with a loose tolerance, not a precision test."""
+    H, W, P = 16, 128, 300
+    scene = sc.make_scene("shell", P, H, 21)
+    scene["opacities"] = np.clip(scene["opacities"], 0.2, 0.8)
+    scene["bg"] = np.array([0.2, 0.4], np.float32)
+    gc, gd, go = sc.upstream_grads(H, W, 21)
+    f = _run(scene, W, H)
+    g = lgo.backward(f, gc, gd, go)
+
+    def loss(op):
+        s2 = dict(scene); s2["opacities"] = op.astype(np.float32)
+        r = _run(s2, W, H)
+        return float((gc * r.color).sum(dtype=np.float64) + (gd * r.depth).sum(dtype=np.float64) + (go * r.occ).sum(dtype=np.float64))
+
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=scene["opacities"].shape)
+    eps = 2e-3
+    fd = (loss(scene["opacities"] + eps * d) - loss(scene["opacities"] - eps * d)) / (2 * eps)
+    an = float((g["dL_dopacity"].astype(np.float64) * d).sum())
+    assert abs(fd - an) <= 0.15 * max(abs(fd), abs(an)), (fd, an)
+
+
+def test_backward_shapes_zero_rows_and_statistic(cfg1):
+    scene, W, H, f = cfg1
+    g = lgo.backward(f, *sc.upstream_grads(H, W, 1))
+    P = scene["means3D"].shape[0]
+    assert g["dL_dmeans2D"].shape == (P, 4) and g["dL_dscales"].shape == (P, 3) and g["dL_drotations"].shape == (P, 4)
+    assert np.all(g["dL_dmeans2D"][:, 3] == 0)               # .w += 0 (R3/cr/backward.cu:780)
+    assert np.all(g["dL_dmeans2D"][:, 2] >= 0)               # .z is a sum of norms (:779)
+    assert np.all(g["dL_dconic"][:, 2] == 0)                 # conic.z slot never written (:783-785)
+    for v in g.values():
+        assert np.isfinite(v).all()
+
+
+# ---- edge cases ---------------------------------------------------------------------------------------------------
+def test_empty_input_and_all_culled():
+    H, W = 16, 512
+    beams = sc.beam_inclinations(H)
+    z = lambda *s: np.zeros(s, np.float32)
+    f = lgo.forward(z(0, 3), z(0, 2), z(0, 1), z(0, 3), z(0, 4), np.eye(4, dtype=np.float32), beams, W, H, bg=np.array([0.5, 0.25], np.float32))
+    assert f.num_rendered == 0
+    assert float(np.abs(f.color).max()) == 0.0      # binding short-circuit: zeros even with a background (R3/rasterize_points.cu:87)
+    scene = sc.make_scene("shell", 500, H, 5)
+    far = dict(scene); far["means3D"] = scene["means3D"] * 50
+    f = _run(far, W, H)
+    assert (f.radii > 0).sum() == 0 and f.num_rendered == 0 and float(np.abs(f.depth).max()) == 0
+    g = lgo.backward(f, *sc.upstream_grads(H, W, 5))
+    assert all(float(np.abs(v).sum()) == 0 for v in g.values())
+
+
+def test_range_and_beam_cull_boundaries():
+    H, W = 16, 512
+    beams = sc.beam_inclinations(H)
+    def one(p, far=80, near=0):
+        f = lgo.forward(np.array([p], np.float32), np.ones((1, 2), np.float32), np.ones((1, 1), np.float32) * 0.9,
+                        np.full((1, 3), 0.1, np.float32), np.array([[1, 0, 0, 0]], np.float32), np.eye(4, dtype=np.float32),
+                        beams, W, H, far=far, near=near)
+        return int(f.radii[0])
+    assert one([10, 0, -1]) > 0
+    assert one([80.0, 0, 0]) == 0 and one([79.9, 0, -2]) > 0          # dist >= far culled (R3/cr/forward.cu:304)
+    assert one([10, 0, -1], near=10) > 0 and one([10, 0, 0], near=10) == 0   # dist <= near culled
+    top, bot = float(beams[-1]), float(beams[0])
+    r = 20.0
+    up = lambda el: [r * np.cos(el), 0.0, r * np.sin(el)]
+    assert one(up(top + 0.0035)) > 0 and one(up(top + 0.0045)) == 0    # +2*Ray_Divergence_Angle guard (:347)
+    assert one(up(bot - 0.0035)) > 0 and one(up(bot - 0.0045)) == 0    # (:356)
+    assert one([0.0, 0.0, -10.0]) == 0                                  # straight down: outside the beam fan
+
+
+def test_ragged_image_sizes_and_tiny_width():
+    for H, W in ((5, 17), (3, 16), (18, 500), (2, 1)):
+        scene = sc.make_scene("shell", 300, max(H, 2), 13)
+        f = _run(scene, W, H)
+        assert np.isfinite(f.color).all() and f.color.shape == (2, H, W)
+        g = lgo.backward(f, *sc.upstream_grads(H, W, 13))
+        assert all(np.isfinite(v).all() for v in g.values())
+
+
+def test_visible_filter_and_mark_visible_agree_with_forward(cfg1):
+    scene, W, H, f = cfg1
+    r = lgo.visible_filter(scene["means3D"], scene["scales"], scene["rotations"], scene["viewmatrix"], scene["beams"], W, H)
+    # K2 differs from K1 only by a 1e-9 floor inside the elevation (R3/cr/forward.cu:456 vs :336)
+    assert (r != f.radii).sum() <= 1
+    vis = lgo.mark_visible(scene["means3D"], scene["viewmatrix"])
+    np.testing.assert_array_equal(vis, scene["means3D"][:, 2] > 0.2)
+
+
+def test_summation_order_band_of_the_gradients(cfg1):
+    """The reference accumulates per-Gaussian gradients with float atomics in scheduling order; the
+    oracle can replay the pixels in reverse to show how wide that band is (it must be far below 1e-4)."""
+    scene, W, H, f = cfg1
+    gr = sc.upstream_grads(H, W, 1)
+    a = lgo.backward(f, *gr)
+    lgo.lib().lgo_set_reverse_pixel_order(1)
+    try:
+        b = lgo.backward(f, *gr)
+    finally:
+        lgo.lib().lgo_set_reverse_pixel_order(0)
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations"):
+        scale = np.abs(a[k]).max()
+        err = np.abs(a[k] - b[k]) / (np.abs(a[k]) + 1e-3 * scale)
+        assert err.max() < 1e-4, (k, err.max())
