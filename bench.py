@@ -60,7 +60,14 @@ def cpu_baseline(kind, P_full, H, W, seed, budget_s=20.0):
         if el > budget_s * 0.5 or frames >= 8:
             break
     fps = frames / el
+    # baseline B2: the reference's numpy per-point projector on one 64x2650 sweep's worth of points
+    from oracle import range_view
+    pts = np.concatenate([scene["means3D"][:20000], scene["colors"][:20000, :1]], 1)
+    t1 = time.perf_counter()
+    range_view.points_to_pano(pts, H, W, scene["beams"])
+    pps = pts.shape[0] / (time.perf_counter() - t1)
     return {
+        "projector_points_per_s": pps,
         "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": f"{frames} fwd+bwd frames of a {P}-Gaussian (1/20) {kind} scene at {H}x{W}, oracle/lidargs_oracle.c, "
                   f"1 thread of {os.cpu_count()} host cores; linear-in-P estimate for the full workload: {fps * P / P_full:.4f} frames/s",

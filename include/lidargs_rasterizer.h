@@ -187,7 +187,8 @@ int lidargs_mark_visible(
  *   lidargs_render_shell    phase 2: composite the already-binned shell again, now from the true
  *                           T_in = product of the nearer shells' T_out.  Outputs are this shell's
  *                           own partial sums, already weighted by the global transmittance
- *                           (pass background = NULL and add T_final*bg after the reduction).
+ *                           (pass background = NULL and add T_final*bg after the reduction);
+ *                           T_end_out f32[H*W] (optional) = transmittance after this shell.
  *   lidargs_backward_shell  like lidargs_backward, seeded with what lies BEHIND the shell:
  *                           behind f32[3*H*W] = (colour0, colour1, depth) partial sums of all
  *                           farther shells; T_final_global f32[H*W].
@@ -209,7 +210,7 @@ int lidargs_render_shell(
     int P, int R, const float* background, int width, int height,
     char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* T_in, int transmittance_pass,
-    float* out_color, float* out_depth, float* out_occ, float* T_out,
+    float* out_color, float* out_depth, float* out_occ, float* T_out, float* T_end_out,
     int debug, void* stream);
 
 int lidargs_backward_shell(

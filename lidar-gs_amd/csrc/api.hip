@@ -351,7 +351,7 @@ int lidargs_forward_shell(lidargs_alloc_fn geometry_alloc, void* geometry_user, 
 
 int lidargs_render_shell(int P, int R, const float* background, int width, int height, char* geom_buffer, char* binning_buffer,
                          char* image_buffer, const float* T_in, int transmittance_pass, float* out_color, float* out_depth,
-                         float* out_occ, float* T_out, int debug, void* stream_) {
+                         float* out_occ, float* T_out, float* T_end_out, int debug, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "render_shell: missing forward buffers%s");
     const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());
@@ -367,6 +367,8 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
     lg::launch_render_forward(ra, stream);
     LG_STAGE_CHECK("render shell");
+    if (T_end_out && !transmittance_pass)
+        LG_HIP(hipMemcpyAsync(T_end_out, img.final_T, sizeof(float) * (size_t)width * height, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 

@@ -36,6 +36,8 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         _lib.lgo_forward.restype = C.c_void_p
+        _lib.lgo_forward_ex.restype = C.c_void_p
+        _lib.lgo_backward_ex.restype = C.c_int
         _lib.lgo_state_array.restype = C.c_void_p
         _lib.lgo_last_error.restype = C.c_char_p
         _lib.lgo_num_rendered.restype = C.c_int
@@ -82,8 +84,11 @@ class ForwardResult:
 
 
 def forward(means3D, colors, opacities, scales, rotations, viewmatrix, beams, W, H, bg=None,
-            scale_modifier=1.0, cov3D_precomp=None, far=80, near=0):
-    """Restates CudaRasterizer::Rasterizer::forward (R3/cr/rasterizer_impl.cu:202-359)."""
+            scale_modifier=1.0, cov3D_precomp=None, far=80, near=0, shell=None, T_in=None, t_only=False):
+    """Restates CudaRasterizer::Rasterizer::forward (R3/cr/rasterizer_impl.cu:202-359).
+
+    shell=(lo, hi), T_in, t_only: the multi-GPU range-shell extension (no reference counterpart);
+    the result then carries .T_pass."""
     means3D = _f32(means3D); colors = _f32(colors); opacities = _f32(opacities)
     scales = _f32(scales); rotations = _f32(rotations); cov3D_precomp = _f32(cov3D_precomp)
     vm = _f32(viewmatrix).reshape(16); beams = _f32(beams)
@@ -97,17 +102,44 @@ def forward(means3D, colors, opacities, scales, rotations, viewmatrix, beams, W,
                   cov3D_precomp=cov3D_precomp, far=far, near=near)
     if P == 0:      # the reference BINDING never enters the core for P == 0 (R3/rasterize_points.cu:87): all-zero outputs
         return ForwardResult(None, color, depth, occ, radii, inputs)
-    h = lib().lgo_forward(
-        C.c_int(P), C.c_int(1), C.c_int(0), _p(bg), C.c_int(W), C.c_int(H),
-        _p(means3D), None, _p(colors), _p(opacities), _p(scales), C.c_float(scale_modifier), _p(rotations),
-        _p(cov3D_precomp), _p(vm), _p(zero3), _p(zero3), _p(beams), C.c_int(0), C.c_int(far), C.c_int(near),
-        _p(color), _p(depth), _p(occ), _p(radii) if P else None)
+    if shell is None and T_in is None and not t_only:
+        h = lib().lgo_forward(
+            C.c_int(P), C.c_int(1), C.c_int(0), _p(bg), C.c_int(W), C.c_int(H),
+            _p(means3D), None, _p(colors), _p(opacities), _p(scales), C.c_float(scale_modifier), _p(rotations),
+            _p(cov3D_precomp), _p(vm), _p(zero3), _p(zero3), _p(beams), C.c_int(0), C.c_int(far), C.c_int(near),
+            _p(color), _p(depth), _p(occ), _p(radii) if P else None)
+        T_pass = None
+    else:
+        lo, hi = shell if shell is not None else (-np.inf, np.inf)
+        T_in = None if T_in is None else _f32(T_in).reshape(-1)
+        T_pass = np.zeros(H * W, np.float32)
+        h = lib().lgo_forward_ex(
+            C.c_int(P), C.c_int(1), C.c_int(0), _p(bg), C.c_int(W), C.c_int(H),
+            _p(means3D), None, _p(colors), _p(opacities), _p(scales), C.c_float(scale_modifier), _p(rotations),
+            _p(cov3D_precomp), _p(vm), _p(zero3), _p(zero3), _p(beams), C.c_int(0), C.c_int(far), C.c_int(near),
+            C.c_float(lo), C.c_float(hi), _p(T_in), C.c_int(int(t_only)), _p(T_pass),
+            _p(color), _p(depth), _p(occ), _p(radii) if P else None)
     if not h:
         raise RuntimeError(lib().lgo_last_error().decode())
-    return ForwardResult(h, color, depth, occ, radii, inputs)
+    res = ForwardResult(h, color, depth, occ, radii, inputs)
+    res.T_pass = T_pass
+    return res
 
 
-def backward(fwd, dL_dcolor, dL_ddepth, dL_docc):
+def render_shell(fwd, T_in=None, t_only=False, bg=None):
+    """Phase 2 of the two-phase shell render on an already-binned oracle state."""
+    i = fwd.inputs
+    H, W = i["H"], i["W"]
+    T_in = None if T_in is None else _f32(T_in).reshape(-1)
+    bg = None if bg is None else _f32(bg)
+    T_pass = np.zeros(H * W, np.float32)
+    lib().lgo_render_ex(C.c_void_p(fwd._h), _p(i["colors"]), _p(bg), _p(i["beams"]), _p(T_in), C.c_int(int(t_only)),
+                        _p(fwd.color), _p(fwd.depth), _p(fwd.occ), _p(T_pass))
+    fwd.T_pass = T_pass
+    return fwd
+
+
+def backward(fwd, dL_dcolor, dL_ddepth, dL_docc, behind=None, T_final_global=None, bg=None):
     """Restates CudaRasterizer::Rasterizer::backward (R3/cr/rasterizer_impl.cu:431-549).
 
     Returns a dict with the 8 tensors the reference binding returns
@@ -123,15 +155,17 @@ def backward(fwd, dL_dcolor, dL_ddepth, dL_docc):
     zero3 = np.zeros(16, np.float32)
     if P == 0:      # R3/rasterize_points.cu:177
         return g
-    rc = lib().lgo_backward(
-        C.c_void_p(fwd._h), C.c_int(P), C.c_int(1), C.c_int(0), C.c_int(fwd.num_rendered), _p(i["bg"]),
+    behind = None if behind is None else _f32(behind).reshape(-1)
+    T_final_global = None if T_final_global is None else _f32(T_final_global).reshape(-1)
+    rc = lib().lgo_backward_ex(
+        C.c_void_p(fwd._h), C.c_int(P), C.c_int(1), C.c_int(0), C.c_int(fwd.num_rendered), _p(i["bg"] if bg is None else _f32(bg)),
         C.c_int(W), C.c_int(H), _p(i["means3D"]), None, _p(i["colors"]), _p(i["scales"]),
         C.c_float(i["scale_modifier"]), _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["vm"]), _p(zero3), _p(zero3),
         _p(i["beams"]), C.c_float(1.0), C.c_float(1.0), _p(fwd.radii),
         _p(dL_dcolor), _p(dL_ddepth), _p(dL_docc),
         _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(g["dL_ddepths"]),
         _p(g["dL_dmeans3D"]), _p(g["dL_dsphere"]), _p(g["dL_dbasis_u1"]), _p(g["dL_dbasis_u2"]),
-        _p(g["dL_dcov3D"]), None, _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+        _p(g["dL_dcov3D"]), None, _p(g["dL_dscales"]), _p(g["dL_drotations"]), _p(behind), _p(T_final_global))
     if rc != 0:
         raise RuntimeError(lib().lgo_last_error().decode())
     return g

@@ -244,7 +244,7 @@ const void* lgo_state_array(const void* h, int which, long long* count) {
 static void preprocess_one(int idx, int filter, lgo_state* s,
                            const float* means3D, const float* scales, float scale_modifier,
                            const float* rotations, const float* opacities, const float* cov3D_precomp,
-                           const float* vm, const float* beams, int far_, int near_, int* radii) {
+                           const float* vm, const float* beams, int far_, int near_, float shell_lo, float shell_hi, int* radii) {
     const int W = s->W, H = s->H;
     radii[idx] = 0;
     if (!filter) s->tiles_touched[idx] = 0;
@@ -253,6 +253,7 @@ static void preprocess_one(int idx, int filter, lgo_state* s,
     f3 pv = transform_point_4x3(p_orig, vm);
     float dist = sqrtf((pv.x) * (pv.x) + (pv.y) * (pv.y) + (pv.z) * (pv.z));
     if (dist >= far_ || dist <= near_) return;                      /* :304 int -> float compare */
+    if (!(dist >= shell_lo && dist < shell_hi)) return;             /* multi-GPU range shell (no reference counterpart) */
 
     const float* cov3D;
     if (cov3D_precomp != NULL) cov3D = cov3D_precomp + idx * 6;
@@ -363,18 +364,75 @@ void lgo_pixel_dir(int x, int y, int W, int H, const float* beams, float* out3) 
     out3[0] = q.x; out3[1] = q.y; out3[2] = q.z;
 }
 
+/* K7: cr/forward.cu:502-641 renderCUDA, per pixel.  The block-cooperative staging and the
+ * __syncthreads_count early-out only change scheduling: each pixel walks its tile's list in order
+ * until `done`.  T_in / t_only / T_pass are the multi-GPU range-shell extension (T_in == NULL,
+ * t_only == 0 is exactly the reference): the walk starts from T_in instead of 1, and T_pass
+ * receives the transmittance handed to the next shell (the value that tripped T < 1e-4, if any). */
+static void render_pixels(lgo_state* s, const float* colors_precomp, const float* background, const float* beams,
+                          const float* T_in, int t_only, float* out_color, float* out_depth, float* out_occ, float* T_pass) {
+    const int W = s->W, H = s->H;
+    const long long N = (long long)W * H;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint32_t tile = (uint32_t)(y / LGO_BLOCK_Y) * s->gx + (uint32_t)(x / LGO_BLOCK_X);
+            const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+            const f3 q = pixel_dir(x, y, W, H, beams);
+            const long long pix = (long long)W * y + x;
+            float T = T_in ? T_in[pix] : 1.0f;
+            float T_break = T;
+            uint32_t contributor = 0, last_contributor = 0;
+            float C[LGO_CHANNELS] = { 0 };
+            float Dp = 0.0f;
+            int done = 0;
+            for (uint32_t k = r0; k < r1 && !done; k++) {
+                contributor++;
+                const uint32_t g = s->point_list[k];
+                const float* sp = s->sphere + 3 * g; const float* u1 = s->basis_u1 + 3 * g; const float* u2 = s->basis_u2 + 3 * g;
+                float dx_ = sp[0] - q.x, dy_ = sp[1] - q.y, dz_ = sp[2] - q.z;
+                float u1_u1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
+                float u2_u2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
+                float d_u1 = dx_ * u1[0] + dy_ * u1[1] + dz_ * u1[2];
+                float d_u2 = dx_ * u2[0] + dy_ * u2[1] + dz_ * u2[2];
+                float ddx = d_u1 / u1_u1, ddy = d_u2 / u2_u2;
+                const float* co = s->conic_opacity + 4 * g;
+                float power = -0.5f * (co[0] * ddx * ddx + co[2] * ddy * ddy) - co[1] * ddx * ddy;
+                if (power > 0.0f) continue;
+                float a = co[3] * expf(power);
+                float alpha = 0.99f < a ? 0.99f : a;        /* min(0.99f, .) */
+                if (alpha < 1.0f / 255.0f) continue;
+                float test_T = T * (1 - alpha);
+                if (test_T < 0.0001f) { done = 1; T_break = test_T; continue; }
+                if (!t_only) {
+                    for (int ch = 0; ch < LGO_CHANNELS; ch++) C[ch] += colors_precomp[g * LGO_CHANNELS + ch] * alpha * T;
+                    Dp += s->depths[g] * alpha * T;
+                }
+                T = test_T; T_break = test_T;
+                last_contributor = contributor;
+            }
+            if (T_pass) T_pass[pix] = T_break;
+            if (t_only) continue;
+            s->final_T[pix] = T;
+            s->n_contrib[pix] = last_contributor;
+            for (int ch = 0; ch < LGO_CHANNELS; ch++) out_color[ch * N + pix] = C[ch] + T * (background ? background[ch] : 0.0f);
+            out_depth[pix] = Dp;
+            out_occ[pix] = 1 - T;
+        }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Forward: cr/rasterizer_impl.cu:202-359 (K1 -> scan -> duplicateWithKeys -> sort -> ranges -> K7)
  * Arguments mirror CudaRasterizer::Rasterizer::forward (cr/rasterizer.h:31-58); D, M, shs,
  * projmatrix, cam_pos and prefiltered are accepted and unused, exactly like the LiDAR path.
  * Returns a state handle (free with lgo_free) or NULL with lgo_last_error() set.
  * ---------------------------------------------------------------------------------------- */
-void* lgo_forward(int P, int D, int M, const float* background, int width, int height,
-                  const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                  const float* beams, int prefiltered, int far_, int near_,
-                  float* out_color, float* out_depth, float* out_occ, int* radii) {
+void* lgo_forward_ex(int P, int D, int M, const float* background, int width, int height,
+                     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                     const float* beams, int prefiltered, int far_, int near_,
+                     float shell_lo, float shell_hi, const float* T_in, int t_only, float* T_pass,
+                     float* out_color, float* out_depth, float* out_occ, int* radii) {
     (void)D; (void)M; (void)shs; (void)projmatrix; (void)cam_pos; (void)prefiltered;
     if (colors_precomp == NULL) {  /* cr/rasterizer_impl.cu:249-252 */
         snprintf(lgo_err, sizeof lgo_err, "For non-RGB, provide precomputed Gaussian colors!");
@@ -397,7 +455,7 @@ void* lgo_forward(int P, int D, int M, const float* background, int width, int h
 
     for (int i = 0; i < P; i++)
         preprocess_one(i, 0, s, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp,
-                       viewmatrix, beams, far_, near_, radii);
+                       viewmatrix, beams, far_, near_, shell_lo, shell_hi, radii);
 
     /* cr/rasterizer_impl.cu:288 InclusiveSum */
     uint32_t run = 0;
@@ -437,50 +495,26 @@ void* lgo_forward(int P, int D, int M, const float* background, int width, int h
         if (i == R - 1) s->ranges[2 * cur + 1] = (uint32_t)R;
     }
 
-    /* K7: cr/forward.cu:502-641 renderCUDA, per pixel.  The block-cooperative staging and the
-     * __syncthreads_count early-out only change scheduling: each pixel walks its tile's list
-     * in order until `done`. */
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            const uint32_t tile = (uint32_t)(y / LGO_BLOCK_Y) * s->gx + (uint32_t)(x / LGO_BLOCK_X);
-            const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
-            const f3 q = pixel_dir(x, y, W, H, beams);
-            float T = 1.0f;
-            uint32_t contributor = 0, last_contributor = 0;
-            float C[LGO_CHANNELS] = { 0 };
-            float Dp = 0.0f;
-            int done = 0;
-            for (uint32_t k = r0; k < r1 && !done; k++) {
-                contributor++;
-                const uint32_t g = s->point_list[k];
-                const float* sp = s->sphere + 3 * g; const float* u1 = s->basis_u1 + 3 * g; const float* u2 = s->basis_u2 + 3 * g;
-                float dx_ = sp[0] - q.x, dy_ = sp[1] - q.y, dz_ = sp[2] - q.z;
-                float u1_u1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
-                float u2_u2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
-                float d_u1 = dx_ * u1[0] + dy_ * u1[1] + dz_ * u1[2];
-                float d_u2 = dx_ * u2[0] + dy_ * u2[1] + dz_ * u2[2];
-                float ddx = d_u1 / u1_u1, ddy = d_u2 / u2_u2;
-                const float* co = s->conic_opacity + 4 * g;
-                float power = -0.5f * (co[0] * ddx * ddx + co[2] * ddy * ddy) - co[1] * ddx * ddy;
-                if (power > 0.0f) continue;
-                float a = co[3] * expf(power);
-                float alpha = 0.99f < a ? 0.99f : a;        /* min(0.99f, .) */
-                if (alpha < 1.0f / 255.0f) continue;
-                float test_T = T * (1 - alpha);
-                if (test_T < 0.0001f) { done = 1; continue; }
-                for (int ch = 0; ch < LGO_CHANNELS; ch++) C[ch] += colors_precomp[g * LGO_CHANNELS + ch] * alpha * T;
-                Dp += s->depths[g] * alpha * T;
-                T = test_T;
-                last_contributor = contributor;
-            }
-            const long long pix = (long long)W * y + x;
-            s->final_T[pix] = T;
-            s->n_contrib[pix] = last_contributor;
-            for (int ch = 0; ch < LGO_CHANNELS; ch++) out_color[ch * N + pix] = C[ch] + T * background[ch];
-            out_depth[pix] = Dp;
-            out_occ[pix] = 1 - T;
-        }
+    render_pixels(s, colors_precomp, background, beams, T_in, t_only, out_color, out_depth, out_occ, T_pass);
     return s;
+}
+
+/* The reference entry point: no shell, T starts at 1. */
+void* lgo_forward(int P, int D, int M, const float* background, int width, int height,
+                  const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                  const float* beams, int prefiltered, int far_, int near_,
+                  float* out_color, float* out_depth, float* out_occ, int* radii) {
+    return lgo_forward_ex(P, D, M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                          rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, beams, prefiltered, far_, near_,
+                          -INFINITY, INFINITY, NULL, 0, NULL, out_color, out_depth, out_occ, radii);
+}
+
+/* Phase 2 of the two-phase shell render: composite the already-binned state again from T_in. */
+void lgo_render_ex(void* h, const float* colors_precomp, const float* background, const float* beams, const float* T_in,
+                   int t_only, float* out_color, float* out_depth, float* out_occ, float* T_pass) {
+    render_pixels((lgo_state*)h, colors_precomp, background, beams, T_in, t_only, out_color, out_depth, out_occ, T_pass);
 }
 
 /* cr/backward.cu:385-448 computeCov3D VJP */
@@ -683,7 +717,7 @@ static void preprocess_bwd_one(int idx, const float* means, const int* radii, co
  * CudaRasterizer::Rasterizer::backward (cr/rasterizer.h:86-122).  All dL_d* outputs must be
  * zero-initialised by the caller, as R3/rasterize_points.cu:163-175 does.
  * ---------------------------------------------------------------------------------------- */
-int lgo_backward(const void* h, int P, int D, int M, int R, const float* background, int width, int height,
+int lgo_backward_ex(const void* h, int P, int D, int M, int R, const float* background, int width, int height,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                  const float* viewmatrix, const float* projmatrix, const float* campos, const float* beams,
@@ -691,7 +725,8 @@ int lgo_backward(const void* h, int P, int D, int M, int R, const float* backgro
                  const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ,
                  float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths,
                  float* dL_dmean3D, float* dL_dsphere, float* dL_dbasis_u1, float* dL_dbasis_u2,
-                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                 const float* behind, const float* T_final_global) {
     (void)D; (void)M; (void)shs; (void)projmatrix; (void)campos; (void)tan_fovx; (void)tan_fovy; (void)dL_dsh;
     const lgo_state* s = (const lgo_state*)h;
     if (s->P != P || s->W != width || s->H != height || s->R != R) {
@@ -709,12 +744,19 @@ int lgo_backward(const void* h, int P, int D, int M, int R, const float* backgro
             const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
             const long long pix = (long long)W * y + x;
             const f3 q = pixel_dir(x, y, W, H, beams);
-            const float T_final = s->final_T[pix];
-            float T = T_final;
+            /* shell extension: T starts at this shell's own end value, T_final is the global one and the
+             * "colour behind" recurrences are seeded with what the farther shells composited */
+            float T = s->final_T[pix];
+            const float T_final = T_final_global ? T_final_global[pix] : T;
             uint32_t contributor = r1 - r0;
             const int last_contributor = (int)s->n_contrib[pix];
             float accum_rec[LGO_CHANNELS] = { 0 };
             float accum_red = 0, accum_reo = 0;
+            if (behind && T > 0.f) {
+                const float inv = 1.f / T;
+                accum_rec[0] = behind[pix] * inv; accum_rec[1] = behind[N + pix] * inv; accum_red = behind[2 * N + pix] * inv;
+                accum_reo = 1.f - T_final * inv;
+            }
             float dL_dpixel[LGO_CHANNELS];
             for (int i = 0; i < C; i++) dL_dpixel[i] = dL_dpix[i * N + pix];
             float dL_dod = dL_dout_depth[pix], dL_doo = dL_dout_occ[pix];
@@ -807,6 +849,21 @@ int lgo_backward(const void* h, int P, int D, int M, int R, const float* backgro
     return 0;
 }
 
+int lgo_backward(const void* h, int P, int D, int M, int R, const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* campos, const float* beams,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths,
+                 float* dL_dmean3D, float* dL_dsphere, float* dL_dbasis_u1, float* dL_dbasis_u2,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
+    return lgo_backward_ex(h, P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                           cov3D_precomp, viewmatrix, projmatrix, campos, beams, tan_fovx, tan_fovy, radii, dL_dpix, dL_dout_depth,
+                           dL_dout_occ, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepths, dL_dmean3D, dL_dsphere,
+                           dL_dbasis_u1, dL_dbasis_u2, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, NULL, NULL);
+}
+
 /* cr/rasterizer_impl.cu:362-426 visible_filter -> K2 only; radii out (R3/rasterize_points.cu:243-318) */
 int lgo_visible_filter(int P, int M, int width, int height, const float* means3D, const float* scales,
                        float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -819,7 +876,8 @@ int lgo_visible_filter(int P, int M, int width, int height, const float* means3D
     size_t Pz = P > 0 ? (size_t)P : 1;
     s.cov3D = (float*)calloc(Pz * 6, 4); s.means2D = (float*)calloc(Pz * 2, 4); s.radii_xy = (int*)calloc(Pz * 2, 4);
     for (int i = 0; i < P; i++)
-        preprocess_one(i, 1, &s, means3D, scales, scale_modifier, rotations, NULL, cov3D_precomp, viewmatrix, beams, far_, near_, radii);
+        preprocess_one(i, 1, &s, means3D, scales, scale_modifier, rotations, NULL, cov3D_precomp, viewmatrix, beams, far_, near_,
+                       -INFINITY, INFINITY, radii);
     free(s.cov3D); free(s.means2D); free(s.radii_xy);
     return 0;
 }

@@ -1,0 +1,127 @@
+"""world_size-2 (and 3) gloo tests of the range-shell multi-GPU path on CPU.
+
+The product code under test is lidargs_dist._ShellRasterize (shell edges, the two all-gathers, the
+transmittance products, T_final selection, behind-sums, gradient reduce-scatter).  The per-rank
+renderer is the oracle-backed stand-in of tests/dist_backend_oracle.py, and the expected result is
+the plain single-process oracle on the whole scene."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import lidargs_scenes as sc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _settings(scene, W, H):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")]
+    from diff_lidargs_rasterization import GaussianRasterizationSettings
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return GaussianRasterizationSettings(H, W, 1.0, 1.0, t(scene["bg"]), 1.0, t(scene["viewmatrix"]), torch.eye(4), 1, torch.zeros(3), False,
+                                         t(scene["beams"]), 80, 0, False)
+
+
+def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lidargs_dist
+    from dist_backend_oracle import OracleShellBackend
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    scene["bg"] = np.array(bg, np.float32)
+    rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleShellBackend(), grad_sync=grad_sync)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
+    leaves = {k: t(scene[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    m2 = torch.zeros(P, 4, requires_grad=True)
+    color, depth, occ, radii = rast(leaves["means3D"], m2, leaves["opacities"], leaves["colors"], leaves["scales"], leaves["rotations"])
+    gc, gd, go = (torch.from_numpy(g) for g in sc.upstream_grads(H, W, seed))
+    torch.autograd.backward([color, depth, occ], [gc, gd, go])
+    out = dict(color=color.detach().numpy(), depth=depth.detach().numpy(), occ=occ.detach().numpy(), radii=radii.numpy(),
+               dL_dmeans3D=leaves["means3D"].grad.numpy(), dL_dmeans2D=m2.grad.numpy(), dL_dcolors=leaves["colors"].grad.numpy(),
+               dL_dopacity=leaves["opacities"].grad.numpy(), dL_dscales=leaves["scales"].grad.numpy(),
+               dL_drotations=leaves["rotations"].grad.numpy())
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CASES = [
+    ("w2_shell", 2, "shell", 4000, 16, 256, 31, (0.0, 0.0), "all_reduce"),
+    ("w2_street_bg", 2, "street", 6000, 16, 256, 32, (0.3, 0.6), "reduce_scatter"),
+    ("w3_dense", 3, "street", 9000, 16, 128, 33, (0.1, 0.2), "reduce_scatter"),   # saturating pixels: the T<1e-4 stop crosses shells
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_shell_sharding_matches_single_process(case, tmp_path):
+    from util import GRAD_KEYS_SR, oracle_forward_backward, parity
+    name, world, kind, P, H, W, seed, bg, grad_sync = case
+    mp.spawn(_worker, args=(world, _free_port(), kind, P, H, W, seed, bg, grad_sync, str(tmp_path)), nprocs=world, join=True)
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    scene["bg"] = np.array(bg, np.float32)
+    ref = oracle_forward_backward(scene, W, H, sc.upstream_grads(H, W, seed))
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    # the image is identical on every rank and matches the single-process composite
+    for r in range(world):
+        np.testing.assert_array_equal(ranks[r]["radii"], ref["radii"])
+        for k in ("color", "depth", "occ"):
+            parity(f"{k}@rank{r}", ranks[r][k], ref[k], verbose=(r == 0))
+            np.testing.assert_array_equal(ranks[r][k], ranks[0][k])
+    # gradients: all_reduce -> full on every rank; reduce_scatter -> rank r holds rows [r*rows, (r+1)*rows)
+    rows = (P + world - 1) // world
+    for k in GRAD_KEYS_SR:
+        if grad_sync == "all_reduce":
+            full = ranks[0][k]
+            np.testing.assert_array_equal(ranks[1][k], full)
+        else:
+            full = np.zeros_like(ref[k])
+            for r in range(world):
+                sl = slice(r * rows, min(P, (r + 1) * rows))
+                full[sl] = ranks[r][k][sl]
+                outside = np.ones(P, bool); outside[sl] = False
+                assert float(np.abs(ranks[r][k][outside]).max(initial=0.0)) == 0.0
+        parity(k, full, ref[k])
+
+
+def test_shell_edges_balance_and_cover():
+    import lidargs_dist
+    scene = sc.make_scene("street", 50_000, 16, 5)
+    e = lidargs_dist.shell_edges(torch.from_numpy(scene["means3D"]), torch.from_numpy(scene["viewmatrix"]), 4, 0, 80)
+    assert e.shape == (5,) and e[0] == float("-inf") and e[-1] == float("inf")
+    assert torch.all(e[1:] > e[:-1])
+    r = np.linalg.norm(scene["means3D"], axis=1)
+    inside = r < 80
+    counts = np.histogram(r[inside], bins=np.array([-1.0] + e[1:-1].tolist() + [1e9]))[0]
+    assert counts.min() > 0.8 * inside.sum() / 4 and counts.max() < 1.2 * inside.sum() / 4
+
+
+def test_single_comm_world_of_one_equals_plain_oracle():
+    """The shell machinery with one rank degenerates to the plain single-GPU walk."""
+    import lidargs_dist
+    from dist_backend_oracle import OracleShellBackend
+    from util import oracle_forward_backward, parity
+    kind, P, H, W, seed = "shell", 3000, 16, 256, 41
+    scene = sc.make_scene(kind, P, H, seed)
+    scene["bg"] = np.array([0.2, 0.1], np.float32)
+    rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.SingleComm(), OracleShellBackend())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
+    lv = {k: t(scene[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    m2 = torch.zeros(P, 4, requires_grad=True)
+    color, depth, occ, radii = rast(lv["means3D"], m2, lv["opacities"], lv["colors"], lv["scales"], lv["rotations"])
+    grads = sc.upstream_grads(H, W, seed)
+    torch.autograd.backward([color, depth, occ], [torch.from_numpy(g) for g in grads])
+    ref = oracle_forward_backward(scene, W, H, grads)
+    parity("color", color.detach().numpy(), ref["color"]); parity("depth", depth.detach().numpy(), ref["depth"])
+    parity("dL_dmeans3D", lv["means3D"].grad.numpy(), ref["dL_dmeans3D"])
+    parity("dL_dopacity", lv["opacities"].grad.numpy(), ref["dL_dopacity"])
