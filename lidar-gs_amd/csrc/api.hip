@@ -61,6 +61,17 @@ int tile_rows() {
     return th;
 }
 
+int max_segments() {
+    static int v = [] {
+        const char* e = getenv("LIDARGS_MAX_SEGMENTS");
+        int m = e ? atoi(e) : 16;
+        if (m < 1) m = 1;
+        if (m > 64) m = 64;
+        return m;
+    }();
+    return v;
+}
+
 int ceil_log2(uint32_t n) {
     int b = 0;
     while ((1u << b) < n && b < 31) b++;
@@ -162,9 +173,11 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (R > (size_t)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
     g_prof.mark("scan+readback", stream);
 
-    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, nullptr));
+    const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
+    const int S = lg::choose_segments(R, grid.num_tiles(), max_segments());
+    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, patches, S, nullptr));
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
-    lg::BinView bin; lg::bin_carve(bin_p, R, &bin);
+    lg::BinView bin; lg::bin_carve(bin_p, R, patches, S, &bin);
 
     // 3. emit instances in range order, bin them by tile (stable)
     const uint32_t* point_list = bin.val_a;
@@ -189,8 +202,10 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     lg::RenderFwdArgs ra;
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = point_list; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
-    ra.final_T = img.final_T; ra.n_contrib = img.n_contrib; ra.T_pass = T_out;
+    ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
+    ra.seg = bin.seg; ra.S = S;
+    ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
     ra.transmittance_only = transmittance_pass;
     lg::launch_render_forward(ra, stream);
     LG_STAGE_CHECK("render forward");
@@ -222,8 +237,10 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
 
     const int TH = tile_rows();
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
+    const int S = lg::choose_segments((size_t)R, grid.num_tiles(), max_segments());
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
-    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, &bin);
+    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
     g_prof.begin(stream);
 
@@ -232,10 +249,11 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
 
     lg::RenderBwdArgs rb;
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
-    rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T; rb.n_contrib = img.n_contrib;
+    rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
+    rb.seg = bin.seg; rb.S = S;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
-    if (R) lg::launch_render_backward(rb, stream);
+    lg::launch_render_backward(rb, stream);
     LG_STAGE_CHECK("render backward");
     g_prof.mark("render_bwd", stream);
 
@@ -355,14 +373,18 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "render_shell: missing forward buffers%s");
     const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());
+    const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
+    const int S = lg::choose_segments((size_t)R, grid.num_tiles(), max_segments());
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
-    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, &bin);
+    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
     lg::RenderFwdArgs ra;
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = bin.val_a; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
-    ra.final_T = img.final_T; ra.n_contrib = img.n_contrib; ra.T_pass = T_out;
+    ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
+    ra.seg = bin.seg; ra.S = S;
+    ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
     lg::launch_render_forward(ra, stream);

@@ -30,6 +30,16 @@
 #define LG_WAVE_ROWS 4        // one wave64 = 16 columns x 4 rows of pixels
 #define LG_CHANNELS 2
 
+// per-(patch, segment) planes of 64 floats written by the forward blend (render.hip)
+#define LG_SEG_TPASS 0    // pass 1: transmittance handed to the next segment (< 1e-4 if the walk tripped)
+#define LG_SEG_C0 1       // pass 2: partial sums, already weighted by the global transmittance
+#define LG_SEG_C1 2
+#define LG_SEG_D 3
+#define LG_SEG_TEND 4     // T after the segment's last blended entry
+#define LG_SEG_TBREAK 5   // = TEND, or the value that tripped T < 1e-4 inside the segment
+#define LG_SEG_LAST 6     // u32: entries of the segment consumed up to the last blended one
+#define LG_SEG_PLANES 7
+
 namespace lg {
 
 struct Carver {
@@ -100,9 +110,19 @@ struct BinView {
     uint32_t* val_a; uint32_t* val_b;
     uint32_t* scratch;
     size_t scratch_words;
+    float* seg;                          // [patches][S][LG_SEG_PLANES][64]
 };
 
-inline size_t bin_carve(char* base, size_t R, BinView* v) {
+// Number of list segments per tile: a pure function of (R, tiles) so that backward recomputes it.
+inline int choose_segments(size_t R, int tiles, int max_segments) {
+    const size_t avg = tiles > 0 ? R / (size_t)tiles : 0;
+    size_t s = (avg + 127) / 128;
+    if (s < 1) s = 1;
+    if (s > (size_t)max_segments) s = (size_t)max_segments;
+    return (int)s;
+}
+
+inline size_t bin_carve(char* base, size_t R, size_t patches, int S, BinView* v) {
     Carver c(base);
     BinView b;
     size_t n = R ? R : 1;
@@ -110,13 +130,14 @@ inline size_t bin_carve(char* base, size_t R, BinView* v) {
     b.val_a = c.take<uint32_t>(n); b.val_b = c.take<uint32_t>(n);
     b.scratch_words = sort_scratch_words(n);
     b.scratch = c.take<uint32_t>(b.scratch_words);
+    b.seg = c.take<float>(patches * (size_t)S * LG_SEG_PLANES * 64);
     if (v) *v = b;
     return (size_t)(c.p - base) + 128;
 }
 
 struct ImgView {
     float* final_T;       // T at the end of this call's list (after early-out)
-    uint32_t* n_contrib;  // entries of the tile list consumed up to the last blended one
+    uint32_t* n_contrib;  // (unused since the segmented blend: per-segment counts live in the binning buffer)
     float* T_pass;        // transmittance handed to the next range shell (multi-GPU only)
     uint2* ranges;        // [tiles]
     float2* coltab;       // [W]  (cos beta, sin beta)
@@ -189,8 +210,10 @@ struct RenderFwdArgs {
     const float2* coltab; const float2* rowtab;
     const float* bg;          // device [2] or nullptr (= 0)
     const float* T_in;        // nullptr = 1
-    float* final_T; uint32_t* n_contrib; float* T_pass;
+    float* final_T; float* T_pass;
     float* out_color; float* out_depth; float* out_occ;
+    float* seg; int S;        // per-(patch, segment) planes, segments per list
+    int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
 };
 void launch_render_forward(const RenderFwdArgs& a, hipStream_t s);
@@ -200,7 +223,8 @@ struct RenderBwdArgs {
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const uint32_t* rowspan;
     const float2* coltab; const float2* rowtab;
     const float* bg;
-    const float* final_T; const uint32_t* n_contrib;
+    const float* final_T;
+    const float* seg; int S;
     const float* T_final_global;   // nullptr = final_T (single GPU)
     const float* behind;           // nullptr or f32[3*N]: colour0, colour1, depth sums of farther shells
     const float* dL_dpix; const float* dL_ddepth; const float* dL_docc;

@@ -2,26 +2,38 @@
 //
 // Replaces renderCUDA fwd (R3/cr/forward.cu:502-641) and bwd (R3/cr/backward.cu:535-791).
 //
-// Mapping.  The reference runs 16-thread blocks (a quarter of a wave64) on 16x1 tiles and
+// Pixel mapping.  The reference runs 16-thread blocks (a quarter of a wave64) on 16x1 tiles and
 // re-evaluates cos/sin of the pixel ray for every (pixel, Gaussian) pair.  Here one wave64 owns a
-// 16-column x 4-row pixel patch; a list tile is 16 columns x TH rows (TH/4 waves, each an
-// independent 64-thread workgroup, so there are no workgroup barriers across waves).  The 16-pixel
-// tile WIDTH is kept equal to the reference's BLOCK_X so that "is this pixel inside the
+// 16-column x 4-row pixel patch; a list tile is 16 columns x TH rows (TH/4 "sub" patches).  The
+// 16-pixel tile WIDTH is kept equal to the reference's BLOCK_X so that "is this pixel inside the
 // Gaussian's rect" -- which is observable, because the rect truncates the footprint at ~3 sigma
-// where alpha can still exceed 1/255 -- reduces to a per-lane test on the pixel ROW only
-// (ymin <= y < ymax): tile columns are shared with the reference grid.
+// where alpha can still exceed 1/255 -- reduces to a per-lane test on the pixel ROW only.
 //
-// Per chunk of 64 list entries: lane l gathers entry l's 64-byte splat record (one aligned
-// segment) + row span into registers while the previous chunk is being composited, then parks it
-// in LDS component-major; the inner loop reads entry j with four broadcast ds_read_b128.
-// The pixel's unit ray comes from two small tables (cos/sin per row and per column).
+// List segments.  Per-pixel compositing is a serial chain through T, and a 64 x 2650 image has only
+// 2656 patches for 1024 SIMDs, so a single walk per patch is bound by the LONGEST list times the
+// per-entry latency (measured: 16k entries x ~180 cycles).  Every tile list is therefore cut into S
+// equal segments and each (patch, segment) is its own 64-thread workgroup:
+//   pass 1  (T only)  every segment walks its entries from T = 1            -> Tpass[patch][seg][lane]
+//   pass 2  (full)    segment k starts from T_in = prod_{j<k} Tpass[j]; the reference's T < 1e-4 stop is
+//                     applied to this GLOBAL transmittance, so a pixel's walk is exactly the serial one;
+//                     segments behind the stop see T_in < 1e-4 and retire immediately
+//   combine           per patch: sum the segments' partial sums, pick T_final, write the image
+//   backward          one workgroup per segment again; its "colour behind" recurrences are seeded with the
+//                     partial sums of the segments (and, multi-GPU, range shells) behind it.
+// If a segment's walk trips T < 1e-4, Tpass holds the value that tripped it (< 1e-4), so every later
+// segment is shut off; otherwise Tpass is the exact product of its (1 - alpha).  This is the same
+// two-phase scheme lidargs_dist.py uses across GPUs, applied across the CUs of one GPU.
 //
-// Backward.  The reference issues 20 global float atomics per contributing (pixel, Gaussian)
-// pair.  Here the 64 pixels of a wave handle the SAME Gaussian in the same step, so the 16 sums
-// that are needed (dL/dsphere follows by linearity from dL/dmean2D, see preprocess.hip) go through
-// a wave-level butterfly REDUCE-SCATTER (8+4+2+1+1+1 exchanges instead of 16x6), after which 16
-// lanes each hold one finished sum and issue ONE atomic instruction into a packed 64-byte
-// accumulator line of that Gaussian.  Entries no lane contributes to are skipped wholesale.
+// Per chunk of 64 list entries: lane l gathers entry l's 64-byte splat record (one aligned segment)
+// + row span into registers while the previous chunk is being composited, then parks it in LDS
+// component-major; the inner loop reads entry j with four broadcast ds_read_b128.
+//
+// Backward sums.  The reference issues 20 global float atomics per contributing (pixel, Gaussian)
+// pair.  Here the 64 pixels of a wave handle the SAME Gaussian in the same step, so the 16 sums that
+// are needed (dL/dsphere follows by linearity from dL/dmean2D, see preprocess.hip) go through a
+// wave-level butterfly REDUCE-SCATTER (8+4+2+1+1+1 exchanges instead of 16x6), after which 16 lanes
+// each hold one finished sum and issue ONE atomic instruction into a packed 64-byte accumulator line
+// of that Gaussian.  Entries no lane contributes to are skipped wholesale.
 #include "lidargs_common.h"
 
 namespace lg {
@@ -66,59 +78,80 @@ __device__ __forceinline__ Staged gather_entry(const uint32_t* __restrict__ poin
     return s;
 }
 
+// [start, end) of segment `seg` of a tile list
+__device__ __forceinline__ uint2 segment_range(uint2 range, int S, int seg) {
+    const uint32_t L = range.y - range.x;
+    const uint32_t len = (L + (uint32_t)S - 1u) / (uint32_t)S;
+    const uint32_t a = min(range.y, range.x + (uint32_t)seg * len);
+    const uint32_t b = min(range.y, a + len);
+    return make_uint2(a, b);
+}
+
 // ------------------------------------------------------------------------------------------------
+// One workgroup = (patch, segment).  T_ONLY: pass 1.  Otherwise pass 2.
 template <bool T_ONLY>
 __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
     __shared__ uint32_t s_span[LG_CHUNK];
     const int lane = threadIdx.x;
+    const int S = a.S;
+    const int seg = blockIdx.x % S;
+    const int patch = blockIdx.x / S;                                  // = tile * waves_per_tile + sub
     const int wpt = a.grid.waves_per_tile;
-    const int tile = blockIdx.x / wpt, sub = blockIdx.x - tile * wpt;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
     const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
-    const uint2 range = a.ranges[tile];
-    const uint32_t n = range.y - range.x;
+    const uint2 sr = segment_range(a.ranges[tile], S, seg);
+    const uint32_t n = sr.y - sr.x;
+    float* segbase = a.seg + ((size_t)patch * S + seg) * (LG_SEG_PLANES * 64);
 
     float T = 1.0f;
-    if (a.T_in && px.inside) T = a.T_in[px.pix];
+    if (!T_ONLY) {
+        if (a.T_in && px.inside) T = a.T_in[px.pix];
+        const float* tp = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + LG_SEG_TPASS * 64 + lane;
+        for (int k = 0; k < seg; k++) T *= tp[(size_t)k * (LG_SEG_PLANES * 64)];
+    }
     float T_break = T;
     float C0 = 0.f, C1 = 0.f, D = 0.f;
     uint32_t last = 0;
-    bool done = !px.inside;
+    // a lane that starts below the threshold can never blend again: every contributing entry trips T < 1e-4
+    bool done = !px.inside || (!T_ONLY && T < 0.0001f);
 
     const uint32_t nchunks = (n + LG_CHUNK - 1) / LG_CHUNK;
-    Staged st = gather_entry(a.point_list, a.rec, a.rowspan, range.x + lane, (uint32_t)lane < n);
-    for (uint32_t c = 0; c < nchunks; c++) {
-        __syncthreads();
-        s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
-        s_span[lane] = st.span;
-        __syncthreads();
-        if (c + 1 < nchunks) {
-            const uint32_t k = (c + 1) * LG_CHUNK + lane;
-            st = gather_entry(a.point_list, a.rec, a.rowspan, range.x + k, k < n);
-        }
-        const uint32_t cnt = min((uint32_t)LG_CHUNK, n - c * LG_CHUNK);
-        if (__ballot(!done) == 0ull) break;                           // R3/cr/forward.cu:559-561 early-out
-        for (uint32_t j = 0; j < cnt; j++) {
-            const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
-            const uint32_t span = s_span[j];
-            const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-            if (!done && rows) {
-                const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-                const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
-                const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
-                const float power = -0.5f * (r1.w * dx * dx + r3.x * dy * dy) - r2.w * dx * dy;   // :601
-                if (power <= 0.0f) {
-                    const float alpha = fminf(0.99f, r3.y * __expf(power));
-                    if (alpha >= 1.0f / 255.0f) {
-                        const float test_T = T * (1.f - alpha);
-                        if (test_T < 0.0001f) { done = true; T_break = test_T; }
-                        else {
-                            if (!T_ONLY) {
-                                const float w = alpha * T;
-                                C0 += r3.z * w; C1 += r3.w * w; D += r0.w * w;
+    if (__ballot(!done) != 0ull && n > 0) {
+        Staged st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + lane, (uint32_t)lane < n);
+        for (uint32_t c = 0; c < nchunks; c++) {
+            __syncthreads();
+            s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
+            s_span[lane] = st.span;
+            __syncthreads();
+            if (c + 1 < nchunks) {
+                const uint32_t k = (c + 1) * LG_CHUNK + lane;
+                st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + k, k < n);
+            }
+            const uint32_t cnt = min((uint32_t)LG_CHUNK, n - c * LG_CHUNK);
+            if (__ballot(!done) == 0ull) break;                       // R3/cr/forward.cu:559-561 early-out
+            for (uint32_t j = 0; j < cnt; j++) {
+                const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
+                const uint32_t span = s_span[j];
+                const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
+                if (!done && rows) {
+                    const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
+                    const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
+                    const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
+                    const float power = -0.5f * (r1.w * dx * dx + r3.x * dy * dy) - r2.w * dx * dy;   // :601
+                    if (power <= 0.0f) {
+                        const float alpha = fminf(0.99f, r3.y * __expf(power));
+                        if (alpha >= 1.0f / 255.0f) {
+                            const float test_T = T * (1.f - alpha);
+                            if (test_T < 0.0001f) { done = true; T_break = test_T; }
+                            else {
+                                if (!T_ONLY) {
+                                    const float w = alpha * T;
+                                    C0 += r3.z * w; C1 += r3.w * w; D += r0.w * w;
+                                }
+                                T = test_T; T_break = test_T;
+                                last = c * LG_CHUNK + j + 1;
                             }
-                            T = test_T; T_break = test_T;
-                            last = c * LG_CHUNK + j + 1;
                         }
                     }
                 }
@@ -126,25 +159,68 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
         }
     }
 
-    if (px.inside) {
-        if (a.T_pass) a.T_pass[px.pix] = T_break;
-        if (!T_ONLY) {
-            const size_t N = (size_t)a.grid.W * a.grid.H;
-            a.final_T[px.pix] = T;
-            a.n_contrib[px.pix] = last;
-            const float b0 = a.bg ? a.bg[0] : 0.f, b1 = a.bg ? a.bg[1] : 0.f;
-            a.out_color[px.pix] = C0 + T * b0;                         // :637
-            a.out_color[N + px.pix] = C1 + T * b1;
-            a.out_depth[px.pix] = D;
-            a.out_occ[px.pix] = 1.f - T;
-        }
+    if (T_ONLY) {
+        segbase[LG_SEG_TPASS * 64 + lane] = T_break;
+    } else {
+        segbase[LG_SEG_C0 * 64 + lane] = C0;
+        segbase[LG_SEG_C1 * 64 + lane] = C1;
+        segbase[LG_SEG_D * 64 + lane] = D;
+        segbase[LG_SEG_TEND * 64 + lane] = T;
+        segbase[LG_SEG_TBREAK * 64 + lane] = T_break;
+        reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = last;
     }
 }
 
+// Per patch: fold the segments (pass 2 results, or pass 1 products when t_only) into the image planes.
+__global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
+    const int lane = threadIdx.x;
+    const int S = a.S;
+    const int patch = blockIdx.x;
+    const int wpt = a.grid.waves_per_tile;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const TileGrid& g = a.grid;
+    const int x = (tile % g.tiles_x) * LG_TILE_W + (lane & 15);
+    const int y = (tile / g.tiles_x) * g.TH + sub * LG_WAVE_ROWS + (lane >> 4);
+    if (x >= g.W || y >= g.H) return;
+    const int pix = y * g.W + x;
+    const float* sb = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + lane;
+    const size_t stride = LG_SEG_PLANES * 64;
+
+    if (a.transmittance_only) {
+        // hand-over value of the whole list: product of the segments' (a tripped segment makes it < 1e-4)
+        float T = 1.f;
+        for (int k = 0; k < S; k++) T *= sb[k * stride + LG_SEG_TPASS * 64];
+        if (a.T_pass) a.T_pass[pix] = T;
+        return;
+    }
+    float C0 = 0.f, C1 = 0.f, D = 0.f;
+    float T_final = a.T_in ? a.T_in[pix] : 1.f, T_hand = T_final;
+    bool stopped = false;
+    for (int k = 0; k < S; k++) {
+        if (stopped) break;
+        C0 += sb[k * stride + LG_SEG_C0 * 64];
+        C1 += sb[k * stride + LG_SEG_C1 * 64];
+        D += sb[k * stride + LG_SEG_D * 64];
+        T_final = sb[k * stride + LG_SEG_TEND * 64];
+        T_hand = sb[k * stride + LG_SEG_TBREAK * 64];
+        stopped = T_hand < 0.0001f;                                    // the walk ended inside segment k
+    }
+    const size_t N = (size_t)g.W * g.H;
+    a.final_T[pix] = T_final;
+    if (a.T_pass) a.T_pass[pix] = T_hand;
+    const float b0 = a.bg ? a.bg[0] : 0.f, b1 = a.bg ? a.bg[1] : 0.f;
+    a.out_color[pix] = C0 + T_final * b0;                              // :637
+    a.out_color[N + pix] = C1 + T_final * b1;
+    a.out_depth[pix] = D;
+    a.out_occ[pix] = 1.f - T_final;
+}
+
 void launch_render_forward(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
-    if (a.transmittance_only) hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
+    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    const unsigned blocks = patches * (unsigned)a.S;
+    if (a.run_pass1) hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
+    if (!a.transmittance_only) hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_render_combine, dim3(patches), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,39 +268,54 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     __shared__ uint32_t s_span[LG_CHUNK];
     __shared__ uint32_t s_gid[LG_CHUNK];
     const int lane = threadIdx.x;
+    const int S = a.S;
+    const int seg = blockIdx.x % S;
+    const int patch = blockIdx.x / S;
     const int wpt = a.grid.waves_per_tile;
-    const int tile = blockIdx.x / wpt, sub = blockIdx.x - tile * wpt;
-    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
-    const uint2 range = a.ranges[tile];
-    const size_t N = (size_t)a.grid.W * a.grid.H;
-
-    const uint32_t n_lane = px.inside ? a.n_contrib[px.pix] : 0u;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const size_t stride = LG_SEG_PLANES * 64;
+    const float* sb = a.seg + (size_t)patch * S * stride + lane;      // this patch's segment planes, this lane
+    const uint32_t n_lane = reinterpret_cast<const uint32_t*>(sb)[(size_t)seg * stride + LG_SEG_LAST * 64];
     uint32_t n_max = n_lane;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
-    if (n_max == 0) return;
+    if (n_max == 0) return;                                            // nothing blended in this segment
 
-    // per-pixel state of the back-to-front walk (R3/cr/backward.cu:590-615)
-    float T = px.inside ? a.final_T[px.pix] : 0.f;
-    const float T_final = a.T_final_global ? (px.inside ? a.T_final_global[px.pix] : 0.f) : T;
+    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
+    const uint2 sr = segment_range(a.ranges[tile], S, seg);
+    const size_t N = (size_t)a.grid.W * a.grid.H;
+
+    // per-pixel state of the back-to-front walk (R3/cr/backward.cu:590-615), restricted to this segment:
+    // T starts at the segment's own end value; the "colour behind" recurrences are seeded with everything
+    // composited behind the segment (later segments of this list + farther range shells), as seen from here.
+    float T = sb[(size_t)seg * stride + LG_SEG_TEND * 64];
+    const float T_final = px.inside ? (a.T_final_global ? a.T_final_global[px.pix] : a.final_T[px.pix]) : 0.f;
     float g0 = 0.f, g1 = 0.f, gd = 0.f, go = 0.f;
     if (px.inside) { g0 = a.dL_dpix[px.pix]; g1 = a.dL_dpix[N + px.pix]; gd = a.dL_ddepth[px.pix]; go = a.dL_docc[px.pix]; }
     const float bgdot = a.bg ? (a.bg[0] * g0 + a.bg[1] * g1) : 0.f;
     float acc0 = 0.f, acc1 = 0.f, accd = 0.f, acco = 0.f;           // accum_rec[2], accum_red, accum_reo
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, ld = 0.f;
-    if (a.behind && px.inside && T > 0.f) {
-        // what lies behind this range shell, as seen from its far boundary (multi-GPU only)
-        const float inv = 1.f / T;
-        acc0 = a.behind[px.pix] * inv; acc1 = a.behind[N + px.pix] * inv; accd = a.behind[2 * N + px.pix] * inv;
-        acco = 1.f - T_final * inv;
+    {
+        float b0 = 0.f, b1 = 0.f, bd = 0.f;
+        for (int k = seg + 1; k < S; k++) {
+            b0 += sb[(size_t)k * stride + LG_SEG_C0 * 64];
+            b1 += sb[(size_t)k * stride + LG_SEG_C1 * 64];
+            bd += sb[(size_t)k * stride + LG_SEG_D * 64];
+        }
+        if (a.behind && px.inside) { b0 += a.behind[px.pix]; b1 += a.behind[N + px.pix]; bd += a.behind[2 * N + px.pix]; }
+        if (T > 0.f) {
+            const float inv = 1.f / T;
+            acc0 = b0 * inv; acc1 = b1 * inv; accd = bd * inv;
+            acco = 1.f - T_final * inv;
+        }
     }
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, ld = 0.f;
 
     const int c_last = (int)((n_max - 1) / LG_CHUNK);
     auto gather = [&](int c, Staged& st, uint32_t& gid) {
         const uint32_t k = (uint32_t)c * LG_CHUNK + lane;
         const bool valid = k < n_max;
-        gid = valid ? a.point_list[range.x + k] : 0u;
-        st = gather_entry(a.point_list, a.rec, a.rowspan, range.x + k, valid);
+        gid = valid ? a.point_list[sr.x + k] : 0u;
+        st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + k, valid);
     };
     Staged st; uint32_t gid;
     gather(c_last, st, gid);
@@ -236,7 +327,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
         if (c > 0) gather(c - 1, st, gid);
         const int hi = (int)min((uint32_t)LG_CHUNK, n_max - (uint32_t)c * LG_CHUNK) - 1;
         for (int j = hi; j >= 0; j--) {
-            const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based list position
+            const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based position inside the segment
             const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
             const uint32_t span = s_span[j];
             const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
@@ -305,7 +396,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
 }
 
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
-    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile) * (unsigned)a.S;
     hipLaunchKernelGGL(k_render_backward, dim3(blocks), dim3(64), 0, s, a);
 }
 
