@@ -7,8 +7,8 @@
 One "step" = one frame: GaussianRasterizer.forward + .backward with non-zero upstream gradients on
 colour, depth and occupancy, inputs already resident in HBM (BASELINE.json metric).
 N = 1: the whole scene on one GPU.  N > 1: the SAME scene (strong scaling), Gaussians sharded by
-range shell across the ranks, RCCL all-gather of the per-shell transmittance plane, all-reduce of
-the W x H x C partial range images and all-gather of the per-Gaussian gradient rows (lidargs_dist.py).
+range shell across the ranks: RCCL all-gather of the per-shell transmittance plane, all-gather of the
+W x H x 5 partial planes, reduce-scatter of the packed per-Gaussian gradient rows (lidargs_dist.py).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     for the dominant kernel (the backward blend): ALGORITHMIC bytes per launch
@@ -118,7 +118,10 @@ def main():
             torch.autograd.backward([color, depth, occ], [gc, gd, go])
     else:
         import lidargs_dist
-        rast = lidargs_dist.ShellRasterizer(settings, lidargs_dist.TorchDistComm())
+        comm = lidargs_dist.TorchDistComm()
+        # range-shell edges are a load-balancing choice, not a result: cut once for this (static) scene and view
+        edges = comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80), 0)
+        rast = lidargs_dist.ShellRasterizer(settings, comm, edges=edges)
 
         def step():
             for t in list(leaves.values()) + [means2D]:
@@ -133,10 +136,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    _C.profile_enable(True)             # pre-creates the event pool (one-off cost, outside the timed region)
     for _ in range(args.warmup):
         step()
     barrier()
-    _C.profile_enable(True)             # events only, no host waits (lidargs_profile_summary reads them afterwards)
+    _C.profile_enable(True)             # reset: from here on only hipEventRecord per stage, no host waits
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

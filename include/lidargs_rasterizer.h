@@ -234,7 +234,8 @@ void lidargs_profile_enable(int on);
 int lidargs_profile_read(float* ms_out, int max_stages);      /* returns #stages written     */
 const char* lidargs_profile_stage_name(int stage);            /* NULL past the last stage    */
 /* Aggregate of all calls recorded since lidargs_profile_enable(1) (up to 512): per distinct stage
- * name the summed milliseconds and sample count; returns the number of names written. */
+ * name the summed milliseconds and sample count; returns the number of names written.
+ * (at most 256 calls are kept; lidargs_profile_enable(1) pre-creates the events and resets.) */
 int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* count_out, int max_stages);
 
 /* Counters of the last forward on this thread: [0]=P, [1]=visible Gaussians V,

@@ -64,7 +64,7 @@ int tile_rows() {
 int max_segments() {
     static int v = [] {
         const char* e = getenv("LIDARGS_MAX_SEGMENTS");
-        int m = e ? atoi(e) : 16;
+        int m = e ? atoi(e) : 32;
         if (m < 1) m = 1;
         if (m > 64) m = 64;
         return m;
@@ -82,7 +82,7 @@ int ceil_log2(uint32_t n) {
 // While enabled, every forward/backward call records one HIP event per stage boundary on the op's
 // own stream into a fresh slot; nothing is waited for until lidargs_profile_read()/summary().
 struct Profiler {
-    static constexpr int MAX_CALLS = 512;
+    static constexpr int MAX_CALLS = 256;
     struct Call { int n = 0; const char* names[LIDARGS_MAX_STAGES]; hipEvent_t ev[LIDARGS_MAX_STAGES + 1]; bool created = false; };
     bool enabled = false;
     int ncalls = 0;          // calls recorded since enable
@@ -175,9 +175,9 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
     const int S = lg::choose_segments(R, grid.num_tiles(), max_segments());
-    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, patches, S, nullptr));
+    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, patches, grid.waves_per_tile, S, nullptr));
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
-    lg::BinView bin; lg::bin_carve(bin_p, R, patches, S, &bin);
+    lg::BinView bin; lg::bin_carve(bin_p, R, patches, grid.waves_per_tile, S, &bin);
 
     // 3. emit instances in range order, bin them by tile (stable)
     const uint32_t* point_list = bin.val_a;
@@ -206,6 +206,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
     ra.seg = bin.seg; ra.S = S;
     ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
+    ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = R;
     ra.transmittance_only = transmittance_pass;
     lg::launch_render_forward(ra, stream);
     LG_STAGE_CHECK("render forward");
@@ -221,7 +222,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
 int backward_impl(int P, int R, const float* background, int width, int height, const float* means3D,
                   const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                   const float* cov3D_precomp, const float* viewmatrix, const float* beams, const int* radii, char* geom_buffer,
-                  char* binning_buffer, char* image_buffer, const float* behind, const float* T_final_global,
+                  char* binning_buffer, char* image_buffer, const float* behind, const float* T_final_global, int shell_mode,
                   const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ, float* dL_dmean2D,
                   float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths, float* dL_dmean3D,
                   float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2, float* dL_dcov3D, float* dL_dscale,
@@ -240,7 +241,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
     const int S = lg::choose_segments((size_t)R, grid.num_tiles(), max_segments());
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
-    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, S, &bin);
+    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
     g_prof.begin(stream);
 
@@ -251,6 +252,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
     rb.seg = bin.seg; rb.S = S;
+    rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = (size_t)R;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
     lg::launch_render_backward(rb, stream);
@@ -305,7 +307,7 @@ int lidargs_backward(int P, int D, int M, int R, const float* background, int wi
                      int debug, void* stream) {
     (void)D; (void)M; (void)shs; (void)projmatrix; (void)campos; (void)tan_fovx; (void)tan_fovy; (void)dL_dsh;
     return backward_impl(P, R, background, width, height, means3D, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                         viewmatrix, beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, nullptr, nullptr, dL_dpix,
+                         viewmatrix, beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, nullptr, nullptr, 0, dL_dpix,
                          dL_dout_depth, dL_dout_occ, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepths, dL_dmean3D,
                          dL_dsphere_means3D, dL_dbasis_u1, dL_dbasis_u2, dL_dcov3D, dL_dscale, dL_drot, debug, (hipStream_t)stream);
 }
@@ -376,7 +378,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
     const int S = lg::choose_segments((size_t)R, grid.num_tiles(), max_segments());
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
-    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, S, &bin);
+    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
     lg::RenderFwdArgs ra;
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = bin.val_a; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
@@ -384,6 +386,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
     ra.seg = bin.seg; ra.S = S;
+    ra.flags = bin.flags; ra.R = (size_t)R;      // written by the shell's phase 1 (lidargs_forward_shell)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
@@ -403,14 +406,23 @@ int lidargs_backward_shell(int P, int R, const float* background, int width, int
                            float* dL_dmean3D, float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2,
                            float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug, void* stream) {
     return backward_impl(P, R, background, width, height, means3D, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                         viewmatrix, beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, behind, T_final_global,
+                         viewmatrix, beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, behind, T_final_global, 1,
                          dL_dpix, dL_dout_depth, dL_dout_occ, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepths, dL_dmean3D,
                          dL_dsphere_means3D, dL_dbasis_u1, dL_dbasis_u2, dL_dcov3D, dL_dscale, dL_drot, debug, (hipStream_t)stream);
 }
 
 void lidargs_profile_enable(int on) {
+    if (on) {
+        // create every event up front so that the timed region only pays for hipEventRecord
+        if (!g_prof.calls) g_prof.calls = new Profiler::Call[Profiler::MAX_CALLS];
+        for (int i = 0; i < Profiler::MAX_CALLS; i++) {
+            Profiler::Call& c = g_prof.calls[i];
+            if (!c.created) { for (auto& e : c.ev) (void)hipEventCreate(&e); c.created = true; }
+            c.n = 0;
+        }
+        g_prof.ncalls = 0;
+    }
     g_prof.enabled = on != 0;
-    if (on) g_prof.ncalls = 0;
 }
 
 // stages of the most recent recorded call

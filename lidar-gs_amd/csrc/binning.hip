@@ -110,13 +110,20 @@ __global__ void __launch_bounds__(64) k_radix_hist(const uint32_t* __restrict__ 
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t cnt[BINS];
     const int lane = threadIdx.x;
-    for (int d = lane; d < BINS; d += 64) cnt[d] = 0;
-    __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
-#pragma unroll 4
+    // all loads first (one wave per block: nothing else hides the HBM latency), then the LDS counting
+    uint32_t k[SORT_ITEMS];
+#pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
-        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & (BINS - 1)], 1u);
+        k[r] = i < n ? keys[i] : 0u;
+    }
+    for (int d = lane; d < BINS; d += 64) cnt[d] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        const size_t i = base + (size_t)r * 64 + lane;
+        if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (BINS - 1)], 1u);
     }
     __syncthreads();
     for (int d = lane; d < BINS; d += 64) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
@@ -129,17 +136,22 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const uint32_t* __restrict
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t run[BINS];
     const int lane = threadIdx.x;
-    for (int d = lane; d < BINS; d += 64) run[d] = bases[(size_t)d * nblocks + blockIdx.x];
-    __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t k[SORT_ITEMS], v[SORT_ITEMS], pos[SORT_ITEMS];
+#pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
-        if (base + (size_t)r * 64 >= n) break;                      // wave-uniform
         const bool valid = i < n;
-        const uint32_t k = valid ? keys_in[i] : 0u;
-        const uint32_t v = valid ? vals_in[i] : 0u;
-        const uint32_t d = (k >> shift) & (BINS - 1);
+        k[r] = valid ? keys_in[i] : 0u;
+        v[r] = valid ? vals_in[i] : 0u;
+    }
+    for (int d = lane; d < BINS; d += 64) run[d] = bases[(size_t)d * nblocks + blockIdx.x];
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        const bool valid = base + (size_t)r * 64 + lane < n;
+        const uint32_t d = (k[r] >> shift) & (BINS - 1);
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
@@ -148,11 +160,16 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const uint32_t* __restrict
             peers &= bit ? m : ~m;
         }
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        const uint32_t pos = run[d] + rank;
-        __syncthreads();                                              // all reads of run[] before the leaders update it
+        // One wave per block: its LDS operations execute in program order, so every lane's read of run[d]
+        // is served before the group leaders' updates below, and the next round sees them.
+        pos[r] = run[d] + rank;
+        __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) run[d] += (uint32_t)__popcll(peers);
-        __syncthreads();
-        if (valid) { keys_out[pos] = k; vals_out[pos] = v; }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        if (base + (size_t)r * 64 + lane < n) { keys_out[pos[r]] = k[r]; vals_out[pos[r]] = v[r]; }
     }
 }
 

@@ -111,6 +111,7 @@ struct BinView {
     uint32_t* scratch;
     size_t scratch_words;
     float* seg;                          // [patches][S][LG_SEG_PLANES][64]
+    uint8_t* flags;                      // [waves_per_tile][R]: pass 1 saw >= 1 pixel of the patch take this entry
 };
 
 // Number of list segments per tile: a pure function of (R, tiles) so that backward recomputes it.
@@ -122,7 +123,7 @@ inline int choose_segments(size_t R, int tiles, int max_segments) {
     return (int)s;
 }
 
-inline size_t bin_carve(char* base, size_t R, size_t patches, int S, BinView* v) {
+inline size_t bin_carve(char* base, size_t R, size_t patches, int waves_per_tile, int S, BinView* v) {
     Carver c(base);
     BinView b;
     size_t n = R ? R : 1;
@@ -131,6 +132,7 @@ inline size_t bin_carve(char* base, size_t R, size_t patches, int S, BinView* v)
     b.scratch_words = sort_scratch_words(n);
     b.scratch = c.take<uint32_t>(b.scratch_words);
     b.seg = c.take<float>(patches * (size_t)S * LG_SEG_PLANES * 64);
+    b.flags = c.take<uint8_t>((size_t)waves_per_tile * n + 64);
     if (v) *v = b;
     return (size_t)(c.p - base) + 128;
 }
@@ -213,6 +215,7 @@ struct RenderFwdArgs {
     float* final_T; float* T_pass;
     float* out_color; float* out_depth; float* out_occ;
     float* seg; int S;        // per-(patch, segment) planes, segments per list
+    uint8_t* flags; size_t R; // per-(sub, entry) contribution flags written by pass 1 (nullptr when pass 1 never runs)
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
 };
@@ -225,6 +228,7 @@ struct RenderBwdArgs {
     const float* bg;
     const float* final_T;
     const float* seg; int S;
+    const uint8_t* flags; size_t R;
     const float* T_final_global;   // nullptr = final_T (single GPU)
     const float* behind;           // nullptr or f32[3*N]: colour0, colour1, depth sums of farther shells
     const float* dL_dpix; const float* dL_ddepth; const float* dL_docc;

@@ -64,6 +64,7 @@ __device__ __forceinline__ PixelSetup pixel_setup(const TileGrid& g, const float
 
 struct Staged { float4 a0, a1, a2, a3; uint32_t span; };
 
+// `valid` already includes the contribution flag where one exists: unflagged entries are never read
 __device__ __forceinline__ Staged gather_entry(const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
                                                const uint32_t* __restrict__ rowspan, uint32_t k, bool valid) {
     Staged s;
@@ -117,23 +118,36 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     bool done = !px.inside || (!T_ONLY && T < 0.0001f);
 
     const uint32_t nchunks = (n + LG_CHUNK - 1) / LG_CHUNK;
+    // Contribution flags: pass 1 records, per (sub-patch, entry), whether ANY pixel took the entry; pass 2 (and the
+    // backward) then touch only flagged entries -- no record gather, no LDS traffic, no evaluation for the rest.
+    // Pass 1 starts from T = 1 (>= the true transmittance), so every pixel is active at least as long as in
+    // pass 2: the flagged set is a superset of what pass 2 / backward can ever blend.
+    uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
+    uint32_t c_done = 0;                                               // chunks whose flags pass 1 has written
     if (__ballot(!done) != 0ull && n > 0) {
-        Staged st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + lane, (uint32_t)lane < n);
+        auto entry_valid = [&](uint32_t k) { return k < n && (T_ONLY || !fl || fl[k] != 0); };
+        Staged st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + lane, entry_valid(lane));
+        bool have = entry_valid(lane);
         for (uint32_t c = 0; c < nchunks; c++) {
             __syncthreads();
             s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
             s_span[lane] = st.span;
+            unsigned long long todo = __ballot(have);                  // entries of this chunk worth visiting
             __syncthreads();
             if (c + 1 < nchunks) {
                 const uint32_t k = (c + 1) * LG_CHUNK + lane;
-                st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + k, k < n);
+                have = entry_valid(k);
+                st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + k, have);
             }
-            const uint32_t cnt = min((uint32_t)LG_CHUNK, n - c * LG_CHUNK);
             if (__ballot(!done) == 0ull) break;                       // R3/cr/forward.cu:559-561 early-out
-            for (uint32_t j = 0; j < cnt; j++) {
+            unsigned long long took = 0ull;
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
                 const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
                 const uint32_t span = s_span[j];
                 const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
+                bool hit = false;
                 if (!done && rows) {
                     const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
                     const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
@@ -142,6 +156,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
                     if (power <= 0.0f) {
                         const float alpha = fminf(0.99f, r3.y * __expf(power));
                         if (alpha >= 1.0f / 255.0f) {
+                            hit = true;
                             const float test_T = T * (1.f - alpha);
                             if (test_T < 0.0001f) { done = true; T_break = test_T; }
                             else {
@@ -150,12 +165,24 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
                                     C0 += r3.z * w; C1 += r3.w * w; D += r0.w * w;
                                 }
                                 T = test_T; T_break = test_T;
-                                last = c * LG_CHUNK + j + 1;
+                                last = c * LG_CHUNK + (uint32_t)j + 1;
                             }
                         }
                     }
                 }
+                if (T_ONLY && __ballot(hit) != 0ull) took |= 1ull << j;
             }
+            if (T_ONLY && fl) {
+                const uint32_t k = c * LG_CHUNK + lane;
+                if (k < n) fl[k] = (uint8_t)((took >> lane) & 1ull);
+                c_done = c + 1;
+            }
+        }
+    }
+    if (T_ONLY && fl) {                                                // entries pass 1 never reached: nobody can take them
+        for (uint32_t c = c_done; c < nchunks; c++) {
+            const uint32_t k = c * LG_CHUNK + lane;
+            if (k < n) fl[k] = 0;
         }
     }
 
@@ -311,22 +338,25 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, ld = 0.f;
 
     const int c_last = (int)((n_max - 1) / LG_CHUNK);
-    auto gather = [&](int c, Staged& st, uint32_t& gid) {
+    const uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
+    auto gather = [&](int c, Staged& st, uint32_t& gid, bool& have) {
         const uint32_t k = (uint32_t)c * LG_CHUNK + lane;
-        const bool valid = k < n_max;
-        gid = valid ? a.point_list[sr.x + k] : 0u;
-        st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + k, valid);
+        have = k < n_max && (!fl || fl[k] != 0);
+        gid = have ? a.point_list[sr.x + k] : 0u;
+        st = gather_entry(a.point_list, a.rec, a.rowspan, sr.x + k, have);
     };
-    Staged st; uint32_t gid;
-    gather(c_last, st, gid);
+    Staged st; uint32_t gid; bool have;
+    gather(c_last, st, gid, have);
     for (int c = c_last; c >= 0; c--) {
         __syncthreads();
         s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
         s_span[lane] = st.span; s_gid[lane] = gid;
+        unsigned long long todo = __ballot(have);
         __syncthreads();
-        if (c > 0) gather(c - 1, st, gid);
-        const int hi = (int)min((uint32_t)LG_CHUNK, n_max - (uint32_t)c * LG_CHUNK) - 1;
-        for (int j = hi; j >= 0; j--) {
+        if (c > 0) gather(c - 1, st, gid, have);
+        while (todo) {
+            const int j = 63 - __builtin_clzll(todo);                 // back to front
+            todo &= ~(1ull << j);
             const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based position inside the segment
             const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
             const uint32_t span = s_span[j];
