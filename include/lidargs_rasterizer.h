@@ -241,7 +241,8 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
 /* Counters of the last forward on this thread: [0]=P, [1]=visible Gaussians V,
  * [2]=instances binned by this library (num_rendered), [3]=R_ref = sum of the reference's
  * 16x1 tiles_touched (what SURVEY.md 8d's byte formula is written in), [4]=tile rows TH,
- * [5]=number of tiles.  Values [1] and [3] are read back from the device on demand. */
+ * [5]=number of tiles, [6]=instances that at least one pixel of their patch took in pass 1 (-1 if the
+ * T-only pass did not run), [7]=segments per list.  Values [1], [3], [6] are read back on demand. */
 int lidargs_last_counters(long long* out, int n);
 
 #ifdef __cplusplus

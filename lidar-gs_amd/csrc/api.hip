@@ -21,7 +21,8 @@
 namespace {
 
 thread_local char g_err[512] = "";
-long long g_counters[6] = {0, 0, 0, 0, 0, 0};
+long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t* g_last_flags = nullptr; size_t g_last_flags_n = 0;
 uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals
 hipStream_t g_last_stream = nullptr;
 
@@ -214,6 +215,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
 
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = (long long)R; g_counters[3] = -1; g_counters[4] = TH;
     g_counters[5] = grid.num_tiles();
+    g_counters[6] = -1; g_counters[7] = S;
+    g_last_flags = ra.flags; g_last_flags_n = (size_t)grid.waves_per_tile * R;
     g_last_totals_dev = geom.ref_tiles;   // R_ref / V are reduced lazily in lidargs_last_counters
     g_last_stream = stream;
     return (int)R;
@@ -484,8 +487,17 @@ int lidargs_last_counters(long long* out, int n) {
         }
         free(h);
     }
+    if (g_counters[6] < 0 && g_last_flags && g_last_flags_n) {
+        uint8_t* h = (uint8_t*)malloc(g_last_flags_n);
+        if (h && hipMemcpy(h, g_last_flags, g_last_flags_n, hipMemcpyDeviceToHost) == hipSuccess) {
+            long long c = 0;
+            for (size_t i = 0; i < g_last_flags_n; i++) c += h[i] != 0;
+            g_counters[6] = c;
+        }
+        free(h);
+    }
     int k = 0;
-    for (; k < n && k < 6; k++) out[k] = g_counters[k];
+    for (; k < n && k < 8; k++) out[k] = g_counters[k];
     return k;
 }
 

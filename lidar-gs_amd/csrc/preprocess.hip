@@ -210,21 +210,35 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // ---- conservative footprint pruning ------------------------------------------------------
         // The reference rect is 3*sqrt(lambda) with lambda floored at mid + sqrt(1e-9) (:328-330), which
         // inflates far/small Gaussians 2-3x per axis.  A pixel inside that rect still SKIPS the Gaussian
-        // unless alpha = opacity*exp(power) >= 1/255 (:606).  With an (almost) orthonormal tangent basis
-        // |d| = sin(theta), theta = angle(pixel ray, centre), and power <= -|d|^2 / (2 lambda_max), so
-        // alpha >= 1/255 needs sin^2(theta) <= 2 ln(255 opacity) lambda_max.  Tiles/rows beyond that
-        // angle can be dropped from the lists without changing any pixel; margins cover float rounding.
+        // unless alpha = opacity*exp(power) >= 1/255 (:606), i.e. unless d^T Q d <= 2 tau, tau = ln(255 o).
+        // The axis-aligned extent of that ellipse is |d.x| <= hx = sqrt(2 tau cov_xx), |d.y| <= hy = sqrt(2 tau cov_yy),
+        // and for the tangent basis used here (u1 = azimuthal, u2 = -d/d elevation) the offsets of the pixel at
+        // (beta, alpha) from the centre (beta0, alpha0) are EXACTLY
+        //     d.x = cos(alpha) sin(beta - beta0)
+        //     d.y = sin(alpha - alpha0) + cos(alpha) sin(alpha0) (1 - cos(beta - beta0)).
+        // Hence a taking pixel needs |sin dbeta| <= hx / cos(alpha) and |sin dalpha| <= hy + |sin alpha0| (1 - cos dbeta_max):
+        // an axis-aligned bound in (column, row) that follows the footprint's anisotropy.  Tiles / rows outside it
+        // are dropped from the lists without changing any pixel; the margins cover float rounding.
         int tx0 = xmin, tx1 = xmax, ty_lo = ymin, ty_hi = ymax;
         const float op = a.opacities[idx];
         if (!(op * 255.f >= 1.f)) { tx1 = tx0; }                       // can never reach 1/255
         else {
-            const float tau = logf(255.f * op) + 0.02f;
-            const float lam = (mid + sqrtf(fmaxf(0.f, mid * mid - det))) * 1.002f;
-            const float s2 = 2.f * tau * lam;
-            if (s2 < 0.25f) {                                          // theta < 30 deg: worth bounding
-                const float theta = asinf(sqrtf(s2)) * 1.002f + 2e-5f;
-                // rows: |beam elevation - centre elevation| <= theta
-                const float e_lo = alpha - theta, e_hi = alpha + theta;
+            const float tau2 = 2.f * (logf(255.f * op) + 0.02f);
+            const float hx = sqrtf(tau2 * ca) * 1.002f + 1e-6f, hy = sqrtf(tau2 * cc) * 1.002f + 1e-6f;
+            const float cfan = fminf(cosf(a.beams[0]), cosf(a.beams[H - 1])) * 0.999f;   // min cos(elevation) of any pixel row
+            const float sb = hx / cfan;                                // bound on |sin(dbeta)|
+            float one_m_cos = 2.f;                                     // 1 - cos(dbeta_max): worst case if unbounded
+            if (sb < 0.7f) {
+                const float dbeta = asinf(sb) * 1.002f + 2e-5f;
+                one_m_cos = 1.f - cosf(dbeta) + 1e-7f;
+                const float dcol = dbeta / pp.col_step + 0.02f;        // pixel x is reachable iff |x - p_c| <= dcol
+                tx0 = max(tx0, (int)floorf((p_c - dcol) / 16.f));
+                tx1 = min(tx1, (int)floorf((p_c + dcol) / 16.f) + 1);
+            }
+            const float sa = hy + fabsf(sinf(alpha)) * one_m_cos;     // bound on |sin(dalpha)|
+            if (sa < 0.7f) {
+                const float dalpha = asinf(sa) * 1.002f + 2e-5f;
+                const float e_lo = alpha - dalpha, e_hi = alpha + dalpha;
                 int lo = 0, hi = H;                                    // first beam >= e_lo
                 while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] < e_lo) lo = md + 1; else hi = md; }
                 const int i_lo = lo;
@@ -233,16 +247,6 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
                 const int i_hi = lo;                                   // beams [i_lo, i_hi) are in reach
                 ty_lo = max(ty_lo, H - i_hi);                          // pixel row y = H-1-i
                 ty_hi = min(ty_hi, H - i_lo);
-                // columns: chord^2 >= 4 cos(a_pix) cos(a_g) sin^2(dbeta/2)
-                const float cmin = fminf(cosf(fminf(fabsf(e_lo), 1.5f)), cosf(fminf(fabsf(e_hi), 1.5f)));
-                const float den = sqrtf(fmaxf(cmin * cosf(alpha), 1e-6f));
-                const float t = sinf(0.5f * theta) / den;
-                if (t < 0.7f) {
-                    const float dbeta = 2.f * asinf(t) * 1.002f + 2e-5f;
-                    const float dcol = dbeta / pp.col_step + 1.0f;     // +1 px slack
-                    tx0 = max(tx0, (int)floorf((p_c - dcol) / 16.f));
-                    tx1 = min(tx1, (int)floorf((p_c + dcol) / 16.f) + 1);
-                }
             }
         }
         if (tx1 <= tx0 || ty_hi <= ty_lo) { tiles = 0; tx0 = tx1 = xmin; ty_lo = ty_hi = ymin; }

@@ -244,6 +244,7 @@ def profile_summary():
 
 def last_counters():
     """dict(P, V, instances, R_ref, tile_rows, tiles) of the last forward on this thread."""
-    buf = (C.c_longlong * 6)()
-    _lib.lidargs_last_counters(buf, C.c_int(6))
-    return dict(P=buf[0], V=buf[1], instances=buf[2], R_ref=buf[3], tile_rows=buf[4], tiles=buf[5])
+    buf = (C.c_longlong * 8)()
+    _lib.lidargs_last_counters(buf, C.c_int(8))
+    return dict(P=buf[0], V=buf[1], instances=buf[2], R_ref=buf[3], tile_rows=buf[4], tiles=buf[5], taken_instances=buf[6],
+                segments=buf[7])
