@@ -97,6 +97,12 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    if rank == 0:
+        import build_hip
+        build_hip.build()               # no-op when the in-tree .so is newer than every source; never a stale library
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     from diff_lidargs_rasterization import GaussianRasterizer, _C
     from util import make_settings, to_torch
 
@@ -141,6 +147,7 @@ def main():
         step()
     barrier()
     _C.profile_enable(True)             # reset: from here on only hipEventRecord per stage, no host waits
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -153,6 +160,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    allocs1 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     stages = _C.profile_summary()
     cnt = _C.last_counters()
     if rank == 0:
@@ -175,6 +183,7 @@ def main():
                          "frame_algorithmic_bytes": fwd_b + bwd_b,
                          "frame_achieved_GBs": (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9},
             "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+            "hipmalloc_calls_in_timed_region": int(allocs1 - allocs0),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kind, P, H, W, seed)

@@ -72,20 +72,47 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_scratch_registry = {}
+
+
+@_ALLOC_FN
+def _alloc_cb(user, nbytes):
+    """The one allocator callback handed to the C ABI; `user` is the key of a live _Scratch."""
+    sc = _scratch_registry.get(user)
+    if sc is None:
+        return 0
+    try:
+        sc.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=sc.device)
+        return sc.tensor.data_ptr()
+    except Exception:  # surface as LIDARGS_ERR_ALLOC instead of unwinding through C
+        return 0
+
+
 class _Scratch:
-    """One resizable byte tensor = resizeFunctional(t) of R3/rasterize_points.cu:27-33."""
+    """One resizable byte tensor = resizeFunctional(t) of R3/rasterize_points.cu:27-33.
+
+    No per-call ctypes closure (a closure over `self` would form a reference cycle and keep the
+    hundreds-of-MB scratch tensor alive until Python's cyclic GC runs -> one hipMalloc per frame)."""
+    __slots__ = ("device", "tensor", "key")
+    cb = _alloc_cb
 
     def __init__(self, device):
         self.device = device
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _ALLOC_FN(self._alloc)
+        self.key = id(self)
+        _scratch_registry[self.key] = self
 
-    def _alloc(self, _user, nbytes):
-        try:
-            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            return self.tensor.data_ptr()
-        except Exception:  # surface as LIDARGS_ERR_ALLOC instead of unwinding through C
-            return 0
+    @property
+    def user(self):
+        return C.c_void_p(self.key)
+
+    def take(self):
+        """Detach from the registry and hand the tensor over."""
+        _scratch_registry.pop(self.key, None)
+        return self.tensor
+
+    def __del__(self):
+        _scratch_registry.pop(getattr(self, "key", None), None)
 
 
 def _stream(device):
@@ -122,7 +149,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _require_device(t, n)
         with torch.cuda.device(dev):
             rendered = _lib.lidargs_forward(
-                geom.cb, None, binning.cb, None, img.cb, None,
+                _alloc_cb, geom.user, _alloc_cb, binning.user, _alloc_cb, img.user,
                 C.c_int(P), C.c_int(int(degree)), C.c_int(M), _ptr(bg), C.c_int(W), C.c_int(H),
                 _ptr(m3), _ptr(shc if shc.is_cuda else None), _ptr(col), _ptr(opa), _ptr(sc if sc.is_cuda else None),
                 C.c_float(float(scale_modifier)), _ptr(rot if rot.is_cuda else None), _ptr(cov if cov.is_cuda else None),
@@ -131,8 +158,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _ptr(out_color), _ptr(out_depth), _ptr(out_occ), _ptr(radii), _ptr(radii_xy),
                 C.c_int(int(bool(debug))), _stream(dev))
         if rendered < 0:
+            geom.take(); binning.take(); img.take()
             _raise(rendered, "rasterize_gaussians")
-    return rendered, out_color, out_depth, out_occ, radii, geom.tensor, binning.tensor, img.tensor
+    return rendered, out_color, out_depth, out_occ, radii, geom.take(), binning.take(), img.take()
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

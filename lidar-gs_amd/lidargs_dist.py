@@ -126,13 +126,16 @@ class HipShellBackend:
             p = _C._ptr
             with torch.cuda.device(dev):
                 n = lib.lidargs_forward_shell(
-                    st["geom"].cb, None, st["binning"].cb, None, st["img"].cb, None, C.c_int(P), None, C.c_int(W), C.c_int(H),
+                    _C._alloc_cb, st["geom"].user, _C._alloc_cb, st["binning"].user, _C._alloc_cb, st["img"].user, C.c_int(P), None,
+                    C.c_int(W), C.c_int(H),
                     p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), C.c_float(inp["scale_modifier"]),
                     p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), C.c_int(inp["far"]), C.c_int(inp["near"]),
                     C.c_float(lo), C.c_float(hi), None, C.c_int(1), p(dummy), p(dummy[2 * H * W:]), p(dummy[3 * H * W:]), p(T_pass),
                     p(st["radii"]), p(st["radii_xy"]), C.c_int(0), _C._stream(dev))
             if n < 0:
                 _C._raise(n, "lidargs_forward_shell")
+        for k in ("geom", "binning", "img"):       # keep only the tensors: nothing holds the registry entries alive
+            st[k] = st[k].take()
         st["R"] = n
         return st, T_pass
 
@@ -147,8 +150,8 @@ class HipShellBackend:
         if st["P"]:
             p = _C._ptr
             with torch.cuda.device(dev):
-                rc = lib.lidargs_render_shell(C.c_int(st["P"]), C.c_int(st["R"]), None, C.c_int(W), C.c_int(H), p(st["geom"].tensor),
-                                              p(st["binning"].tensor), p(st["img"].tensor), p(T_in.contiguous()), C.c_int(0), p(part),
+                rc = lib.lidargs_render_shell(C.c_int(st["P"]), C.c_int(st["R"]), None, C.c_int(W), C.c_int(H), p(st["geom"]),
+                                              p(st["binning"]), p(st["img"]), p(T_in.contiguous()), C.c_int(0), p(part),
                                               p(part[2 * N:]), p(part[3 * N:]), p(T_pass2), p(T_end), C.c_int(0), _C._stream(dev))
             if rc < 0:
                 _C._raise(rc, "lidargs_render_shell")
@@ -172,7 +175,7 @@ class HipShellBackend:
                 rc = lib.lidargs_backward_shell(
                     C.c_int(P), C.c_int(st["R"]), p(inp["bg"]), C.c_int(W), C.c_int(H), p(inp["means3D"]), p(inp["colors"]), p(inp["scales"]),
                     C.c_float(inp["scale_modifier"]), p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), p(st["radii"]),
-                    p(st["geom"].tensor), p(st["binning"].tensor), p(st["img"].tensor), p(behind.contiguous()), p(T_final.contiguous()),
+                    p(st["geom"]), p(st["binning"]), p(st["img"]), p(behind.contiguous()), p(T_final.contiguous()),
                     p(gc), p(gd), p(go), p(g_m2), p(g_con), p(g_op), p(g_col), p(g_dep), p(g_m3), p(g_sph), p(g_u1), p(g_u2), p(g_cov),
                     p(g_sc), p(g_rot), C.c_int(0), _C._stream(dev))
             if rc < 0:
