@@ -141,36 +141,43 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
             }
             if (__ballot(!done) == 0ull) break;                       // R3/cr/forward.cu:559-561 early-out
             unsigned long long took = 0ull;
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
+            if (todo) {
+                // Software-pipelined, branch-free walk: the LDS reads of the NEXT flagged entry are issued before the
+                // current one is evaluated, and every per-pixel decision is a select (no exec-mask branching).
+                int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
-                const uint32_t span = s_span[j];
-                const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-                bool hit = false;
-                if (!done && rows) {
+                float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
+                uint32_t span = s_span[j];
+                while (true) {
+                    const bool more = todo != 0ull;
+                    const int jn = more ? __builtin_ctzll(todo) : j;
+                    todo &= todo - 1ull;
+                    const float4 n0 = s_rec[jn], n1 = s_rec[LG_CHUNK + jn], n2 = s_rec[2 * LG_CHUNK + jn], n3 = s_rec[3 * LG_CHUNK + jn];
+                    const uint32_t nspan = s_span[jn];
+
+                    const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
                     const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
                     const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
                     const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
                     const float power = -0.5f * (r1.w * dx * dx + r3.x * dy * dy) - r2.w * dx * dy;   // :601
-                    if (power <= 0.0f) {
-                        const float alpha = fminf(0.99f, r3.y * __expf(power));
-                        if (alpha >= 1.0f / 255.0f) {
-                            hit = true;
-                            const float test_T = T * (1.f - alpha);
-                            if (test_T < 0.0001f) { done = true; T_break = test_T; }
-                            else {
-                                if (!T_ONLY) {
-                                    const float w = alpha * T;
-                                    C0 += r3.z * w; C1 += r3.w * w; D += r0.w * w;
-                                }
-                                T = test_T; T_break = test_T;
-                                last = c * LG_CHUNK + (uint32_t)j + 1;
-                            }
-                        }
+                    const float alpha = fminf(0.99f, r3.y * __expf(fminf(power, 0.f)));
+                    const bool hit = !done && rows && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                    const float test_T = T * (1.f - alpha);
+                    const bool trip = hit && (test_T < 0.0001f);
+                    const bool blend = hit && !trip;
+                    if (!T_ONLY) {
+                        const float w = blend ? alpha * T : 0.f;
+                        C0 += r3.z * w; C1 += r3.w * w; D += r0.w * w;
                     }
+                    T = blend ? test_T : T;
+                    T_break = hit ? test_T : T_break;
+                    last = blend ? (c * LG_CHUNK + (uint32_t)j + 1u) : last;
+                    done = done || trip;
+                    if (T_ONLY) took |= (__ballot(hit) != 0ull) ? (1ull << j) : 0ull;
+
+                    if (!more) break;
+                    r0 = n0; r1 = n1; r2 = n2; r3 = n3; span = nspan; j = jn;
                 }
-                if (T_ONLY && __ballot(hit) != 0ull) took |= 1ull << j;
             }
             if (T_ONLY && fl) {
                 const uint32_t k = c * LG_CHUNK + lane;
@@ -255,13 +262,26 @@ void launch_render_forward(const RenderFwdArgs& a, hipStream_t s) {
 // (L < 16; every 16-lane row holds the same) owns the wave-wide sum of value slot
 //   id(L) = 8*(L&1) + 4*((L>>1)&1) + 2*((L>>2)&1) + ((L>>3)&1)
 // in v[0].
+// lane ^ 1 and lane ^ 2 partners come from DPP quad permutes (VALU, no LDS crossbar round trip); ^4, ^8, ^16 from
+// ds_swizzle bit-mode (no address VGPR); ^32 from ds_bpermute.
+__device__ __forceinline__ float xchg_xor1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float xchg_xor2(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+template <int XORMASK>
+__device__ __forceinline__ float xchg_swz(float x) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (XORMASK << 10) | 0x1F));
+}
+
 __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
     {
         const bool hi = lane & 1;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const float keep = hi ? v[k + 8] : v[k], send = hi ? v[k] : v[k + 8];
-            v[k] = keep + __shfl_xor(send, 1);
+            v[k] = keep + xchg_xor1(send);
         }
     }
     {
@@ -269,7 +289,7 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const float keep = hi ? v[k + 4] : v[k], send = hi ? v[k] : v[k + 4];
-            v[k] = keep + __shfl_xor(send, 2);
+            v[k] = keep + xchg_xor2(send);
         }
     }
     {
@@ -277,15 +297,15 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const float keep = hi ? v[k + 2] : v[k], send = hi ? v[k] : v[k + 2];
-            v[k] = keep + __shfl_xor(send, 4);
+            v[k] = keep + xchg_swz<4>(send);
         }
     }
     {
         const bool hi = lane & 8;
         const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
-        v[0] = keep + __shfl_xor(send, 8);
+        v[0] = keep + xchg_swz<8>(send);
     }
-    v[0] += __shfl_xor(v[0], 16);
+    v[0] += xchg_swz<16>(v[0]);
     v[0] += __shfl_xor(v[0], 32);
     return v[0];
 }
@@ -354,73 +374,82 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
         unsigned long long todo = __ballot(have);
         __syncthreads();
         if (c > 0) gather(c - 1, st, gid, have);
-        while (todo) {
-            const int j = 63 - __builtin_clzll(todo);                 // back to front
-            todo &= ~(1ull << j);
+        if (todo == 0ull) continue;
+        // back to front, software-pipelined: the next flagged entry's LDS reads are in flight while this one is evaluated
+        int j = 63 - __builtin_clzll(todo);
+        todo &= ~(1ull << j);
+        float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
+        uint32_t span = s_span[j];
+        while (true) {
+            const bool more = todo != 0ull;
+            const int jn = more ? 63 - __builtin_clzll(todo) : j;
+            todo &= ~(1ull << jn);
+            const float4 n0 = s_rec[jn], n1 = s_rec[LG_CHUNK + jn], n2 = s_rec[2 * LG_CHUNK + jn], n3 = s_rec[3 * LG_CHUNK + jn];
+            const uint32_t nspan = s_span[jn];
+
             const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based position inside the segment
-            const float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
-            const uint32_t span = s_span[j];
             const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-            bool contrib = false;
-            float v[16];
+            const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
+            const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
+            const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
+            const float A = r1.w, B = r2.w, Cc = r3.x, op = r3.y;
+            const float power = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
+            const float G = __expf(fminf(power, 0.f));
+            const float alpha = fminf(0.99f, op * G);
+            // :650 skip entries behind the last contributor; :673-679 the forward's skips
+            const bool contrib = rows && (e < n_lane) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+            if (__ballot(contrib) != 0ull) {                           // wave-uniform
+                const float Tn = T / (1.f - alpha);                    // :681
+                const float w = alpha * Tn;
+                const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                const float ad = last_alpha * ld + (1.f - last_alpha) * accd;
+                const float ao = last_alpha + (1.f - last_alpha) * acco;
+                float dL_dalpha = (r3.z - a0) * g0 + (r3.w - a1) * g1 + (r0.w - ad) * gd + (1.f - ao) * go;
+                dL_dalpha *= Tn;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;       // :727
+                const float dL_dG = op * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float gx = dL_dG * (-gdx * A - gdy * B);         // dL/dmean2D.x  (:734,:753)
+                const float gy = dL_dG * (-gdy * Cc - gdx * B);        // dL/dmean2D.y
+                // per-pixel sphere-gradient norm statistic (:759-779): |gx u1' + gy u2'|
+                const float sx = gx * r1.x + gy * r2.x, sy = gx * r1.y + gy * r2.y, sz = gx * r1.z + gy * r2.z;
+                // dL/du1 = gx (delta/uu1 - 2 dx u1'),  1/uu1 = |u1'|^2      (:738-750)
+                const float iu1 = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
+                const float iu2 = r2.x * r2.x + r2.y * r2.y + r2.z * r2.z;
+                const float t1 = -2.f * dx, t2 = -2.f * dy;
+                float v[16];
+                v[0] = gx;
+                v[1] = gy;
+                v[2] = sqrtf(sx * sx + sy * sy + sz * sz);
+                v[3] = -0.5f * gdx * dx * dL_dG;                       // conic A (:783)
+                v[4] = -0.5f * gdx * dy * dL_dG;                       // conic B
+                v[5] = -0.5f * gdy * dy * dL_dG;                       // conic C
+                v[6] = G * dL_dalpha;                                  // opacity (:788)
+                v[7] = w * g0;                                         // colours (:702)
+                v[8] = w * g1;
+                v[9] = w * gd;                                         // range (:711)
+                v[10] = gx * (ex * iu1 + t1 * r1.x);
+                v[11] = gx * (ey * iu1 + t1 * r1.y);
+                v[12] = gx * (ez * iu1 + t1 * r1.z);
+                v[13] = gy * (ex * iu2 + t2 * r2.x);
+                v[14] = gy * (ey * iu2 + t2 * r2.y);
+                v[15] = gy * (ez * iu2 + t2 * r2.z);
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = 0.f;
-            if (rows && e < n_lane) {                                  // :650 skip entries behind the last contributor
-                const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-                const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
-                const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
-                const float A = r1.w, B = r2.w, Cc = r3.x, op = r3.y;
-                const float power = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
-                if (power <= 0.0f) {
-                    const float G = __expf(power);
-                    const float alpha = fminf(0.99f, op * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        contrib = true;
-                        T = T / (1.f - alpha);                         // :681
-                        const float w = alpha * T;
-                        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = r3.z;
-                        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = r3.w;
-                        accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = r0.w;
-                        acco = last_alpha + (1.f - last_alpha) * acco;
-                        float dL_dalpha = (r3.z - acc0) * g0 + (r3.w - acc1) * g1 + (r0.w - accd) * gd + (1.f - acco) * go;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;   // :727
-                        const float dL_dG = op * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float gx = dL_dG * (-gdx * A - gdy * B);     // dL/dmean2D.x  (:734,:753)
-                        const float gy = dL_dG * (-gdy * Cc - gdx * B);    // dL/dmean2D.y
-                        // per-pixel sphere-gradient norm statistic (:759-779): |gx u1' + gy u2'|
-                        const float sx = gx * r1.x + gy * r2.x, sy = gx * r1.y + gy * r2.y, sz = gx * r1.z + gy * r2.z;
-                        // dL/du1 = gx (delta/uu1 - 2 dx u1'),  1/uu1 = |u1'|^2      (:738-750)
-                        const float iu1 = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
-                        const float iu2 = r2.x * r2.x + r2.y * r2.y + r2.z * r2.z;
-                        const float t1 = -2.f * dx, t2 = -2.f * dy;
-                        v[0] = gx;
-                        v[1] = gy;
-                        v[2] = sqrtf(sx * sx + sy * sy + sz * sz);
-                        v[3] = -0.5f * gdx * dx * dL_dG;               // conic A (:783)
-                        v[4] = -0.5f * gdx * dy * dL_dG;               // conic B
-                        v[5] = -0.5f * gdy * dy * dL_dG;               // conic C
-                        v[6] = G * dL_dalpha;                          // opacity (:788)
-                        v[7] = w * g0;                                 // colours (:702)
-                        v[8] = w * g1;
-                        v[9] = w * gd;                                 // range (:711)
-                        v[10] = gx * (ex * iu1 + t1 * r1.x);
-                        v[11] = gx * (ey * iu1 + t1 * r1.y);
-                        v[12] = gx * (ez * iu1 + t1 * r1.z);
-                        v[13] = gy * (ex * iu2 + t2 * r2.x);
-                        v[14] = gy * (ey * iu2 + t2 * r2.y);
-                        v[15] = gy * (ez * iu2 + t2 * r2.z);
-                    }
+                for (int k = 0; k < 16; k++) v[k] = contrib ? v[k] : 0.f;
+                // commit the per-pixel recurrences only where this pixel really blended the entry
+                T = contrib ? Tn : T;
+                acc0 = contrib ? a0 : acc0; acc1 = contrib ? a1 : acc1; accd = contrib ? ad : accd; acco = contrib ? ao : acco;
+                lc0 = contrib ? r3.z : lc0; lc1 = contrib ? r3.w : lc1; ld = contrib ? r0.w : ld;
+                last_alpha = contrib ? alpha : last_alpha;
+                const float mine = reduce_scatter16(v, lane);
+                if (lane < 16) {
+                    const int slot = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                    atomicAdd(a.gacc + 16 * (size_t)s_gid[j] + slot, mine);
                 }
             }
-            if (__ballot(contrib) == 0ull) continue;                   // wave-uniform
-            const float mine = reduce_scatter16(v, lane);
-            if (lane < 16) {
-                const int slot = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
-                atomicAdd(a.gacc + 16 * (size_t)s_gid[j] + slot, mine);
-            }
+            if (!more) break;
+            r0 = n0; r1 = n1; r2 = n2; r3 = n3; span = nspan; j = jn;
         }
     }
 }
