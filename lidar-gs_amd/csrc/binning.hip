@@ -11,8 +11,8 @@
 // A stable bin of a range-ordered stream leaves every tile's list ordered by (range, id): the
 // cub sort's tie-break (R3/cr/rasterizer_impl.cu:317-322, stable on identical keys).
 //
-// Kernels: one wave64 per block, no cross-wave traffic.  Ranks inside a wave come from
-// ballot-matching the digit bits (wave-wide match-any), so every pass is stable by construction.
+// Ranks inside a wave come from ballot-matching the digit bits (wave-wide match-any), so every pass is
+// stable by construction; blocks sort locally in LDS and write whole digit runs.
 #include "lidargs_common.h"
 
 namespace lg {
@@ -102,23 +102,28 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// LSD radix sort pass, one wave per block, SORT_CHUNK consecutive keys per block.
-// hist layout: [digit][block]  (digit-major, so one exclusive scan yields global bucket bases)
+// LSD radix sort pass on (u32 key, u32 value) pairs.  A block = 4 waves = 4096 consecutive keys, wave w
+// owning the w-th 1024-key slice so that the order (wave, round, lane) IS the key order (stability).
+//   k_radix_hist          per-block digit histogram -> hist[digit][block]
+//   k_radix_digit_prefix  one wave per digit: exclusive prefix over the blocks in place, digit totals -> tot[digit]
+//   k_radix_scatter       ranks its keys (ballot match-any per round, per-wave LDS counters), sorts the block into
+//                         LDS, then streams it out: consecutive threads write consecutive addresses inside each digit
+//                         run, so the pass writes whole lines instead of 4-byte crumbs (measured 5x write
+//                         amplification with direct per-key scatter).
 template <int BITS>
-__global__ void __launch_bounds__(64) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, int shift,
-                                                   uint32_t* __restrict__ hist, unsigned nblocks) {
+__global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, int shift,
+                                                    uint32_t* __restrict__ hist, unsigned nblocks) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t cnt[BINS];
-    const int lane = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
-    // all loads first (one wave per block: nothing else hides the HBM latency), then the LDS counting
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t base = (size_t)blockIdx.x * SORT_CHUNK + (size_t)w * (64 * SORT_ITEMS);
     uint32_t k[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
         k[r] = i < n ? keys[i] : 0u;
     }
-    for (int d = lane; d < BINS; d += 64) cnt[d] = 0;
+    for (int d = tid; d < BINS; d += 256) cnt[d] = 0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
@@ -126,17 +131,41 @@ __global__ void __launch_bounds__(64) k_radix_hist(const uint32_t* __restrict__ 
         if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (BINS - 1)], 1u);
     }
     __syncthreads();
-    for (int d = lane; d < BINS; d += 64) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
+    for (int d = tid; d < BINS; d += 256) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
+}
+
+__global__ void __launch_bounds__(256) k_radix_digit_prefix(uint32_t* __restrict__ hist, unsigned nblocks, int bins,
+                                                            uint32_t* __restrict__ tot) {
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= bins) return;
+    uint32_t* row = hist + (size_t)d * nblocks;
+    uint32_t carry = 0;
+    for (unsigned b0 = 0; b0 < nblocks; b0 += 64) {
+        const unsigned b = b0 + lane;
+        const uint32_t v = b < nblocks ? row[b] : 0u;
+        const uint32_t inc = wave_incl_scan(v, lane);
+        if (b < nblocks) row[b] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) tot[d] = carry;
 }
 
 template <int BITS>
-__global__ void __launch_bounds__(64) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                      size_t n, int shift, const uint32_t* __restrict__ bases, unsigned nblocks) {
+__global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                       size_t n, int shift, const uint32_t* __restrict__ hist,
+                                                       const uint32_t* __restrict__ tot, unsigned nblocks) {
     constexpr int BINS = 1 << BITS;
-    __shared__ uint32_t run[BINS];
-    const int lane = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * SORT_CHUNK;
+    __shared__ uint32_t run[SORT_WAVES][BINS];   // per-wave running digit counts, then wave bases
+    __shared__ uint32_t dbase[BINS];             // block-local start of each digit run
+    __shared__ uint32_t gbase[BINS];             // global start of this block's run of each digit
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_key[SORT_CHUNK];
+    __shared__ uint32_t s_val[SORT_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t blk_base = (size_t)blockIdx.x * SORT_CHUNK;
+    const size_t base = blk_base + (size_t)w * (64 * SORT_ITEMS);
     uint32_t k[SORT_ITEMS], v[SORT_ITEMS], pos[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
@@ -145,8 +174,21 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const uint32_t* __restrict
         k[r] = valid ? keys_in[i] : 0u;
         v[r] = valid ? vals_in[i] : 0u;
     }
-    for (int d = lane; d < BINS; d += 64) run[d] = bases[(size_t)d * nblocks + blockIdx.x];
+    // global digit bases: exclusive scan of the digit totals (every block repeats this tiny scan)
+    uint32_t my_tot = 0, my_hist = 0;
+    if (tid < BINS) { my_tot = tot[tid]; my_hist = hist[(size_t)tid * nblocks + blockIdx.x]; }
+    {
+        const uint32_t inc = wave_incl_scan(my_tot, lane);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int q = 0; q < w; q++) off += wsum[q];
+        if (tid < BINS) gbase[tid] = off + inc - my_tot + my_hist;
+    }
+    for (int d = lane; d < BINS; d += 64) run[w][d] = 0;
     __syncthreads();
+
+    // A. wave-local stable ranks
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
@@ -160,16 +202,50 @@ __global__ void __launch_bounds__(64) k_radix_scatter(const uint32_t* __restrict
             peers &= bit ? m : ~m;
         }
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        // One wave per block: its LDS operations execute in program order, so every lane's read of run[d]
-        // is served before the group leaders' updates below, and the next round sees them.
-        pos[r] = run[d] + rank;
+        // one wave owns run[w][]: its LDS operations execute in program order (read, then the leaders' update)
+        pos[r] = run[w][d] + rank;
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) run[d] += (uint32_t)__popcll(peers);
+        if (valid && rank == 0) run[w][d] += (uint32_t)__popcll(peers);
         __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
+
+    // B. block-local digit starts: digit-major, then wave-major inside a digit
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, dsum = 0;
+    if (tid < BINS) { c0 = run[0][tid]; c1 = run[1][tid]; c2 = run[2][tid]; c3 = run[3][tid]; dsum = c0 + c1 + c2 + c3; }
+    {
+        const uint32_t inc = wave_incl_scan(dsum, lane);
+        __syncthreads();                       // wsum reuse
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int q = 0; q < w; q++) off += wsum[q];
+        if (tid < BINS) {
+            const uint32_t start = off + inc - dsum;
+            dbase[tid] = start;
+            run[0][tid] = start; run[1][tid] = start + c0; run[2][tid] = start + c0 + c1; run[3][tid] = start + c0 + c1 + c2;
+        }
+    }
+    __syncthreads();
+
+    // C. park the block in LDS in sorted order
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; r++) {
-        if (base + (size_t)r * 64 + lane < n) { keys_out[pos[r]] = k[r]; vals_out[pos[r]] = v[r]; }
+        if (base + (size_t)r * 64 + lane < n) {
+            const uint32_t d = (k[r] >> shift) & (BINS - 1);
+            const uint32_t p = run[w][d] + pos[r];
+            s_key[p] = k[r]; s_val[p] = v[r];
+        }
+    }
+    __syncthreads();
+
+    // D. stream out: thread i writes element i of the sorted block to its digit run
+    const uint32_t count = (uint32_t)(n - blk_base < (size_t)SORT_CHUNK ? n - blk_base : (size_t)SORT_CHUNK);
+    for (uint32_t i = tid; i < count; i += 256) {
+        const uint32_t kk = s_key[i];
+        const uint32_t d = (kk >> shift) & (BINS - 1);
+        const size_t g = (size_t)gbase[d] + (i - dbase[d]);
+        keys_out[g] = kk; vals_out[g] = s_val[i];
     }
 }
 
@@ -177,12 +253,12 @@ template <int BITS>
 static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, int shift,
                        uint32_t* scratch, hipStream_t s) {
     const unsigned nb = (unsigned)sort_blocks(n);
-    const size_t hwords = (size_t)(1 << BITS) * nb;
+    constexpr int BINS = 1 << BITS;
     uint32_t* hist = scratch;
-    uint32_t* scan_scratch = scratch + (size_t)SORT_BINS * nb;       // after the largest possible histogram
-    hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(64), 0, s, kin, n, shift, hist, nb);
-    launch_exclusive_scan(hist, hist, hwords, nullptr, scan_scratch, s);
-    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(64), 0, s, kin, vin, kout, vout, n, shift, hist, nb);
+    uint32_t* tot = scratch + (size_t)SORT_BINS * nb;
+    hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
+    hipLaunchKernelGGL(k_radix_digit_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, hist, nb, BINS, tot);
+    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, shift, hist, tot, nb);
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,

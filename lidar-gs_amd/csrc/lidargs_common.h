@@ -54,18 +54,19 @@ struct Carver {
 };
 
 // ---- radix sort / scan scratch sizing (binning.hip) --------------------------------------------
-constexpr int SORT_ITEMS = 16;                  // rounds of 64 keys per wave-block
-constexpr int SORT_CHUNK = 64 * SORT_ITEMS;     // keys per block
+constexpr int SORT_ITEMS = 16;                  // rounds of 64 keys per wave
+constexpr int SORT_WAVES = 4;                   // waves per sort block
+constexpr int SORT_CHUNK = 64 * SORT_ITEMS * SORT_WAVES;   // keys per block (4096)
 constexpr int SORT_RADIX_BITS = 8;
 constexpr int SORT_BINS = 1 << SORT_RADIX_BITS;
 constexpr int SCAN_BLOCK = 1024;                // elements per scan block (256 threads x 4)
 
 inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
 inline size_t scan_blocks(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
-// u32 words of scratch needed to sort n pairs: digit histogram [BINS x blocks] + scan partials
+// u32 words of scratch needed to sort n pairs: digit histogram [BINS x blocks] + per-digit totals
 inline size_t sort_scratch_words(size_t n) {
     size_t h = (size_t)SORT_BINS * sort_blocks(n);
-    return h + scan_blocks(h) + 64;
+    return h + SORT_BINS + 64;
 }
 inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 
