@@ -11,9 +11,10 @@ range shell across the ranks: RCCL all-gather of the per-shell transmittance pla
 W x H x 5 partial planes, reduce-scatter of the packed per-Gaussian gradient rows (lidargs_dist.py).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     for the dominant kernel (the backward blend): ALGORITHMIC bytes per launch
-               (68*R_ref + 24*N + 84*V, SURVEY.md 8d / DESIGN.md section 5) / its mean launch duration,
-               measured with HIP events on the op's own stream inside the timed region, vs 8 TB/s HBM.
+  roofline     for the dominant kernel (whichever of the forward blend K7 = 68*R_ref + 24*N bytes and the backward
+               blend K8 = 68*R_ref + 24*N + 84*V bytes takes longer; SURVEY.md 8d / DESIGN.md section 5):
+               ALGORITHMIC bytes per launch / mean duration measured with HIP events on the op's own stream
+               inside the timed region, vs 8 TB/s HBM; `traffic` = PMC bytes from the committed profile.
   cpu_baseline the CPU oracle (oracle/lidargs_oracle.c, 1 thread) on a bounded sample of the same
                workload, timed on this box's host cores.
 """
@@ -35,11 +36,28 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def algorithmic_bytes(P, V, R_ref, N, T):
-    """SURVEY.md 8d compact form; returns (fwd, bwd, bwd_blend_kernel) bytes per frame."""
+    """SURVEY.md 8d compact form; returns (fwd, bwd, K7 forward blend, K8 backward blend) bytes per frame."""
     fwd = 48 * P + 112 * V + 112 * R_ref + 8 * T + 24 * N
     bwd = 112 * P + 192 * V + 68 * R_ref + 24 * N
-    blend_bwd = 68 * R_ref + 24 * N + 84 * V
-    return fwd, bwd, blend_bwd
+    blend_fwd = 68 * R_ref + 24 * N               # record gather per reference instance + per-pixel outputs
+    blend_bwd = 68 * R_ref + 24 * N + 84 * V      # + raster gradients written once per visible Gaussian
+    return fwd, bwd, blend_fwd, blend_bwd
+
+
+def pmc_traffic(kernel_names):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1]))["kernels"]
+    tot = 0
+    for name in kernel_names:
+        if name not in k:
+            return None
+        tot += k[name]["hbm_bytes_per_launch_corrected"]
+    return tot
 
 
 def cpu_baseline(kind, P_full, H, W, seed, budget_s=20.0):
@@ -166,8 +184,17 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         N_pix, T_ref = H * W, H * ((W + 15) // 16)
-        fwd_b, bwd_b, blend_b = algorithmic_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
-        blend_ms = stages.get("render_bwd", (0.0, 0))[0]
+        fwd_b, bwd_b, k7_b, k8_b = algorithmic_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
+        ms = lambda name: stages.get(name, (0.0, 0))[0]
+        k7_ms = ms("render_pass1") + ms("render_pass2") + ms("render_combine")
+        k8_ms = ms("render_bwd")
+        # the dominant kernel of the frame: the forward blend (3 launches: pass 1, pass 2, combine) or the backward blend
+        if k7_ms >= k8_ms:
+            dom, blend_b, blend_ms = "k_render_forward<T-only> + k_render_forward + k_render_combine (reference K7)", k7_b, k7_ms
+            traffic = pmc_traffic(["lg::k_render_forward<true>", "lg::k_render_forward<false>", "lg::k_render_combine"])
+        else:
+            dom, blend_b, blend_ms = "k_render_backward (reference K8)", k8_b, k8_ms
+            traffic = pmc_traffic(["lg::k_render_backward"])
         achieved = blend_b / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
         out = {
             "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s",
@@ -177,8 +204,8 @@ def main():
                                    f"lidar_far=80 lidar_near=0, bg=0",
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
                        "tile_rows": cnt["tile_rows"], "sharding": "single GPU" if world == 1 else f"{world} range shells"},
-            "roofline": {"bound": "hbm", "kernel": "k_render_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": blend_b, "kernel_ms": blend_ms,
                          "frame_algorithmic_bytes": fwd_b + bwd_b,
                          "frame_achieved_GBs": (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9},

@@ -209,9 +209,19 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = R;
     ra.transmittance_only = transmittance_pass;
-    lg::launch_render_forward(ra, stream);
-    LG_STAGE_CHECK("render forward");
-    g_prof.mark("render_fwd", stream);
+    if (ra.run_pass1) {
+        lg::launch_render_pass1(ra, stream);
+        LG_STAGE_CHECK("render pass 1");
+        g_prof.mark("render_pass1", stream);
+    }
+    if (!transmittance_pass) {
+        lg::launch_render_pass2(ra, stream);
+        LG_STAGE_CHECK("render pass 2");
+        g_prof.mark("render_pass2", stream);
+    }
+    lg::launch_render_combine(ra, stream);
+    LG_STAGE_CHECK("render combine");
+    g_prof.mark("render_combine", stream);
 
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = (long long)R; g_counters[3] = -1; g_counters[4] = TH;
     g_counters[5] = grid.num_tiles();
@@ -393,7 +403,9 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
-    lg::launch_render_forward(ra, stream);
+    if (ra.run_pass1) lg::launch_render_pass1(ra, stream);
+    if (!transmittance_pass) lg::launch_render_pass2(ra, stream);
+    lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render shell");
     if (T_end_out && !transmittance_pass)
         LG_HIP(hipMemcpyAsync(T_end_out, img.final_T, sizeof(float) * (size_t)width * height, hipMemcpyDeviceToDevice, stream));

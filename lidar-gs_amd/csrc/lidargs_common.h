@@ -220,7 +220,9 @@ struct RenderFwdArgs {
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
 };
-void launch_render_forward(const RenderFwdArgs& a, hipStream_t s);
+void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s);     // T-only walk of every segment
+void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s);     // full walk from the true T_in
+void launch_render_combine(const RenderFwdArgs& a, hipStream_t s);   // fold the segments into the image planes
 
 struct RenderBwdArgs {
     TileGrid grid;

@@ -249,11 +249,16 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     a.out_occ[pix] = 1.f - T_final;
 }
 
-void launch_render_forward(const RenderFwdArgs& a, hipStream_t s) {
+void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s) {
+    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile) * (unsigned)a.S;
+    hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
+}
+void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
+    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile) * (unsigned)a.S;
+    hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
+}
+void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
-    const unsigned blocks = patches * (unsigned)a.S;
-    if (a.run_pass1) hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
-    if (!a.transmittance_only) hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_render_combine, dim3(patches), dim3(64), 0, s, a);
 }
 
