@@ -94,7 +94,9 @@ int lidargs_forward(
     void* stream);
 
 /* Rasterizer::backward -- R3/cr/rasterizer.h:86-122, R3/cr/rasterizer_impl.cu:431-549.
- * All dL_d* outputs are caller-allocated and ZERO-INITIALISED (R3/rasterize_points.cu:163-175):
+ * All dL_d* outputs are caller-allocated.  The reference zero-initialises them (R3/rasterize_points.cu:163-175)
+ * and accumulates with atomics; this library instead WRITES every one of the P rows of every output (zeros for
+ * Gaussians with radii <= 0), so they may be passed uninitialised:
  * dL_dmean2D f32[4P], dL_dconic f32[4P], dL_dopacity f32[P], dL_dcolor f32[2P],
  * dL_ddepths f32[P], dL_dmean3D f32[3P], dL_dsphere_means3D f32[3P], dL_dbasis_u1 f32[3P],
  * dL_dbasis_u2 f32[3P], dL_dcov3D f32[6P], dL_dsh (untouched), dL_dscale f32[3P], dL_drot f32[4P]. */

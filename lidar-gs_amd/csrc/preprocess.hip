@@ -315,7 +315,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view, unsigne
 //   gx*u1' + gy*u2' (R3/cr/backward.cu:759-777 sums exactly these per-pixel terms).
 __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.P || !(a.radii[idx] > 0)) return;
+    if (idx >= a.P) return;
     const float* vm = a.view;
 
     const float3 pw = f3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
@@ -324,7 +324,18 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
                         vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
     const float n2 = d.x * d.x + d.y * d.y + d.z * d.z;
     const float dist = sqrtf(n2);
-    if (dist <= 0.f) return;                                          // R3/cr/backward.cu:488
+    if (!(a.radii[idx] > 0) || dist <= 0.f) {                         // R3/cr/backward.cu:479, :488: no gradient at all
+        // every output row is written, so the caller need not pre-zero them (the reference relies on torch::zeros)
+        for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_dconic[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; }
+        for (int k = 0; k < 3; k++) {
+            a.dL_dmean3D[3 * idx + k] = 0.f; a.dL_dsphere[3 * idx + k] = 0.f; a.dL_dbasis_u1[3 * idx + k] = 0.f;
+            a.dL_dbasis_u2[3 * idx + k] = 0.f; a.dL_dscale[3 * idx + k] = 0.f;
+        }
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0.f;
+        a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f;
+        a.dL_dopacity[idx] = 0.f; a.dL_ddepths[idx] = 0.f;
+        return;
+    }
     const float3 dir = f3(d.x / dist, d.y / dist, d.z / dist);
     float3 u1, u2;
     tangent_basis(dir, u1, u2);
@@ -419,7 +430,10 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float3 gw = view_to_world(vm, v);                            // transformVec4x3Transpose (:525)
     a.dL_dmean3D[3 * idx] = gw.x; a.dL_dmean3D[3 * idx + 1] = gw.y; a.dL_dmean3D[3 * idx + 2] = gw.z;
 
-    if (a.scales) {
+    if (!a.scales) {
+        for (int k = 0; k < 3; k++) a.dL_dscale[3 * idx + k] = 0.f;
+        for (int k = 0; k < 4; k++) a.dL_drot[4 * idx + k] = 0.f;
+    } else {
         // Sigma = sum_k s_k^2 r_k r_k^T, G = symmetric gradient (off-diagonals halved, :415-419)
         if (!have_sr) {
             const float m = a.scale_modifier;
