@@ -24,8 +24,8 @@ _ARRAYS = {
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    src = os.path.join(_HERE, "lidargs_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("lidargs_oracle.c", "lidargs_surfel_oracle.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liblidargs_oracle.so"])
     return _SO
 
@@ -38,6 +38,9 @@ def lib():
         _lib.lgo_forward.restype = C.c_void_p
         _lib.lgo_forward_ex.restype = C.c_void_p
         _lib.lgo_backward_ex.restype = C.c_int
+        _lib.sfo_forward.restype = C.c_void_p
+        _lib.sfo_state_array.restype = C.c_void_p
+        _lib.sfo_last_error.restype = C.c_char_p
         _lib.lgo_state_array.restype = C.c_void_p
         _lib.lgo_last_error.restype = C.c_char_p
         _lib.lgo_num_rendered.restype = C.c_int
