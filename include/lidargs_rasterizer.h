@@ -227,6 +227,49 @@ int lidargs_backward_shell(
     float* dL_dmean3D, float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2,
     float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug, void* stream);
 
+/* ---- 2DGS "laser-surfel" variant (BASELINE config 5) ---------------------------------------------
+ * Drop-in for CudaRasterizer::Rasterizer of /root/reference/submodules/diff_lidargs_surfel_rasterization
+ * ("R2/"): forward R2/cuda_rasterizer/rasterizer.h:31-58, backward :60-94, visible_filter :96-114
+ * (markVisible is identical to the 3-D variant's: use lidargs_mark_visible).  Same conventions as above.
+ * scales is f32[2P] (vec2 per surfel, the reference reads the tensor with a row stride of 2 floats,
+ * R2/cr/rasterizer_impl.cu:256).  out_others f32[7*H*W] = depth, alpha, normal xyz, median depth, distortion
+ * (R2/cr/auxiliary.h:23-27).  `pixels` f32[P] is accepted and never written (neither does the reference:
+ * the atomicAdd is commented out, R2/cr/forward.cu:522).  transMat_precomp must be NULL (the reference's
+ * backward rejects it, R2/cr/backward.cu:655-658).  Backward outputs (written for all P rows): dL_dmean2D f32[4P],
+ * dL_dnormal f32[3P], dL_dopacity f32[P], dL_dcolor f32[2P], dL_dmean3D f32[3P], dL_dtransMat f32[9P],
+ * dL_dtransMat_2dtemp f32[3P], dL_dscale f32[2P], dL_drot f32[4P], depth f32[P]; dL_depths is the gradient of
+ * all 7 planes of out_others. */
+int lidargs_surfel_forward(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, const float* beam_inclinations,
+    int prefiltered, int lidar_far, int lidar_near,
+    float* out_color, float* out_others, float* pixels, int* radii, int* radii_xy, int debug, void* stream);
+
+int lidargs_surfel_backward(
+    int P, int D, int M, int R, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* beam_inclinations,
+    const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths,
+    float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dtransMat, float* dL_dtransMat_2dtemp, float* dL_dsh, float* dL_dscale, float* dL_drot, float* depth,
+    int debug, void* stream);
+
+int lidargs_surfel_visible_filter(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, int M, int width, int height,
+    const float* means3D, const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* beam_inclinations,
+    int prefiltered, int lidar_far, int lidar_near, int* radii, int* radii_xy, int debug, void* stream);
+
 /* ---- introspection used by bench.py / tests (no reference counterpart) ---------------------
  * Per-stage HIP-event timing on the op's own stream.  While enabled, every forward/backward call
  * records one event per stage boundary (no host wait); lidargs_profile_read() synchronises the

@@ -78,6 +78,17 @@ int ceil_log2(uint32_t n) {
     while ((1u << b) < n && b < 31) b++;
     return b;
 }
+}  // namespace
+
+// helpers shared with the surfel entry points (surfel_api.inc)
+namespace lg {
+int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+int api_check_launch(hipStream_t s, int debug, const char* what) { return check_launch(s, debug, what); }
+int api_tile_rows() { return tile_rows(); }
+int api_ceil_log2(uint32_t n) { return ceil_log2(n); }
+}  // namespace lg
+
+namespace {
 
 // ---- per-stage event timing -------------------------------------------------------------------
 // While enabled, every forward/backward call records one HIP event per stage boundary on the op's

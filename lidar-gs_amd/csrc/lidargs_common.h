@@ -190,6 +190,12 @@ struct PreprocessParams {
     const float* view;          // DEVICE pointer to the 16 floats (wave-uniform -> scalar loads)
 };
 
+// helpers exported by api.hip for the other entry-point files
+int api_fail(int code, const char* msg);
+int api_check_launch(hipStream_t s, int debug, const char* what);
+int api_tile_rows();
+int api_ceil_log2(uint32_t n);
+
 // kernels / launchers (defined in the .hip files)
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);
 void launch_preprocess(const PreprocessParams& pp, const float* means3D, const float* scales, const float* rotations,

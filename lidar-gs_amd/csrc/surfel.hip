@@ -1,0 +1,570 @@
+// surfel.hip -- the 2DGS "laser-surfel" rasterizer (BASELINE config 5) on gfx950.
+//
+// Reference: /root/reference/submodules/diff_lidargs_surfel_rasterization ("R2/"):
+//   K1'  preprocessCUDA_cylinder   R2/cr/forward.cu:217-325      -> k_sf_preprocess
+//   K2'  filter_preprocessCUDA     R2/cr/forward.cu:551-631      -> k_sf_preprocess<FILTER>
+//   K7'  renderCUDA (forward)      R2/cr/forward.cu:327-547      -> k_sf_render_forward
+//   K8'  renderCUDA (backward)     R2/cr/backward.cu:143-605     -> k_sf_render_backward
+//   K10' preprocessCUDA (backward) R2/cr/backward.cu:607-749     -> k_sf_gaussian_backward
+// Binning (range sort, load-balanced instance emit, stable tile bin, ranges) is shared with the 3D variant
+// (binning.hip); so are the pixel mapping (one wave64 = 16 columns x 4 rows, per-lane row test against the
+// reference rect, tile width 16 = BLOCK_X) and the ray tables.
+//
+// Per-surfel record, 80 bytes, written once by k_sf_preprocess and gathered per (tile, surfel) instance:
+//   r0 = (Tu'.xyz, opacity)     Tu' = Tu / (Tu.Tu), Tu = view-space first axis (incl. scale)
+//   r1 = (Tv'.xyz, colour0)     so that s = (dp.Tu', dp.Tv') needs no division per pair (R2/cr/forward.cu:463-468)
+//   r2 = (Tw.xyz,  colour1)     Tw = view-space centre
+//   r3 = (n.xyz,   lambda)      n = normal flipped towards the sensor, lambda = Tw.n (distance of the plane)
+//   r4 = (p_c, p_r, |Tw|, Tw.n) projected centre in pixels (2-D filter, :469), range, and the raw dot Tw.n (backward)
+//
+// Backward sums.  The reference accumulates up to 27 atomics per pair.  Here 23 per-(wave, surfel) sums go
+// through one 32-slot butterfly reduce-scatter and ONE 32-lane atomic instruction into a packed 128-byte line;
+// several of the reference's accumulators are linear (or abs-linear) in others with per-surfel coefficients and
+// are reconstructed in the per-surfel epilogue instead (the 3-D branch's dL/dmean2D statistics from the |dL/dTw|
+// sums; the 2-D branch's dL/dTw from its dL/dmean2D sums and one dL/dz sum).
+#include "lidargs_common.h"
+
+namespace lg {
+
+#define SF_CHUNK 64
+#define SF_NEAR_N 0.2f
+#define SF_FAR_N 80.0f
+
+__device__ __forceinline__ float3 sf3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float sdot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// (column, row) of a view-space point (R2/cr/forward.cu:118-174); returns false when the beam-fan cull fires
+__device__ __forceinline__ bool sf_pix(float3 p, int W, int H, const float* __restrict__ beams, bool with_cull, float col_step, float2& pix) {
+    const float pi_f = 3.14159265358979323846f;
+    // atan2 through double = the correctly rounded fp32 value, independent of the device libm: p_c ~ 1e3 px enters the
+    // 2-D filter exponent with a gain of ~80 per pixel, so one ulp of atan2f is a 1e-3 change of a blend weight
+    const float p_c = (pi_f - (float)atan2((double)p.y, (double)p.x)) / col_step;
+    const float alpha = (float)atan2((double)p.z, (double)sqrtf(p.x * p.x + p.y * p.y));
+    int bi;
+    if (alpha >= beams[H - 1]) bi = H - 1;
+    else if (alpha <= beams[0]) bi = 0;
+    else {
+        int lo = 0, hi = H;
+        while (lo < hi) { const int md = (lo + hi) >> 1; if (beams[md] < alpha) lo = md + 1; else hi = md; }
+        bi = lo;
+    }
+    float p_r;
+    const float guard = 0.006f;                                        // Ray_Divergence_Angle, R2/cr/forward.cu:18
+    if (bi > 0) {
+        const float before = beams[bi - 1], after = beams[bi];
+        p_r = (float)(bi - 1) + (alpha - before) / (after - before);
+        if (with_cull && alpha > (after + guard)) return false;
+    } else {
+        const float before = beams[0], after = beams[1];
+        p_r = (float)(bi + 1) + (alpha - after) / (after - before);
+        if (with_cull && alpha < (before - guard)) return false;
+    }
+    pix = make_float2(p_c, (float)H - p_r - 1.f);
+    return true;
+}
+
+// columns of the rotation matrix of the NORMALISED quaternion (R2/cr/auxiliary.h:249-271)
+__device__ __forceinline__ void sf_quat_cols(float4 q, float3& c0, float3& c1, float3& c2) {
+    const float s = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+    c0 = sf3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y));
+    c1 = sf3(2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x));
+    c2 = sf3(2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y));
+}
+// world -> view rotation of a direction: transformVec4x3
+__device__ __forceinline__ float3 sf_rot_view(const float* vm, float3 v) {
+    return sf3(vm[0] * v.x + vm[4] * v.y + vm[8] * v.z, vm[1] * v.x + vm[5] * v.y + vm[9] * v.z, vm[2] * v.x + vm[6] * v.y + vm[10] * v.z);
+}
+// view -> world: transformVec4x3Transpose
+__device__ __forceinline__ float3 sf_rot_world(const float* vm, float3 v) {
+    return sf3(vm[0] * v.x + vm[1] * v.y + vm[2] * v.z, vm[4] * v.x + vm[5] * v.y + vm[6] * v.z, vm[8] * v.x + vm[9] * v.y + vm[10] * v.z);
+}
+
+struct SfPreArgs {
+    int P, W, H, TH, tiles_x;
+    float scale_modifier, near_f, far_f, col_step;
+    const float* view;
+    const float* means3D; const float* scales; const float* rotations; const float* opacities; const float* colors; const float* beams;
+    int* radii; int* radii_xy;
+    float4* rec; uint32_t* rowspan; uint32_t* xspan; uint32_t* dkey; uint32_t* ids; uint32_t* tcount; uint32_t* ref_tiles;
+};
+
+template <bool FILTER>
+__global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P) return;
+    int out_radius = 0, rx = 0, ry = 0;
+    uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0;
+    float4 r0, r1, r2, r3, r4;
+    bool live = false;
+    do {
+        const float* vm = a.view;
+        const float3 pw = sf3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        const float3 pv = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+                              vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+        const float dist = sqrtf(pv.x * pv.x + pv.y * pv.y + pv.z * pv.z);
+        if (dist >= a.far_f || dist <= a.near_f) break;
+        float2 pim;
+        if (!sf_pix(pv, a.W, a.H, a.beams, true, a.col_step, pim)) break;
+
+        const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+        float3 c0, c1, c2;
+        sf_quat_cols(q, c0, c1, c2);
+        const float sx = a.scale_modifier * a.scales[2 * idx], sy = a.scale_modifier * a.scales[2 * idx + 1];
+        // view-space axes of the surfel: rows of T = transpose(splat2world) * world2view (R2/cr/forward.cu:271-295)
+        const float3 Tu = sf_rot_view(vm, sf3(c0.x * sx, c0.y * sx, c0.z * sx));
+        const float3 Tv = sf_rot_view(vm, sf3(c1.x * sy, c1.y * sy, c1.z * sy));
+        float3 n = sf_rot_view(vm, c2);
+        if (!FILTER) {
+            const float c = -(pv.x * n.x + pv.y * n.y + pv.z * n.z);  // DUAL_VISIABLE, :297-302
+            if (c == 0.f) break;
+            if (!(c > 0.f)) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+        }
+        // extent: +-3 sigma axis end points through the beam model, at least one pixel (:177-215)
+        float2 e0, e1, e2, e3;
+        sf_pix(sf3(pv.x + 3.f * Tu.x, pv.y + 3.f * Tu.y, pv.z + 3.f * Tu.z), a.W, a.H, a.beams, false, a.col_step, e0);
+        sf_pix(sf3(pv.x - 3.f * Tu.x, pv.y - 3.f * Tu.y, pv.z - 3.f * Tu.z), a.W, a.H, a.beams, false, a.col_step, e1);
+        sf_pix(sf3(pv.x + 3.f * Tv.x, pv.y + 3.f * Tv.y, pv.z + 3.f * Tv.z), a.W, a.H, a.beams, false, a.col_step, e2);
+        sf_pix(sf3(pv.x - 3.f * Tv.x, pv.y - 3.f * Tv.y, pv.z - 3.f * Tv.z), a.W, a.H, a.beams, false, a.col_step, e3);
+        const float ax = fmaxf(fabsf(e0.x - pim.x), fabsf(e1.x - pim.x)), ay = fmaxf(fabsf(e0.y - pim.y), fabsf(e1.y - pim.y));
+        const float bx = fmaxf(fabsf(e2.x - pim.x), fabsf(e3.x - pim.x)), by = fmaxf(fabsf(e2.y - pim.y), fabsf(e3.y - pim.y));
+        rx = (int)ceilf(fmaxf(fmaxf(ax, bx), 1.0f));
+        ry = (int)ceilf(fmaxf(fmaxf(ay, by), 1.0f));
+        // R2/cr/auxiliary.h:99-112: x and ymin truncate, ymax = round(p.y + ry)
+        const int gx = a.tiles_x, gy = a.H;
+        const int xmin = min(gx, max(0, (int)((pim.x - (float)rx) / 16.f)));
+        const int xmax = min(gx, max(0, (int)((pim.x + (float)rx + 15.f) / 16.f)));
+        const int ymin = min(gy, max(0, (int)(pim.y - (float)ry)));
+        const int ymax = min(gy, max(0, (int)roundf(pim.y + (float)ry)));
+        if ((xmax - xmin) * (ymax - ymin) == 0) break;
+        live = true;
+        out_radius = max(rx, ry);
+        if (FILTER) break;
+
+        reftiles = (uint32_t)((xmax - xmin) * (ymax - ymin));
+        const int ty0 = ymin / a.TH, ty1 = (ymax - 1) / a.TH;
+        tiles = (uint32_t)((xmax - xmin) * (ty1 - ty0 + 1));
+        rspan = (uint32_t)ymin | ((uint32_t)ymax << 16);
+        xsp = (uint32_t)xmin | ((uint32_t)xmax << 16);
+        key = __float_as_uint(dist);
+        const float uu = sdot(Tu, Tu), vv = sdot(Tv, Tv);
+        const float iu = uu > 0.f ? 1.f / uu : 0.f, iv = vv > 0.f ? 1.f / vv : 0.f;
+        r0 = make_float4(Tu.x * iu, Tu.y * iu, Tu.z * iu, a.opacities[idx]);
+        r1 = make_float4(Tv.x * iv, Tv.y * iv, Tv.z * iv, a.colors[2 * idx]);
+        r2 = make_float4(pv.x, pv.y, pv.z, a.colors[2 * idx + 1]);
+        // lambda = |Tw| * cos(phi1) with cos(phi1) = (Tw.n)/|Tw|, rounded in the reference's order (:449-452): the hit
+        // point lam2 * p - Tw cancels ~3 digits, so a 1-ulp change of lambda is a 1e-4 change of the Gaussian weight
+        r3 = make_float4(n.x, n.y, n.z, dist * ((pv.x * n.x + pv.y * n.y + pv.z * n.z) / dist));
+        r4 = make_float4(pim.x, pim.y, dist, pv.x * n.x + pv.y * n.y + pv.z * n.z);
+    } while (false);
+
+    a.radii[idx] = out_radius;
+    a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;
+    if (FILTER) return;
+    a.dkey[idx] = key; a.ids[idx] = (uint32_t)idx; a.tcount[idx] = tiles; a.ref_tiles[idx] = reftiles;
+    if (live) {
+        a.rowspan[idx] = rspan; a.xspan[idx] = xsp;
+        float4* r = a.rec + 5 * (size_t)idx;
+        r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4;
+    }
+}
+
+void launch_sf_preprocess(const SfPreArgs& a, bool filter_only, hipStream_t s) {
+    const dim3 grid((a.P + 255) / 256), block(256);
+    if (filter_only) hipLaunchKernelGGL(k_sf_preprocess<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_sf_preprocess<false>, grid, block, 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SfPixel { int x, y, pix; bool inside; float3 p; };
+
+__device__ __forceinline__ SfPixel sf_pixel(const TileGrid& g, const float2* __restrict__ coltab, const float2* __restrict__ rowtab, int patch, int lane) {
+    SfPixel o;
+    const int wpt = g.waves_per_tile;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    o.x = (tile % g.tiles_x) * LG_TILE_W + (lane & 15);
+    o.y = (tile / g.tiles_x) * g.TH + sub * LG_WAVE_ROWS + (lane >> 4);
+    o.inside = o.x < g.W && o.y < g.H;
+    o.pix = o.y * g.W + o.x;
+    o.p = sf3(0.f, 0.f, 1.f);
+    if (o.inside) { const float2 cb = coltab[o.x], ca = rowtab[o.y]; o.p = sf3(ca.x * cb.x, ca.x * cb.y, ca.y); }
+    return o;
+}
+
+struct SfStaged { float4 a0, a1, a2, a3, a4; uint32_t span, gid; };
+
+__device__ __forceinline__ SfStaged sf_gather(const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+                                              const uint32_t* __restrict__ rowspan, uint32_t k, bool valid) {
+    SfStaged s;
+    s.a0 = s.a1 = s.a2 = s.a3 = s.a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.span = 0; s.gid = 0;
+    if (valid) {
+        const uint32_t g = point_list[k];
+        const float4* r = rec + 5 * (size_t)g;
+        s.a0 = r[0]; s.a1 = r[1]; s.a2 = r[2]; s.a3 = r[3]; s.a4 = r[4];
+        s.span = rowspan[g]; s.gid = g;
+    }
+    return s;
+}
+
+// Everything up to alpha for one (pixel, surfel) pair: R2/cr/forward.cu:426-490 == R2/cr/backward.cu:283-340.
+struct SfPair { bool ok, in3d; float sx, sy, dxp, dyp, lam2, cos2, depth, G, alpha; float3 dp; };
+
+__device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r1, float4 r2, float4 r3, float4 r4) {
+    SfPair o;
+    const float3 n = sf3(r3.x, r3.y, r3.z);
+    o.cos2 = sdot(px.p, n);
+    const float safe = o.cos2 != 0.f ? o.cos2 : 1.f;
+    o.lam2 = r3.w / safe;                                              // ray / plane hit distance (:449-457)
+    o.dp = sf3(o.lam2 * px.p.x - r2.x, o.lam2 * px.p.y - r2.y, o.lam2 * px.p.z - r2.z);
+    o.sx = o.dp.x * r0.x + o.dp.y * r0.y + o.dp.z * r0.z;
+    o.sy = o.dp.x * r1.x + o.dp.y * r1.y + o.dp.z * r1.z;
+    const float rho3d = o.sx * o.sx + o.sy * o.sy;
+    o.dxp = r4.x - (float)px.x; o.dyp = r4.y - (float)px.y;
+    const float rho2d = 2.0f * (40.f * o.dxp * o.dxp + 100.f * o.dyp * o.dyp);   // FilterInvSquare * (...), :469
+    const bool front = o.lam2 > 0.f;
+    const float rho = front ? fminf(rho3d, rho2d) : rho2d;
+    o.in3d = front && (rho3d <= rho2d);
+    o.depth = o.in3d ? o.lam2 : r4.z;
+    const float power = -0.5f * rho;
+    o.G = __expf(fminf(power, 0.f));
+    o.alpha = fminf(0.99f, r0.w * o.G);
+    o.ok = (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N) && !(power > 0.f) && !(o.alpha < 1.0f / 255.0f);
+    return o;
+}
+
+struct SfFwdArgs {
+    TileGrid grid;
+    const uint2* ranges; const uint32_t* point_list; const float4* rec; const uint32_t* rowspan;
+    const float2* coltab; const float2* rowtab; const float* bg;
+    float* accum;          // [3N] final_T, M1, M2
+    uint32_t* n_contrib;   // [2N] last contributor, median contributor
+    float* out_color; float* out_others;
+};
+
+__global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
+    __shared__ float4 s_rec[5 * SF_CHUNK];
+    __shared__ uint32_t s_span[SF_CHUNK];
+    const int lane = threadIdx.x;
+    const int patch = blockIdx.x;
+    const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
+    const uint2 range = a.ranges[patch / a.grid.waves_per_tile];
+    const uint32_t n = range.y - range.x;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    uint32_t last = 0, med_c = 0;
+    bool done = !px.inside;
+    const uint32_t nchunks = (n + SF_CHUNK - 1) / SF_CHUNK;
+    if (n > 0) {
+        SfStaged st = sf_gather(a.point_list, a.rec, a.rowspan, range.x + lane, (uint32_t)lane < n);
+        for (uint32_t c = 0; c < nchunks; c++) {
+            __syncthreads();
+            s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
+            s_rec[4 * SF_CHUNK + lane] = st.a4; s_span[lane] = st.span;
+            __syncthreads();
+            if (c + 1 < nchunks) { const uint32_t k = (c + 1) * SF_CHUNK + lane; st = sf_gather(a.point_list, a.rec, a.rowspan, range.x + k, k < n); }
+            if (__ballot(!done) == 0ull) break;
+            const uint32_t cnt = min((uint32_t)SF_CHUNK, n - c * SF_CHUNK);
+            for (uint32_t j = 0; j < cnt; j++) {
+                const float4 r0 = s_rec[j], r1 = s_rec[SF_CHUNK + j], r2 = s_rec[2 * SF_CHUNK + j], r3 = s_rec[3 * SF_CHUNK + j], r4 = s_rec[4 * SF_CHUNK + j];
+                const uint32_t span = s_span[j];
+                const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
+                const SfPair q = sf_pair(px, r0, r1, r2, r3, r4);
+                const bool hit = !done && rows && q.ok;
+                const float test_T = T * (1.f - q.alpha);
+                const bool trip = hit && test_T < 0.0001f;
+                const bool blend = hit && !trip;
+                const float w = blend ? q.alpha * T : 0.f;
+                const float m = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / q.depth);
+                dist += blend ? (m * m * (1.f - T) + M2 - 2.f * m * M1) * w : 0.f;     // :497-499
+                D += blend ? q.depth * w : 0.f;
+                M1 += blend ? m * w : 0.f;
+                M2 += blend ? m * m * w : 0.f;
+                const bool is_med = blend && T > 0.5f;                                 // :503-507
+                med = is_med ? q.depth : med;
+                med_c = is_med ? (c * SF_CHUNK + j + 1) : med_c;
+                N0 += r3.x * w; N1 += r3.y * w; N2 += r3.z * w;
+                C0 += r1.w * w; C1 += r2.w * w;
+                T = blend ? test_T : T;
+                last = blend ? (c * SF_CHUNK + j + 1) : last;
+                done = done || trip;
+            }
+        }
+    }
+    if (px.inside) {
+        const size_t N = (size_t)a.grid.W * a.grid.H;
+        a.accum[px.pix] = T; a.accum[N + px.pix] = M1; a.accum[2 * N + px.pix] = M2;
+        a.n_contrib[px.pix] = last; a.n_contrib[N + px.pix] = med_c;
+        a.out_color[px.pix] = C0 + T * a.bg[0];
+        a.out_color[N + px.pix] = C1 + T * a.bg[1];
+        a.out_others[0 * N + px.pix] = D;
+        a.out_others[1 * N + px.pix] = 1.f - T;
+        a.out_others[2 * N + px.pix] = N0; a.out_others[3 * N + px.pix] = N1; a.out_others[4 * N + px.pix] = N2;
+        a.out_others[5 * N + px.pix] = med;
+        a.out_others[6 * N + px.pix] = dist;
+    }
+}
+
+void launch_sf_render_forward(const SfFwdArgs& a, hipStream_t s) {
+    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    hipLaunchKernelGGL(k_sf_render_forward, dim3(patches), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 32-slot butterfly reduce-scatter: lane L (< 32) ends with the wave-wide sum of slot bitrev5(L).
+__device__ __forceinline__ float sf_x1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float sf_x2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)); }
+template <int M> __device__ __forceinline__ float sf_xs(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (M << 10) | 0x1F)); }
+
+__device__ __forceinline__ float sf_reduce_scatter32(float (&v)[32], int lane) {
+    { const bool hi = lane & 1;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const float keep = hi ? v[k + 16] : v[k], send = hi ? v[k] : v[k + 16]; v[k] = keep + sf_x1(send); } }
+    { const bool hi = lane & 2;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const float keep = hi ? v[k + 8] : v[k], send = hi ? v[k] : v[k + 8]; v[k] = keep + sf_x2(send); } }
+    { const bool hi = lane & 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const float keep = hi ? v[k + 4] : v[k], send = hi ? v[k] : v[k + 4]; v[k] = keep + sf_xs<4>(send); } }
+    { const bool hi = lane & 8;
+#pragma unroll
+      for (int k = 0; k < 2; k++) { const float keep = hi ? v[k + 2] : v[k], send = hi ? v[k] : v[k + 2]; v[k] = keep + sf_xs<8>(send); } }
+    { const bool hi = lane & 16;
+      const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1]; v[0] = keep + sf_xs<16>(send); }
+    v[0] += __shfl_xor(v[0], 32);
+    return v[0];
+}
+
+// packed accumulator slots (32 floats = 128 B per surfel)
+enum { SFA_COL0 = 0, SFA_COL1, SFA_OPA, SFA_N0, SFA_N1, SFA_N2, SFA_TU0, SFA_TU1, SFA_TU2, SFA_TV0, SFA_TV1, SFA_TV2,
+       SFA_TW0, SFA_TW1, SFA_TW2, SFA_AW0, SFA_AW1, SFA_AW2, SFA_M2X, SFA_M2Y, SFA_M2AX, SFA_M2AY, SFA_Z2D, SFA_COUNT };
+
+struct SfBwdArgs {
+    TileGrid grid;
+    const uint2* ranges; const uint32_t* point_list; const float4* rec; const uint32_t* rowspan;
+    const float2* coltab; const float2* rowtab; const float* bg;
+    const float* accum; const uint32_t* n_contrib;
+    const float* dL_dpix; const float* dL_dothers;
+    float* gacc;           // [32 P]
+};
+
+__global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
+    __shared__ float4 s_rec[5 * SF_CHUNK];
+    __shared__ uint32_t s_span[SF_CHUNK];
+    __shared__ uint32_t s_gid[SF_CHUNK];
+    const int lane = threadIdx.x;
+    const int patch = blockIdx.x;
+    const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
+    const uint2 range = a.ranges[patch / a.grid.waves_per_tile];
+    const size_t N = (size_t)a.grid.W * a.grid.H;
+    const uint32_t n_lane = px.inside ? a.n_contrib[px.pix] : 0u;
+    uint32_t n_max = n_lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
+    if (n_max == 0) return;
+
+    const float T_final = px.inside ? a.accum[px.pix] : 0.f;
+    const float final_D = px.inside ? a.accum[N + px.pix] : 0.f;
+    const float final_A = 1.f - T_final;
+    const uint32_t med_c = px.inside ? a.n_contrib[N + px.pix] : 0u;
+    float T = T_final;
+    float g0 = 0.f, g1 = 0.f, g_depth = 0.f, g_alpha = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, g_med = 0.f, g_reg = 0.f;
+    if (px.inside) {
+        g0 = a.dL_dpix[px.pix]; g1 = a.dL_dpix[N + px.pix];
+        g_depth = a.dL_dothers[0 * N + px.pix]; g_alpha = a.dL_dothers[1 * N + px.pix];
+        gn0 = a.dL_dothers[2 * N + px.pix]; gn1 = a.dL_dothers[3 * N + px.pix]; gn2 = a.dL_dothers[4 * N + px.pix];
+        g_med = a.dL_dothers[5 * N + px.pix]; g_reg = a.dL_dothers[6 * N + px.pix];
+    }
+    const float bgdot = a.bg[0] * g0 + a.bg[1] * g1;
+    float acc_c0 = 0.f, acc_d = 0.f, acc_a = 0.f, acc_n0 = 0.f, acc_n1 = 0.f, acc_n2 = 0.f;
+    float last_alpha = 0.f, l_c0 = 0.f, l_d = 0.f, l_n0 = 0.f, l_n1 = 0.f, l_n2 = 0.f;
+
+    const int c_last = (int)((n_max - 1) / SF_CHUNK);
+    auto gather = [&](int c) { const uint32_t k = (uint32_t)c * SF_CHUNK + lane; return sf_gather(a.point_list, a.rec, a.rowspan, range.x + k, k < n_max); };
+    SfStaged st = gather(c_last);
+    for (int c = c_last; c >= 0; c--) {
+        __syncthreads();
+        s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
+        s_rec[4 * SF_CHUNK + lane] = st.a4; s_span[lane] = st.span; s_gid[lane] = st.gid;
+        __syncthreads();
+        if (c > 0) st = gather(c - 1);
+        const int hi = (int)min((uint32_t)SF_CHUNK, n_max - (uint32_t)c * SF_CHUNK) - 1;
+        for (int j = hi; j >= 0; j--) {
+            const uint32_t e = (uint32_t)c * SF_CHUNK + j;            // 0-based list position == the reference's `contributor`
+            const float4 r0 = s_rec[j], r1 = s_rec[SF_CHUNK + j], r2 = s_rec[2 * SF_CHUNK + j], r3 = s_rec[3 * SF_CHUNK + j], r4 = s_rec[4 * SF_CHUNK + j];
+            const uint32_t span = s_span[j];
+            const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
+            const SfPair q = sf_pair(px, r0, r1, r2, r3, r4);
+            const bool contrib = rows && (e < n_lane) && q.ok;
+            if (__ballot(contrib) == 0ull) continue;
+            const float alpha = q.alpha, G = q.G, c_d = q.depth;
+            const float Tn = T / (1.f - alpha);
+            const float w = alpha * Tn;
+            // recurrences of "what lies behind" (R2/cr/backward.cu:349-410)
+            const float a_c0 = last_alpha * l_c0 + (1.f - last_alpha) * acc_c0;
+            const float a_d = last_alpha * l_d + (1.f - last_alpha) * acc_d;
+            const float a_a = last_alpha + (1.f - last_alpha) * acc_a;
+            const float a_n0 = last_alpha * l_n0 + (1.f - last_alpha) * acc_n0;
+            const float a_n1 = last_alpha * l_n1 + (1.f - last_alpha) * acc_n1;
+            const float a_n2 = last_alpha * l_n2 + (1.f - last_alpha) * acc_n2;
+            float dL_dalpha = (r1.w - a_c0) * g0;                      // only channel 0 (:358-359)
+            const float m_d = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / c_d);
+            const float dmd_dd = (SF_FAR_N * SF_NEAR_N) / ((SF_FAR_N - SF_NEAR_N) * c_d * c_d);
+            float dL_dz = (e + 1u == med_c) ? g_med : 0.f;             // contributor == median_contributor - 1 (:371)
+            dL_dz += 2.0f * (Tn * alpha) * (m_d * final_A - final_D) * g_reg * dmd_dd;     // DETACH_WEIGHT: only the m_d path (:375-388)
+            dL_dalpha += (c_d - a_d) * g_depth + (1.f - a_a) * g_alpha;
+            dL_dalpha += (r3.x - a_n0) * gn0 + (r3.y - a_n1) * gn1 + (r3.z - a_n2) * gn2;
+            dL_dalpha *= Tn;
+            dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
+            const float dL_dG = r0.w * dL_dalpha;
+            dL_dz += w * g_depth;                                       // :420
+            // 3-D branch: gradient through s = (dp.Tu', dp.Tv'), dp = lam2 p - Tw, lam2 = (Tw.n)/(p.n)   (:427-563)
+            const float ga = -dL_dG * G * q.sx, gb = -dL_dG * G * q.sy;   // dL/ds
+            const float iu = r0.x * r0.x + r0.y * r0.y + r0.z * r0.z;     // 1/(Tu.Tu)
+            const float iv = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
+            // dL/dTu = ga (dp - 2 sx Tu)/(Tu.Tu) = ga (dp * iu - 2 sx Tu')
+            const float3 gTu = sf3(ga * (q.dp.x * iu - 2.f * q.sx * r0.x), ga * (q.dp.y * iu - 2.f * q.sx * r0.y), ga * (q.dp.z * iu - 2.f * q.sx * r0.z));
+            const float3 gTv = sf3(gb * (q.dp.x * iv - 2.f * q.sy * r1.x), gb * (q.dp.y * iv - 2.f * q.sy * r1.y), gb * (q.dp.z * iv - 2.f * q.sy * r1.z));
+            const float3 gdp = sf3(ga * r0.x + gb * r1.x, ga * r0.y + gb * r1.y, ga * r0.z + gb * r1.z);
+            const float g_lam = sdot(gdp, px.p) + dL_dz;
+            const float icos = 1.f / (q.cos2 != 0.f ? q.cos2 : 1.f);
+            const float3 gTw = sf3(-gdp.x + g_lam * r3.x * icos, -gdp.y + g_lam * r3.y * icos, -gdp.z + g_lam * r3.z * icos);
+            // d lam2 / d n = (Tw (p.n) - (Tw.n) p) / (p.n)^2 = -dp / (p.n): evaluated as the reference writes it (:452-461), the
+            // difference of two ~range-sized vectors, so that its rounding (3 digits of cancellation) is the reference's
+            const float icos2 = icos * icos;
+            const float3 gN = sf3(g_lam * ((r2.x * q.cos2 - r4.w * px.p.x) * icos2), g_lam * ((r2.y * q.cos2 - r4.w * px.p.y) * icos2),
+                                  g_lam * ((r2.z * q.cos2 - r4.w * px.p.z) * icos2));
+            // 2-D branch (:578-599)
+            const float m2x = dL_dG * (-G * 2.0f * 40.f * q.dxp), m2y = dL_dG * (-G * 2.0f * 100.f * q.dyp);
+            const bool b3 = contrib && q.in3d, b2 = contrib && !q.in3d;
+            float v[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) v[k] = 0.f;
+            v[SFA_COL0] = contrib ? w * g0 : 0.f; v[SFA_COL1] = contrib ? w * g1 : 0.f;
+            v[SFA_OPA] = contrib ? G * dL_dalpha : 0.f;
+            v[SFA_N0] = (contrib ? w * gn0 : 0.f) + (b3 ? gN.x : 0.f);
+            v[SFA_N1] = (contrib ? w * gn1 : 0.f) + (b3 ? gN.y : 0.f);
+            v[SFA_N2] = (contrib ? w * gn2 : 0.f) + (b3 ? gN.z : 0.f);
+            v[SFA_TU0] = b3 ? gTu.x : 0.f; v[SFA_TU1] = b3 ? gTu.y : 0.f; v[SFA_TU2] = b3 ? gTu.z : 0.f;
+            v[SFA_TV0] = b3 ? gTv.x : 0.f; v[SFA_TV1] = b3 ? gTv.y : 0.f; v[SFA_TV2] = b3 ? gTv.z : 0.f;
+            v[SFA_TW0] = b3 ? gTw.x : 0.f; v[SFA_TW1] = b3 ? gTw.y : 0.f; v[SFA_TW2] = b3 ? gTw.z : 0.f;
+            v[SFA_AW0] = b3 ? fabsf(gTw.x) : 0.f; v[SFA_AW1] = b3 ? fabsf(gTw.y) : 0.f; v[SFA_AW2] = b3 ? fabsf(gTw.z) : 0.f;
+            v[SFA_M2X] = b2 ? m2x : 0.f; v[SFA_M2Y] = b2 ? m2y : 0.f; v[SFA_M2AX] = b2 ? fabsf(m2x) : 0.f; v[SFA_M2AY] = b2 ? fabsf(m2y) : 0.f;
+            v[SFA_Z2D] = b2 ? dL_dz : 0.f;
+            // commit the per-pixel state where this pixel really blended the entry
+            T = contrib ? Tn : T;
+            acc_c0 = contrib ? a_c0 : acc_c0; acc_d = contrib ? a_d : acc_d; acc_a = contrib ? a_a : acc_a;
+            acc_n0 = contrib ? a_n0 : acc_n0; acc_n1 = contrib ? a_n1 : acc_n1; acc_n2 = contrib ? a_n2 : acc_n2;
+            l_c0 = contrib ? r1.w : l_c0; l_d = contrib ? c_d : l_d; l_n0 = contrib ? r3.x : l_n0; l_n1 = contrib ? r3.y : l_n1; l_n2 = contrib ? r3.z : l_n2;
+            last_alpha = contrib ? alpha : last_alpha;
+            const float mine = sf_reduce_scatter32(v, lane);
+            if (lane < 32) {
+                const int slot = 16 * (lane & 1) + 8 * ((lane >> 1) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 4) & 1);
+                if (slot < SFA_COUNT) atomicAdd(a.gacc + 32 * (size_t)s_gid[j] + slot, mine);
+            }
+        }
+    }
+}
+
+void launch_sf_render_backward(const SfBwdArgs& a, hipStream_t s) {
+    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    hipLaunchKernelGGL(k_sf_render_backward, dim3(patches), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SfGaussBwdArgs {
+    int P, W, H;
+    const float* view; const float* means3D; const float* scales; const float* rotations; const float* beams; const int* radii;
+    const float* gacc;
+    float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D; float* dL_dtransMat;
+    float* dL_dtransMat_2dtemp; float* dL_dscale; float* dL_drot; float* depth;
+};
+
+__global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P) return;
+    if (!(a.radii[idx] > 0)) {                                         // every output row is written (zeros here)
+        for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; }
+        for (int k = 0; k < 3; k++) { a.dL_dnormal[3 * idx + k] = 0.f; a.dL_dmean3D[3 * idx + k] = 0.f; a.dL_dtransMat_2dtemp[3 * idx + k] = 0.f; }
+        for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
+        a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f; a.dL_dopacity[idx] = 0.f;
+        a.dL_dscale[2 * idx] = 0.f; a.dL_dscale[2 * idx + 1] = 0.f; a.depth[idx] = 0.f;
+        return;
+    }
+    const float* vm = a.view;
+    const float* g = a.gacc + 32 * (size_t)idx;
+    const float3 pw = sf3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const float3 Tw = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+                          vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+    const float rho_r = sqrtf(sdot(Tw, Tw));
+    const float rxy = sqrtf(Tw.x * Tw.x + Tw.y * Tw.y);
+    const float pi_f = 3.14159265358979323846f;
+    const float ga = fabsf(a.beams[a.H - 1] - a.beams[0]) / ((float)a.H - 1.f);   // grad_alpha (:425)
+
+    a.dL_dcolor[2 * idx] = g[SFA_COL0]; a.dL_dcolor[2 * idx + 1] = g[SFA_COL1];
+    a.dL_dopacity[idx] = g[SFA_OPA];
+    const float3 gn = sf3(g[SFA_N0], g[SFA_N1], g[SFA_N2]);
+    a.dL_dnormal[3 * idx] = gn.x; a.dL_dnormal[3 * idx + 1] = gn.y; a.dL_dnormal[3 * idx + 2] = gn.z;
+    const float3 aw = sf3(g[SFA_AW0], g[SFA_AW1], g[SFA_AW2]);
+    a.dL_dtransMat_2dtemp[3 * idx] = aw.x; a.dL_dtransMat_2dtemp[3 * idx + 1] = aw.y; a.dL_dtransMat_2dtemp[3 * idx + 2] = aw.z;
+
+    // dL/dmean2D: 3-D branch statistics are abs-linear in |dL/dTw| with per-surfel coefficients (:564-577);
+    // |sin(beta_t) cos(alpha_t)| = |Tw.y|/rho_r, |cos(beta_t) cos(alpha_t)| = |Tw.x|/rho_r, ...
+    const float irho = rho_r > 0.f ? 1.f / rho_r : 0.f, irxy = rxy > 0.f ? 1.f / rxy : 0.f;
+    const float mx3 = pi_f * (fabsf(Tw.y) * aw.x + fabsf(Tw.x) * aw.y);                        // (|..|2pi/W) * rho_r * 0.5 W
+    const float my3 = 0.5f * (float)a.H * ga * (fabsf(Tw.z) * fabsf(Tw.x) * irxy * aw.x + fabsf(Tw.z) * fabsf(Tw.y) * irxy * aw.y + rxy * aw.z);
+    const float m2x = g[SFA_M2X], m2y = g[SFA_M2Y];
+    a.dL_dmean2D[4 * idx] = mx3 + m2x * 0.5f * (float)a.W;
+    a.dL_dmean2D[4 * idx + 1] = my3 + m2y * 0.5f * (float)a.H;
+    a.dL_dmean2D[4 * idx + 2] = mx3 + g[SFA_M2AX] * 0.5f * (float)a.W;
+    a.dL_dmean2D[4 * idx + 3] = my3 + g[SFA_M2AY] * 0.5f * (float)a.H;
+
+    // dL/dT rows: 3-D sums + the 2-D branch's Tw terms (:590-598)
+    float3 gTw = sf3(g[SFA_TW0], g[SFA_TW1], g[SFA_TW2]);
+    {
+        const float z2 = g[SFA_Z2D];
+        const float kx = (float)a.W / (2.f * pi_f) * irxy * irxy;
+        const float3 ddelx = sf3(kx * Tw.y, -kx * Tw.x, 0.f);
+        const float ky = ga * irho * irho;
+        const float3 ddely = sf3(-ky * Tw.z * Tw.x * irxy, -ky * Tw.z * Tw.y * irxy, ky * rxy);
+        gTw.x += z2 * Tw.x * irho + m2x * ddelx.x + m2y * ddely.x;
+        gTw.y += z2 * Tw.y * irho + m2x * ddelx.y + m2y * ddely.y;
+        gTw.z += z2 * Tw.z * irho + m2y * ddely.z;
+    }
+    float* gT = a.dL_dtransMat + 9 * (size_t)idx;
+    const float3 gTu = sf3(g[SFA_TU0], g[SFA_TU1], g[SFA_TU2]), gTv = sf3(g[SFA_TV0], g[SFA_TV1], g[SFA_TV2]);
+    gT[0] = gTu.x; gT[1] = gTu.y; gT[2] = gTu.z; gT[3] = gTv.x; gT[4] = gTv.y; gT[5] = gTv.z; gT[6] = gTw.x; gT[7] = gTw.y; gT[8] = gTw.z;
+
+    // K10': T rows are (Rv L0, Rv L1, p_view)  =>  dL/dL0 = Rv^T dL/dTu, dL/dL1 = Rv^T dL/dTv, dL/dp = Rv^T dL/dTw
+    const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+    float3 c0, c1, c2;
+    sf_quat_cols(q, c0, c1, c2);
+    const float3 dL0 = sf_rot_world(vm, gTu), dL1 = sf_rot_world(vm, gTv), dLp = sf_rot_world(vm, gTw);
+    float3 dtn = sf_rot_world(vm, gn);
+    const float3 nv = sf_rot_view(vm, c2);
+    const float cs = -(Tw.x * nv.x + Tw.y * nv.y + Tw.z * nv.z);
+    if (!(cs > 0.f)) { dtn.x = -dtn.x; dtn.y = -dtn.y; dtn.z = -dtn.z; }
+    a.depth[idx] = sqrtf(Tw.x * Tw.x + Tw.z * Tw.z);                   // :670 (x,z only, as the reference)
+    const float s0 = a.scales[2 * idx], s1 = a.scales[2 * idx + 1];   // the backward ignores scale_modifier (:632)
+    a.dL_dscale[2 * idx] = sdot(dL0, c0);
+    a.dL_dscale[2 * idx + 1] = sdot(dL1, c1);
+    a.dL_dmean3D[3 * idx] = dLp.x; a.dL_dmean3D[3 * idx + 1] = dLp.y; a.dL_dmean3D[3 * idx + 2] = dLp.z;
+    // quat_to_rotmat_vjp with v_R columns (dL0*s0, dL1*s1, dtn)  (R2/cr/auxiliary.h:274-316)
+    const float3 v0 = sf3(dL0.x * s0, dL0.y * s0, dL0.z * s0), v1 = sf3(dL1.x * s1, dL1.y * s1, dL1.z * s1), v2 = dtn;
+    const float sn = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const float w = q.x * sn, x = q.y * sn, y = q.z * sn, z = q.w * sn;
+    // v_R[c][r]: column c = v_c, row r = component
+    const float R01 = v0.y, R02 = v0.z, R10 = v1.x, R12 = v1.z, R20 = v2.x, R21 = v2.y, R00 = v0.x, R11 = v1.y, R22 = v2.z;
+    float* gq = a.dL_drot + 4 * (size_t)idx;
+    gq[0] = 2.f * (x * (R12 - R21) + y * (R20 - R02) + z * (R01 - R10));
+    gq[1] = 2.f * (-2.f * x * (R11 + R22) + y * (R01 + R10) + z * (R02 + R20) + w * (R12 - R21));
+    gq[2] = 2.f * (x * (R01 + R10) - 2.f * y * (R00 + R22) + z * (R12 + R21) + w * (R20 - R02));
+    gq[3] = 2.f * (x * (R02 + R20) + y * (R12 + R21) - 2.f * z * (R00 + R11) + w * (R01 - R10));
+}
+
+void launch_sf_gaussian_backward(const SfGaussBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_sf_gaussian_backward, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace lg
+
+#include "surfel_api.inc"

@@ -18,6 +18,10 @@
  * rounds exactly as written in the reference source (float ops in float, the handful of
  * double promotions of SURVEY.md Appendix A.5 in double).  GLM's column-major mat3 product
  * order (third_party/glm/glm/detail/type_mat3x3.inl:486-520) is reproduced by m3_mul().
+ * The cos/sin of the per-pixel ray table are evaluated in double and rounded to float (lgo_cosf / lgo_sinf):
+ * the correctly rounded fp32 value, so the oracle does not inherit the host libm's last-ulp choices (glibc's
+ * cosf/sinf differ from the correctly rounded result on ~1.5 % of the 2650 azimuths of a 64x2650 frame, CUDA's
+ * on others; one ulp of a ray component moves a blend weight by up to 1e-3 at 50 m range).
  */
 #include <math.h>
 #include <stdint.h>
@@ -30,6 +34,8 @@
 #define LGO_BLOCK_Y 1    /* cr/config.h:17 */
 
 static const float LGO_PI = 3.14159265358979323846f; /* cr/forward.cu:21, cr/backward.cu:18 */
+static float lgo_cosf(float x) { return (float)cos((double)x); }
+static float lgo_sinf(float x) { return (float)sin((double)x); }
 static const float LGO_RAY_DIV = 0.002f;             /* cr/forward.cu:22 Ray_Divergence_Angle */
 
 typedef struct { float x, y, z; } f3;
@@ -349,12 +355,12 @@ static void stable_sort_pairs(uint64_t* keys, uint32_t* vals, long long n, int e
 }
 
 /* Unit direction of pixel (x,y): cr/forward.cu:589-591 == cr/backward.cu:659-661.
- * beta is evaluated in double and rounded to float; cos/sin are the float overloads. */
+ * beta is evaluated in double and rounded to float; cos/sin are the float overloads (correctly rounded here). */
 static f3 pixel_dir(int x, int y, int W, int H, const float* beams) {
     float pixfx = (float)x;
     float alp = beams[H - 1 - y];
     float beta = (float)(-((double)pixfx - (double)(float)W / 2.0) / (double)(float)W * 2.0 * (double)LGO_PI);
-    f3 q = { cosf(alp) * cosf(beta), cosf(alp) * sinf(beta), sinf(alp) };
+    f3 q = { lgo_cosf(alp) * lgo_cosf(beta), lgo_cosf(alp) * lgo_sinf(beta), lgo_sinf(alp) };
     return q;
 }
 

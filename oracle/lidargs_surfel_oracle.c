@@ -8,7 +8,10 @@
  * Compile-time configuration restated: NUM_CHANNELS 2, BLOCK_X 16, BLOCK_Y 1 (R2/cr/config.h:15-17);
  * RENDER_AXUTILITY 1, DUAL_VISIABLE 1, DETACH_WEIGHT 1, near_n 0.2, far_n 80, FilterInvSquare 2
  * (R2/cr/auxiliary.h:21-39); Ray_Divergence_Angle 0.006 (R2/cr/forward.cu:18).
- * Plain C, -ffp-contract=off: every expression rounds as written.
+ * Plain C, -ffp-contract=off: every expression rounds as written.  atan2 and the ray-table cos/sin are evaluated in
+ * double and rounded to float (sf_atan2, sf_cosf, sf_sinf), i.e. the correctly rounded fp32 result, so the oracle does not depend on the host libm's
+ * atan2f error (CUDA's atan2f is 2-ulp, glibc's 1-ulp: the projected centre p_c ~ 1e3 px enters the 2-D filter
+ * exponent with a gain of ~80/px, so one ulp of atan2f is a 1e-3 change of a blend weight).
  */
 #include <math.h>
 #include <stdint.h>
@@ -32,6 +35,13 @@ static const float SF_NEAR_N = 0.2f, SF_FAR_N = 80.0f, SF_FILTER_INV_SQ = 2.0f;
 
 typedef struct { float x, y, z; } sf3;
 typedef struct { float x, y; } sf2;
+
+static float sf_cosf(float x) { return (float)cos((double)x); }
+static float sf_sinf(float x) { return (float)sin((double)x); }
+static float sf_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+static int sfo_reverse_pixel_order = 0;
+void sfo_set_reverse_pixel_order(int on) { sfo_reverse_pixel_order = on; }
 
 static char sfo_err[256] = "";
 const char* sfo_last_error(void) { return sfo_err; }
@@ -74,9 +84,9 @@ static sf3 sf_vec4x3_t(sf3 p, const float* m) {        /* transformVec4x3Transpo
 /* R2/cr/forward.cu:118-174 cpmpute_pix_f / cpmpute_pix: (column, row) of a view-space point.
  * with_cull: the Ray_Divergence_Angle beam-fan cull (single, not doubled as in R3). */
 static int sf_compute_pix(sf3 p, int W, int H, const float* beams, int with_cull, sf2* pix) {
-    float beta = SF_PI - atan2f(p.y, p.x);
+    float beta = SF_PI - sf_atan2(p.y, p.x);
     float p_c = beta / (2 * SF_PI / (float)W);
-    float alpha = atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y));
+    float alpha = sf_atan2(p.z, sqrtf(p.x * p.x + p.y * p.y));
     int i = sf_find_closest_label(beams, alpha, H);
     float before, after, p_r;
     if (i > 0) {
@@ -260,7 +270,7 @@ static sf3 sf_pixel_dir(int x, int y, int W, int H, const float* beams) {
     float pixfx = (float)x;
     float beta = (float)(-((double)pixfx - (double)(float)W / 2.0) / (double)(float)W * 2.0 * (double)SF_PI);
     float alp = beams[H - 1 - y];
-    sf3 p = { cosf(alp) * cosf(beta), cosf(alp) * sinf(beta), sinf(alp) };
+    sf3 p = { sf_cosf(alp) * sf_cosf(beta), sf_cosf(alp) * sf_sinf(beta), sf_sinf(alp) };
     return p;
 }
 
@@ -424,8 +434,11 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
     const float pi = SF_PI;
 
     /* K8': R2/cr/backward.cu:143-605 */
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
+    for (int yy = 0; yy < H; yy++)
+        for (int xx = 0; xx < W; xx++) {
+            /* the reference accumulates with float atomics in scheduling order; the knob replays the pixels in reverse
+             * so that tests can measure how wide that summation-order band is */
+            const int y = sfo_reverse_pixel_order ? H - 1 - yy : yy, x = sfo_reverse_pixel_order ? W - 1 - xx : xx;
             const uint32_t tile = (uint32_t)(y / SF_BLOCK_Y) * s->gx + (uint32_t)(x / SF_BLOCK_X);
             const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
             const long long pix = (long long)W * y + x;
@@ -498,8 +511,8 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
                 const float dL_dG = q.opa * dL_dalpha;
                 dL_dz += alpha * T * dL_ddepth;
                 const sf3 Tw = q.Tw, Tu = q.Tu, Tv = q.Tv, dp = q.dp;
-                float beta_temp = pi - atan2f(Tw.y, Tw.x);
-                float alpha_temp = atan2f(Tw.z, sqrtf(Tw.x * Tw.x + Tw.y * Tw.y));
+                float beta_temp = pi - sf_atan2(Tw.y, Tw.x);
+                float alpha_temp = sf_atan2(Tw.z, sqrtf(Tw.x * Tw.x + Tw.y * Tw.y));
                 float grad_alpha = fabsf(beams[H - 1] - beams[0]) / ((float)H - 1);
                 if (q.rho3d <= q.rho2d && q.real_depth > 0) {
                     float dL_dD = dL_dz;

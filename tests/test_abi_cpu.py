@@ -101,7 +101,7 @@ def test_product_never_touches_the_oracle():
         if os.path.basename(base) in ("build", "__pycache__"):
             continue
         for fn in files:
-            if fn.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+            if fn.endswith((".py", ".hip", ".h", ".inc", ".cpp", ".c")):
                 txt = open(os.path.join(base, fn), errors="replace").read()
                 if re.search(r"\boracle\b|lidargs_oracle|liblidargs_oracle|\blgo\b", txt):
                     bad.append(os.path.join(base, fn))
@@ -119,3 +119,27 @@ def test_missing_library_is_a_loud_import_error(tmp_path, hip_lib_built):
     code = f"import sys; sys.path.insert(0, {str(tmp_path)!r}); import diff_lidargs_rasterization"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "liblidargs_hip.so is missing" in (r.stderr + r.stdout).replace("\n", " ") or "is missing" in r.stderr
+
+
+def test_surfel_package_mirrors_the_reference_interface(hip_lib_built):
+    """diff_lidargs_surfel_rasterization: 14-field settings tuple, the three rasterizer methods, loud CPU refusal."""
+    import torch
+    import diff_lidargs_surfel_rasterization as pkg
+    assert pkg.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "bg", "scale_modifier", "depth_threshold", "viewmatrix", "projmatrix", "sh_degree", "campos",
+        "prefiltered", "beam_inclinations", "lidar_far", "lidar_near", "debug")
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "rasterize_aussians_filter"):
+        assert callable(getattr(pkg._C, name))
+    P = 4
+    s = pkg.GaussianRasterizationSettings(16, 512, torch.zeros(2), 1.0, 0.0, torch.eye(4), torch.eye(4), 1, torch.zeros(3), False,
+                                          torch.linspace(-0.4, 0.1, 16), 80, 0, False)
+    r = pkg.GaussianRasterizer(s)
+    m3, m2, op = torch.randn(P, 3), torch.zeros(P, 4), torch.ones(P, 1)
+    with pytest.raises(Exception, match="excatly one"):
+        r(m3, m2, op)
+    with pytest.raises(Exception, match="exactly one"):
+        r(m3, m2, op, colors_precomp=torch.zeros(P, 2))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        r(m3, m2, op, colors_precomp=torch.zeros(P, 2), scales=torch.ones(P, 2), rotations=torch.ones(P, 4))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        r.visible_filter(m3, torch.ones(P, 2), torch.ones(P, 4))

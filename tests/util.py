@@ -17,14 +17,14 @@ OUTLIER_FRAC = 2e-3
 OUTLIER_MAX = 5e-2
 
 
-def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, outlier_frac=OUTLIER_FRAC, outlier_max=OUTLIER_MAX, verbose=True):
+def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, outlier_frac=OUTLIER_FRAC, outlier_max=OUTLIER_MAX, verbose=True, scale=None):
     hip = np.asarray(hip, dtype=np.float64).ravel()
     ref = np.asarray(ref, dtype=np.float64).ravel()
     assert hip.shape == ref.shape, (name, hip.shape, ref.shape)
     assert np.isfinite(hip).all(), f"{name}: non-finite values in the HIP result"
     if ref.size == 0:
         return dict(name=name, max=0.0, outliers=0, n=0)
-    scale = np.abs(ref).max()
+    scale = np.abs(ref).max() if scale is None else float(scale)   # `scale`: magnitude of the terms the value is a difference of
     err = np.abs(hip - ref) / (np.abs(ref) + floor * scale + 1e-30)
     bad = err > rtol
     nbad = int(bad.sum())
@@ -104,3 +104,54 @@ def oracle_forward_backward(scene, W, H, grads=None, cov3D_precomp=None, far=80,
 
 
 GRAD_KEYS_SR = ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations")
+
+
+# ---- surfel variant (BASELINE config 5) ---------------------------------------------------------------------------
+GRAD_KEYS_SURFEL = ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations")
+
+
+def surfel_scene(kind, P, H, seed, random_view=True):
+    import lidargs_scenes as sc
+    s = sc.make_scene(kind, P, H, seed, random_view=random_view)
+    s["scales"] = np.ascontiguousarray(s["scales"][:, :2])
+    return s
+
+
+def surfel_upstream_grads(H, W, seed):
+    rng = np.random.default_rng(seed + 200)
+    return rng.normal(size=(2, H, W)).astype(np.float32), rng.normal(size=(7, H, W)).astype(np.float32)
+
+
+def hip_surfel_forward_backward(scene, W, H, grads=None, far=80, near=0, scale_modifier=1.0, device="cuda"):
+    import torch
+    from diff_lidargs_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    st = to_torch(scene, device)
+    P = st["means3D"].shape[0]
+    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((P, 4), dtype=torch.float32, device=device, requires_grad=True)
+    settings = GaussianRasterizationSettings(
+        image_height=int(H), image_width=int(W), bg=st["bg"], scale_modifier=scale_modifier, depth_threshold=0.0,
+        viewmatrix=st["viewmatrix"], projmatrix=torch.eye(4, device=device), sh_degree=1, campos=torch.zeros(3, device=device),
+        prefiltered=False, beam_inclinations=st["beams"], lidar_far=int(far), lidar_near=int(near), debug=False)
+    rast = GaussianRasterizer(settings)
+    color, radii, others, pixels = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=None,
+                                        colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+    out = dict(color=color.detach().cpu().numpy(), others=others.detach().cpu().numpy(), radii=radii.cpu().numpy(),
+               pixels=pixels.cpu().numpy(), rasterizer=rast)
+    if grads is not None:
+        gc, go = (torch.from_numpy(g).to(device) for g in grads)
+        torch.autograd.backward([color, others], [gc, go])
+        out.update(dL_dmeans3D=leaves["means3D"].grad.cpu().numpy(), dL_dmeans2D=means2D.grad.cpu().numpy(),
+                   dL_dcolors=leaves["colors"].grad.cpu().numpy(), dL_dopacity=leaves["opacities"].grad.cpu().numpy(),
+                   dL_dscales=leaves["scales"].grad.cpu().numpy(), dL_drotations=leaves["rotations"].grad.cpu().numpy())
+    return out
+
+
+def oracle_surfel_forward_backward(scene, W, H, grads=None, far=80, near=0, scale_modifier=1.0):
+    from oracle import lgo_surfel
+    f = lgo_surfel.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
+                           scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"], scale_modifier=scale_modifier, far=far, near=near)
+    out = dict(color=f.color, others=f.others, radii=f.radii, fwd=f)
+    if grads is not None:
+        out.update(lgo_surfel.backward(f, *grads))
+    return out
