@@ -14,6 +14,7 @@ BASELINE_CONFIGS = {
     "cfg2": ("street", 500_000, 64, 2650, 2),
     "cfg3": ("street", 2_000_000, 64, 2650, 3),
     "cfg4": ("shell", 8_000_000, 128, 4096, 4),
+    "cfg5": ("street", 2_000_000, 64, 2650, 5),     # surfel variant: scales[:, :2] are the two surfel axes
 }
 
 
