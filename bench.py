@@ -144,7 +144,11 @@ def main():
         import lidargs_dist
         comm = lidargs_dist.TorchDistComm()
         # range-shell edges are a load-balancing choice, not a result: cut once for this (static) scene and view
-        edges = comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80), 0)
+        import math
+        beams = st["beams"]
+        tile_rad = (16 * 2 * math.pi / W, 4 * float(beams[-1] - beams[0]) / max(1, H - 1))      # 16 columns x 4 rows per tile
+        edges = comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
+                                                        tile_rad=tile_rad), 0)
         rast = lidargs_dist.ShellRasterizer(settings, comm, edges=edges)
 
         def step():

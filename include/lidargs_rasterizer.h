@@ -227,6 +227,24 @@ int lidargs_backward_shell(
     float* dL_dmean3D, float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2,
     float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug, void* stream);
 
+/* ---- range-shell helpers (multi-GPU, lidar-gs_amd/lidargs_dist.py; no reference counterpart) -------------------------
+ * lidargs_shell_select compacts the Gaussians whose view-space range lies in [shell_lo, shell_hi) -- the same float test
+ * lidargs_forward_shell applies -- into dense arrays, in ascending index order, so that a rank's frame runs on ~P/N rows.
+ * idx_out i32[P] and the five out_* arrays have room for P rows; scratch holds lidargs_shell_select_scratch_bytes(P) bytes.
+ * Returns the number of selected Gaussians (synchronises the stream) or a negative error code.
+ * lidargs_shell_transmittance: T_in[i] = prod_{g<rank} all_T[g*N+i].
+ * lidargs_shell_compose folds the gathered per-shell planes (planes f32[G*5*N], per shell C0, C1, D, T_end, T_hand):
+ * image = sum of partials (+ T_final * background), T_final = T_end of the first shell whose T_hand < 1e-4 (the last
+ * shell's otherwise), behind f32[3N] = sum of the partials of the shells behind `rank`. */
+size_t lidargs_shell_select_scratch_bytes(int P);
+int lidargs_shell_select(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                         const float* rotations, const float* viewmatrix, float shell_lo, float shell_hi,
+                         int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
+                         float* out_rotations, char* scratch, size_t scratch_bytes, void* stream);
+int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, void* stream);
+int lidargs_shell_compose(int G, int rank, int N, const float* planes, const float* background, float* out_color,
+                          float* out_depth, float* out_occ, float* T_final, float* behind, void* stream);
+
 /* ---- 2DGS "laser-surfel" variant (BASELINE config 5) ---------------------------------------------
  * Drop-in for CudaRasterizer::Rasterizer of /root/reference/submodules/diff_lidargs_surfel_rasterization
  * ("R2/"): forward R2/cuda_rasterizer/rasterizer.h:31-58, backward :60-94, visible_filter :96-114

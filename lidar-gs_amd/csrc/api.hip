@@ -65,9 +65,19 @@ int tile_rows() {
 int max_segments() {
     static int v = [] {
         const char* e = getenv("LIDARGS_MAX_SEGMENTS");
-        int m = e ? atoi(e) : 32;
+        int m = e ? atoi(e) : 33;
         if (m < 1) m = 1;
-        if (m > 64) m = 64;
+        if (m > 63) m = 63;
+        return m | 1;       // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
+    }();
+    return v;
+}
+
+int segment_length() {
+    static int v = [] {
+        const char* e = getenv("LIDARGS_SEG_LEN");
+        int m = e ? atoi(e) : LG_SEG_LEN_DEFAULT;
+        if (m < 64) m = 64;
         return m;
     }();
     return v;
@@ -216,7 +226,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
-    ra.seg = bin.seg; ra.S = S;
+    ra.seg = bin.seg; ra.S = S; ra.seg_len = segment_length();
     ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = R;
     ra.transmittance_only = transmittance_pass;
@@ -275,7 +285,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     lg::RenderBwdArgs rb;
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
-    rb.seg = bin.seg; rb.S = S;
+    rb.seg = bin.seg; rb.S = S; rb.seg_len = segment_length();
     rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = (size_t)R;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
@@ -409,7 +419,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
-    ra.seg = bin.seg; ra.S = S;
+    ra.seg = bin.seg; ra.S = S; ra.seg_len = segment_length();
     ra.flags = bin.flags; ra.R = (size_t)R;      // written by the shell's phase 1 (lidargs_forward_shell)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
@@ -522,6 +532,50 @@ int lidargs_last_counters(long long* out, int n) {
     int k = 0;
     for (; k < n && k < 8; k++) out[k] = g_counters[k];
     return k;
+}
+
+size_t lidargs_shell_select_scratch_bytes(int P) {
+    const size_t n = P > 0 ? (size_t)P : 1;
+    return sizeof(uint32_t) * (2 * n + lg::scan_scratch_words(n) + 64) + 256;
+}
+
+int lidargs_shell_select(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
+                         const float* viewmatrix, float shell_lo, float shell_hi, int* idx_out, float* out_means3D, float* out_colors,
+                         float* out_opacities, float* out_scales, float* out_rotations, char* scratch, size_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: P < 0%s");
+    if (P == 0) return 0;
+    if (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !idx_out || !out_means3D || !out_colors || !out_opacities ||
+        !out_scales || !out_rotations || !scratch)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: NULL pointer%s");
+    if (scratch_bytes < lidargs_shell_select_scratch_bytes(P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: scratch too small%s");
+    lg::Carver c(scratch);
+    uint32_t* flags = c.take<uint32_t>((size_t)P);
+    uint32_t* offs = c.take<uint32_t>((size_t)P);
+    uint32_t* total = c.take<uint32_t>(64);
+    uint32_t* scan_scratch = c.take<uint32_t>(lg::scan_scratch_words((size_t)P));
+    lg::launch_shell_flags(P, means3D, viewmatrix, shell_lo, shell_hi, flags, stream);
+    lg::launch_exclusive_scan(flags, offs, (size_t)P, total, scan_scratch, stream);
+    lg::launch_shell_gather(P, flags, offs, means3D, colors, opacities, scales, rotations, idx_out, out_means3D, out_colors, out_opacities,
+                            out_scales, out_rotations, stream);
+    uint32_t total_h = 0;
+    LG_HIP(hipMemcpyAsync(&total_h, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    LG_HIP(hipStreamSynchronize(stream));
+    return (int)total_h;
+}
+
+int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, void* stream_) {
+    if (G < 1 || rank < 0 || rank >= G || N < 0 || !all_T || !T_in) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_transmittance: bad argument%s");
+    if (N) lg::launch_shell_transmittance(G, rank, N, all_T, T_in, (hipStream_t)stream_);
+    return 0;
+}
+
+int lidargs_shell_compose(int G, int rank, int N, const float* planes, const float* background, float* out_color, float* out_depth,
+                          float* out_occ, float* T_final, float* behind, void* stream_) {
+    if (G < 1 || rank < 0 || rank >= G || N < 0 || !planes || !out_color || !out_depth || !out_occ || !T_final || !behind)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_compose: bad argument%s");
+    if (N) lg::launch_shell_compose(G, rank, N, planes, background, out_color, out_depth, out_occ, T_final, behind, (hipStream_t)stream_);
+    return 0;
 }
 
 }  // extern "C"

@@ -115,13 +115,14 @@ struct BinView {
     uint8_t* flags;                      // [waves_per_tile][R]: pass 1 saw >= 1 pixel of the patch take this entry
 };
 
-// Number of list segments per tile: a pure function of (R, tiles) so that backward recomputes it.
+// List segments: the launch provides `max_segments` workgroups per patch; each tile uses ceil(len / seg_len) of them
+// (render.hip segment_count), so long lists of a skewed frame (far range shells, street canyons) are split as finely as
+// the short ones are left alone.  The count is a pure function of the tile's range: backward recomputes it.
+#define LG_SEG_LEN_DEFAULT 128
 inline int choose_segments(size_t R, int tiles, int max_segments) {
-    const size_t avg = tiles > 0 ? R / (size_t)tiles : 0;
-    size_t s = (avg + 127) / 128;
-    if (s < 1) s = 1;
-    if (s > (size_t)max_segments) s = (size_t)max_segments;
-    return (int)s;
+    (void)tiles;
+    if (R == 0) return 1;
+    return max_segments < 1 ? 1 : max_segments;
 }
 
 inline size_t bin_carve(char* base, size_t R, size_t patches, int waves_per_tile, int S, BinView* v) {
@@ -167,7 +168,7 @@ struct TileGrid {
     int tiles_x, tiles_y;   // list tiles
     int ref_tiles_x;        // == tiles_x (16-wide), reference grid.x
     int waves_per_tile;
-    int num_tiles() const { return tiles_x * tiles_y; }
+    __host__ __device__ int num_tiles() const { return tiles_x * tiles_y; }
 };
 
 inline TileGrid make_grid(int W, int H, int TH) {
@@ -203,6 +204,13 @@ void launch_preprocess(const PreprocessParams& pp, const float* means3D, const f
                        int* radii, int* radii_xy, GeomView g, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
 
+void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s);
+void launch_shell_compose(int G, int rank, int N, const float* planes, const float* bg, float* out_color, float* out_depth, float* out_occ,
+                          float* T_final, float* behind, hipStream_t s);
+void launch_shell_flags(int P, const float* means3D, const float* view, float lo, float hi, uint32_t* flags, hipStream_t s);
+void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, const float* means3D, const float* colors, const float* opacities,
+                         const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
+                         float* o_scales, float* o_rot, hipStream_t s);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s);
 // sorts (key,val) pairs on key bits [0,end_bit); result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
@@ -221,7 +229,8 @@ struct RenderFwdArgs {
     const float* T_in;        // nullptr = 1
     float* final_T; float* T_pass;
     float* out_color; float* out_depth; float* out_occ;
-    float* seg; int S;        // per-(patch, segment) planes, segments per list
+    float* seg; int S;        // per-(patch, segment) planes, segment slots per list
+    int seg_len;              // target entries per segment (a tile uses min(S, ceil(len / seg_len)) segments)
     uint8_t* flags; size_t R; // per-(sub, entry) contribution flags written by pass 1 (nullptr when pass 1 never runs)
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
@@ -236,7 +245,7 @@ struct RenderBwdArgs {
     const float2* coltab; const float2* rowtab;
     const float* bg;
     const float* final_T;
-    const float* seg; int S;
+    const float* seg; int S; int seg_len;
     const uint8_t* flags; size_t R;
     const float* T_final_global;   // nullptr = final_T (single GPU)
     const float* behind;           // nullptr or f32[3*N]: colour0, colour1, depth sums of farther shells

@@ -464,4 +464,46 @@ void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_gaussian_backward, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Range-shell selection (multi-GPU): flag the Gaussians whose range lies in [lo, hi) with exactly the arithmetic
+// k_preprocess uses for its own shell test (same expression, same -ffp-contract=off file), then gather their
+// attributes into dense arrays in ascending index order.  The rank's whole frame then runs on P/N rows.
+__global__ void __launch_bounds__(256) k_shell_flags(int P, const float* __restrict__ means3D, const float* __restrict__ vm, float lo, float hi,
+                                                     uint32_t* __restrict__ flags) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float3 pw = f3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 p = f3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12],
+                        vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+                        vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+    const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    flags[idx] = (dist >= lo && dist < hi) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_shell_gather(int P, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs,
+                                                      const float* __restrict__ means3D, const float* __restrict__ colors,
+                                                      const float* __restrict__ opacities, const float* __restrict__ scales,
+                                                      const float* __restrict__ rotations, int* __restrict__ idx_out,
+                                                      float* __restrict__ o_means, float* __restrict__ o_colors, float* __restrict__ o_opac,
+                                                      float* __restrict__ o_scales, float* __restrict__ o_rot) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P || flags[idx] == 0u) return;
+    const size_t c = offs[idx];
+    idx_out[c] = idx;
+    for (int k = 0; k < 3; k++) { o_means[3 * c + k] = means3D[3 * (size_t)idx + k]; o_scales[3 * c + k] = scales[3 * (size_t)idx + k]; }
+    o_colors[2 * c] = colors[2 * (size_t)idx]; o_colors[2 * c + 1] = colors[2 * (size_t)idx + 1];
+    o_opac[c] = opacities[idx];
+    reinterpret_cast<float4*>(o_rot)[c] = reinterpret_cast<const float4*>(rotations)[idx];
+}
+
+void launch_shell_flags(int P, const float* means3D, const float* view, float lo, float hi, uint32_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_flags, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, lo, hi, flags);
+}
+void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, const float* means3D, const float* colors, const float* opacities,
+                         const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
+                         float* o_scales, float* o_rot, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_gather, dim3((P + 255) / 256), dim3(256), 0, s, P, flags, offs, means3D, colors, opacities, scales, rotations,
+                       idx_out, o_means, o_colors, o_opac, o_scales, o_rot);
+}
+
 }  // namespace lg

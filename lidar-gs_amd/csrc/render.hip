@@ -79,10 +79,30 @@ __device__ __forceinline__ Staged gather_entry(const uint32_t* __restrict__ poin
     return s;
 }
 
-// [start, end) of segment `seg` of a tile list
-__device__ __forceinline__ uint2 segment_range(uint2 range, int S, int seg) {
+// blockIdx -> (patch, segment): segment-fastest, with S ODD.  Workgroups are dealt round-robin to the 8 XCDs (b % 8) and
+// the work of a frame is front-loaded (pass 2 and the backward retire the segments behind the T < 1e-4 stop at once), so
+// with S a multiple of 8 every first segment lands on the same XCD (measured: backward blend 0.30 -> 2.56 ms at S = 32).
+// With S odd the segment index is decorrelated from b % 8.  Dealing spatial groups of patches to XCDs instead (for L2
+// reuse between neighbouring tiles) measured slower on pass 1 (0.39 vs 0.36 ms), so the plain numbering stays.
+__device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int S, int& patch, int& seg) {
+    seg = (int)(b % (unsigned)S);
+    patch = (int)(b / (unsigned)S);
+    return patch < patches;
+}
+__host__ inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * (unsigned)S; }
+
+// Segments of a tile list: ceil(L / seg_len) of them, at most S (the launch provides S workgroups per patch; the
+// surplus ones retire at once and never touch the segment planes).  A pure function of the tile's range, so every
+// kernel of a frame (and the backward) recomputes the same split.
+__device__ __forceinline__ int segment_count(uint2 range, int S, int seg_len) {
     const uint32_t L = range.y - range.x;
-    const uint32_t len = (L + (uint32_t)S - 1u) / (uint32_t)S;
+    const uint32_t want = (L + (uint32_t)seg_len - 1u) / (uint32_t)seg_len;
+    return (int)min((uint32_t)S, max(1u, want));
+}
+// [start, end) of segment `seg` (< segment_count) of a tile list
+__device__ __forceinline__ uint2 segment_range(uint2 range, int St, int seg) {
+    const uint32_t L = range.y - range.x;
+    const uint32_t len = (L + (uint32_t)St - 1u) / (uint32_t)St;
     const uint32_t a = min(range.y, range.x + (uint32_t)seg * len);
     const uint32_t b = min(range.y, a + len);
     return make_uint2(a, b);
@@ -96,12 +116,15 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     __shared__ uint32_t s_span[LG_CHUNK];
     const int lane = threadIdx.x;
     const int S = a.S;
-    const int seg = blockIdx.x % S;
-    const int patch = blockIdx.x / S;                                  // = tile * waves_per_tile + sub
     const int wpt = a.grid.waves_per_tile;
+    int patch, seg;                                                    // patch = tile * waves_per_tile + sub
+    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, S, patch, seg)) return;
     const int tile = patch / wpt, sub = patch - tile * wpt;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    if (seg >= St) return;
     const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
-    const uint2 sr = segment_range(a.ranges[tile], S, seg);
+    const uint2 sr = segment_range(tr, St, seg);
     const uint32_t n = sr.y - sr.x;
     float* segbase = a.seg + ((size_t)patch * S + seg) * (LG_SEG_PLANES * 64);
 
@@ -219,18 +242,19 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     const int pix = y * g.W + x;
     const float* sb = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + lane;
     const size_t stride = LG_SEG_PLANES * 64;
+    const int St = segment_count(a.ranges[tile], S, a.seg_len);
 
     if (a.transmittance_only) {
         // hand-over value of the whole list: product of the segments' (a tripped segment makes it < 1e-4)
         float T = 1.f;
-        for (int k = 0; k < S; k++) T *= sb[k * stride + LG_SEG_TPASS * 64];
+        for (int k = 0; k < St; k++) T *= sb[k * stride + LG_SEG_TPASS * 64];
         if (a.T_pass) a.T_pass[pix] = T;
         return;
     }
     float C0 = 0.f, C1 = 0.f, D = 0.f;
     float T_final = a.T_in ? a.T_in[pix] : 1.f, T_hand = T_final;
     bool stopped = false;
-    for (int k = 0; k < S; k++) {
+    for (int k = 0; k < St; k++) {
         if (stopped) break;
         C0 += sb[k * stride + LG_SEG_C0 * 64];
         C1 += sb[k * stride + LG_SEG_C1 * 64];
@@ -250,11 +274,11 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
 }
 
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile) * (unsigned)a.S;
+    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S);
     hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
 }
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile) * (unsigned)a.S;
+    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S);
     hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
 }
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
@@ -321,11 +345,14 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     __shared__ uint32_t s_gid[LG_CHUNK];
     const int lane = threadIdx.x;
     const int S = a.S;
-    const int seg = blockIdx.x % S;
-    const int patch = blockIdx.x / S;
     const int wpt = a.grid.waves_per_tile;
+    int patch, seg;
+    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, S, patch, seg)) return;
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const size_t stride = LG_SEG_PLANES * 64;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    if (seg >= St) return;
     const float* sb = a.seg + (size_t)patch * S * stride + lane;      // this patch's segment planes, this lane
     const uint32_t n_lane = reinterpret_cast<const uint32_t*>(sb)[(size_t)seg * stride + LG_SEG_LAST * 64];
     uint32_t n_max = n_lane;
@@ -334,7 +361,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     if (n_max == 0) return;                                            // nothing blended in this segment
 
     const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
-    const uint2 sr = segment_range(a.ranges[tile], S, seg);
+    const uint2 sr = segment_range(tr, St, seg);
     const size_t N = (size_t)a.grid.W * a.grid.H;
 
     // per-pixel state of the back-to-front walk (R3/cr/backward.cu:590-615), restricted to this segment:
@@ -348,7 +375,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     float acc0 = 0.f, acc1 = 0.f, accd = 0.f, acco = 0.f;           // accum_rec[2], accum_red, accum_reo
     {
         float b0 = 0.f, b1 = 0.f, bd = 0.f;
-        for (int k = seg + 1; k < S; k++) {
+        for (int k = seg + 1; k < St; k++) {
             b0 += sb[(size_t)k * stride + LG_SEG_C0 * 64];
             b1 += sb[(size_t)k * stride + LG_SEG_C1 * 64];
             bd += sb[(size_t)k * stride + LG_SEG_D * 64];
@@ -460,8 +487,49 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
 }
 
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
-    const unsigned blocks = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile) * (unsigned)a.S;
+    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S);
     hipLaunchKernelGGL(k_render_backward, dim3(blocks), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU glue (lidargs_dist): per-pixel folds over the G range shells, one launch each instead of a dozen
+// elementwise framework ops on a 0.2 ms critical path.
+__global__ void __launch_bounds__(256) k_shell_transmittance(int G, int rank, int N, const float* __restrict__ all_T, float* __restrict__ T_in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float T = 1.f;
+    for (int g = 0; g < rank && g < G; g++) T *= all_T[(size_t)g * N + i];
+    T_in[i] = T;
+}
+
+// planes[g] = (C0, C1, D, T_end, T_hand) of shell g.  The walk stopped in the first shell whose hand-over value fell
+// below the reference's 1e-4 threshold; T_final is that shell's T_end (the last shell's if none stopped).
+__global__ void __launch_bounds__(256) k_shell_compose(int G, int rank, int N, const float* __restrict__ planes, const float* __restrict__ bg,
+                                                       float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_occ,
+                                                       float* __restrict__ T_final, float* __restrict__ behind) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float c0 = 0.f, c1 = 0.f, d = 0.f, b0 = 0.f, b1 = 0.f, bd = 0.f, Tf = 1.f;
+    bool stopped = false;
+    for (int g = 0; g < G; g++) {
+        const float* p = planes + (size_t)g * 5 * N + i;
+        const float pc0 = p[0], pc1 = p[(size_t)N], pd = p[2 * (size_t)N];
+        c0 += pc0; c1 += pc1; d += pd;
+        if (g > rank) { b0 += pc0; b1 += pc1; bd += pd; }
+        if (!stopped) { Tf = p[3 * (size_t)N]; stopped = p[4 * (size_t)N] < 0.0001f; }
+    }
+    const float g0 = bg ? bg[0] : 0.f, g1 = bg ? bg[1] : 0.f;
+    out_color[i] = c0 + Tf * g0; out_color[(size_t)N + i] = c1 + Tf * g1;
+    out_depth[i] = d; out_occ[i] = 1.f - Tf; T_final[i] = Tf;
+    behind[i] = b0; behind[(size_t)N + i] = b1; behind[2 * (size_t)N + i] = bd;
+}
+
+void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_transmittance, dim3((N + 255) / 256), dim3(256), 0, s, G, rank, N, all_T, T_in);
+}
+void launch_shell_compose(int G, int rank, int N, const float* planes, const float* bg, float* out_color, float* out_depth, float* out_occ,
+                          float* T_final, float* behind, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_compose, dim3((N + 255) / 256), dim3(256), 0, s, G, rank, N, planes, bg, out_color, out_depth, out_occ, T_final, behind);
 }
 
 }  // namespace lg

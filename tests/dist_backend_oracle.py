@@ -8,8 +8,42 @@ import torch
 from oracle import lgo
 
 
+ROW_KEYS = ("means3D", "colors", "opacities", "scales", "rotations")
+
+
 class OracleShellBackend:
+    def select(self, inp, lo, hi):
+        """Same float arithmetic as the oracle's own shell test (K1 view transform, left-to-right fp32, then sqrtf)."""
+        m = inp["means3D"].detach().cpu().numpy().astype(np.float32)
+        v = inp["viewmatrix"].detach().cpu().numpy().astype(np.float32).reshape(16)
+        x, y, z = m[:, 0], m[:, 1], m[:, 2]
+        px = ((v[0] * x + v[4] * y) + v[8] * z) + v[12]
+        py = ((v[1] * x + v[5] * y) + v[9] * z) + v[13]
+        pz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14]
+        dist = np.sqrt((px * px + py * py) + pz * pz, dtype=np.float32)
+        keep = (dist >= np.float32(lo)) & (dist < np.float32(hi))
+        idx = torch.from_numpy(np.nonzero(keep)[0].astype(np.int32))
+        sel = dict(inp)
+        for k in ROW_KEYS:
+            sel[k] = inp[k][idx.long()]
+        return idx, sel
+
+    def transmittance(self, allT, rank):
+        return torch.prod(allT[:rank], dim=0) if rank > 0 else torch.ones_like(allT[0])
+
+    def compose(self, planes, rank, bg, H, W):
+        G, N = planes.shape[0], H * W
+        img = planes[:, :3].sum(0)
+        stopped = planes[:, 4] < 1e-4
+        first = torch.where(stopped.any(0), stopped.float().argmax(0), torch.full((N,), G - 1))
+        T_final = planes[:, 3].gather(0, first.view(1, N)).view(N)
+        color = torch.stack([img[0] + T_final * bg[0], img[1] + T_final * bg[1]], 0).view(2, H, W)
+        behind = planes[rank + 1:, :3].sum(0) if rank + 1 < G else torch.zeros(3, N)
+        return color, img[2].view(1, H, W), (1.0 - T_final).view(1, H, W), T_final, behind.contiguous()
+
     def forward(self, inp, lo, hi):
+        if int(inp["means3D"].shape[0]) == 0:        # empty shell: nothing in the way
+            return dict(inp=inp, P=0, fwd=None, radii=torch.zeros(0, dtype=torch.int32), R=0), torch.ones(inp["H"] * inp["W"])
         n = lambda k: inp[k].detach().cpu().numpy()
         f = lgo.forward(n("means3D"), n("colors"), n("opacities"), n("scales"), n("rotations"), n("viewmatrix"), n("beams"),
                         inp["W"], inp["H"], bg=np.zeros(2, np.float32), scale_modifier=inp["scale_modifier"], far=inp["far"], near=inp["near"],
@@ -19,15 +53,16 @@ class OracleShellBackend:
 
     def render(self, st, T_in):
         f = st["fwd"]
-        if st["P"] == 0:
-            N = T_in.numel()
-            return torch.zeros(3, N), T_in.clone(), T_in.clone()
-        lgo.render_shell(f, T_in=T_in.numpy(), t_only=False, bg=None)
         N = T_in.numel()
-        part = np.concatenate([f.color.reshape(2, N), f.depth.reshape(1, N)], 0)
-        return torch.from_numpy(part.copy()), torch.from_numpy(f.array("final_T").copy()), torch.from_numpy(f.T_pass.copy())
+        if st["P"] == 0:
+            return torch.cat([torch.zeros(3, N), T_in.view(1, N), T_in.view(1, N)], 0)
+        lgo.render_shell(f, T_in=T_in.numpy(), t_only=False, bg=None)
+        planes = np.concatenate([f.color.reshape(2, N), f.depth.reshape(1, N), f.array("final_T").reshape(1, N), f.T_pass.reshape(1, N)], 0)
+        return torch.from_numpy(planes.astype(np.float32).copy())
 
     def backward(self, st, behind, T_final, grads):
+        if st["P"] == 0:
+            return {k: torch.zeros(0, w) for k, w in (("means3D", 3), ("means2D", 4), ("colors", 2), ("opacities", 1), ("scales", 3), ("rotations", 4))}
         f = st["fwd"]
         gc, gd, go = (g.detach().cpu().numpy() for g in grads)
         g = lgo.backward(f, gc, gd, go, behind=behind.numpy(), T_final_global=T_final.numpy(), bg=st["inp"]["bg"].numpy())

@@ -31,7 +31,7 @@ def _settings(scene, W, H):
                                          t(scene["beams"]), 80, 0, False)
 
 
-def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir):
+def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir, edges=None):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -40,7 +40,8 @@ def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir):
     from dist_backend_oracle import OracleShellBackend
     scene = sc.make_scene(kind, P, H, seed, random_view=True)
     scene["bg"] = np.array(bg, np.float32)
-    rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleShellBackend(), grad_sync=grad_sync)
+    rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleShellBackend(), grad_sync=grad_sync,
+                                        edges=None if edges is None else torch.tensor(edges, dtype=torch.float32))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
     leaves = {k: t(scene[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     m2 = torch.zeros(P, 4, requires_grad=True)
@@ -60,6 +61,9 @@ CASES = [
     ("w2_shell", 2, "shell", 4000, 16, 256, 31, (0.0, 0.0), "all_reduce"),
     ("w2_street_bg", 2, "street", 6000, 16, 256, 32, (0.3, 0.6), "reduce_scatter"),
     ("w3_dense", 3, "street", 9000, 16, 128, 33, (0.1, 0.2), "reduce_scatter"),   # saturating pixels: the T<1e-4 stop crosses shells
+    ("w2_dense_rs", 2, "shell", 3001, 16, 256, 34, (0.0, 0.1), "reduce_scatter_dense"),   # P not divisible by the world size
+    ("w3_odd_sparse", 3, "shell", 2999, 16, 256, 35, (0.2, 0.0), "reduce_scatter"),
+    ("w2_none", 2, "shell", 3000, 16, 256, 36, (0.0, 0.0), "none"),
 ]
 
 
@@ -84,6 +88,11 @@ def test_shell_sharding_matches_single_process(case, tmp_path):
         if grad_sync == "all_reduce":
             full = ranks[0][k]
             np.testing.assert_array_equal(ranks[1][k], full)
+        elif grad_sync == "none":
+            # every rank keeps its own shell's rows: supports are disjoint and their union is the full gradient
+            nz = [np.abs(ranks[r][k]).reshape(P, -1).max(1) > 0 for r in range(world)]
+            assert not (nz[0] & nz[1]).any()
+            full = sum(ranks[r][k] for r in range(world))
         else:
             full = np.zeros_like(ref[k])
             for r in range(world):
@@ -92,6 +101,28 @@ def test_shell_sharding_matches_single_process(case, tmp_path):
                 outside = np.ones(P, bool); outside[sl] = False
                 assert float(np.abs(ranks[r][k][outside]).max(initial=0.0)) == 0.0
         parity(k, full, ref[k])
+
+
+def test_empty_shells_are_harmless(tmp_path):
+    """Explicit edges that leave the first and the last of three shells empty."""
+    from util import GRAD_KEYS_SR, oracle_forward_backward, parity
+    world, kind, P, H, W, seed, bg = 3, "shell", 2000, 16, 256, 37, (0.1, 0.0)
+    edges = [float("-inf"), 1e-3, 1e6, float("inf")]
+    mp.spawn(_worker, args=(world, _free_port(), kind, P, H, W, seed, bg, "reduce_scatter", str(tmp_path), edges), nprocs=world, join=True)
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    scene["bg"] = np.array(bg, np.float32)
+    ref = oracle_forward_backward(scene, W, H, sc.upstream_grads(H, W, seed))
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    rows = (P + world - 1) // world
+    for r in range(world):
+        for k in ("color", "depth", "occ"):
+            parity(f"{k}@rank{r}", ranks[r][k], ref[k], verbose=False)
+    for k in GRAD_KEYS_SR:
+        full = np.zeros_like(ref[k])
+        for r in range(world):
+            sl = slice(r * rows, min(P, (r + 1) * rows))
+            full[sl] = ranks[r][k][sl]
+        parity(k, full, ref[k], verbose=False)
 
 
 def test_shell_edges_balance_and_cover():

@@ -44,6 +44,19 @@ class ThreadComm:
         t.copy_(torch.stack(self._exchange(t.clone()), 0).sum(0))
         return t
 
+    def all_reduce_async(self, t):
+        self.all_reduce(t)
+        return lambda: None
+
+    def all_to_all_rows(self, t, send_counts, recv_counts):
+        vals = self._exchange((t.contiguous().clone(), list(send_counts)))
+        parts = []
+        for src, (ts, sc) in enumerate(vals):
+            o = sum(sc[:self.rank])
+            parts.append(ts[o:o + sc[self.rank]])
+            assert sc[self.rank] == recv_counts[src]
+        return torch.cat(parts, 0)
+
     def reduce_scatter_rows(self, t):
         rows = t.shape[0] // self.world
         full = torch.stack(self._exchange(t.clone()), 0).sum(0)
@@ -71,22 +84,24 @@ def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results):
 
 
 CASES = [
-    ("w1", 1, "shell", 8000, 16, 512, 51, (0.0, 0.0)),
-    ("w2_bg", 2, "street", 20000, 16, 512, 52, (0.3, 0.6)),
-    ("w4_dense", 4, "street", 60000, 32, 800, 53, (0.2, 0.1)),
+    ("w1", 1, "shell", 8000, 16, 512, 51, (0.0, 0.0), "all_reduce"),
+    ("w2_bg", 2, "street", 20000, 16, 512, 52, (0.3, 0.6), "all_reduce"),
+    ("w4_dense", 4, "street", 60000, 32, 800, 53, (0.2, 0.1), "all_reduce"),
+    ("w4_sparse_exchange", 4, "street", 50001, 32, 800, 54, (0.0, 0.2), "reduce_scatter"),
+    ("w3_dense_exchange", 3, "shell", 20000, 16, 512, 55, (0.1, 0.0), "reduce_scatter_dense"),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_shell_path_on_hip_matches_oracle(case, hip_lib_built):
-    name, world, kind, P, H, W, seed, bg = case
+    name, world, kind, P, H, W, seed, bg, grad_sync = case
     scene = sc.make_scene(kind, P, H, seed, random_view=True)
     scene["bg"] = np.array(bg, np.float32)
     grads = sc.upstream_grads(H, W, seed)
     ref = oracle_forward_backward(scene, W, H, grads)
     shared = ThreadComm.Shared(world)
     results = [None] * world
-    threads = [threading.Thread(target=_run_rank, args=(shared, r, scene, W, H, grads, "all_reduce", results)) for r in range(world)]
+    threads = [threading.Thread(target=_run_rank, args=(shared, r, scene, W, H, grads, grad_sync, results)) for r in range(world)]
     for t in threads: t.start()
     for t in threads: t.join(timeout=120)
     assert not any(t.is_alive() for t in threads), "virtual ranks hung"
@@ -99,5 +114,15 @@ def test_shell_path_on_hip_matches_oracle(case, hip_lib_built):
         assert mism <= max(1, int(1e-4 * P))
         for k in ("color", "depth", "occ"):
             parity(f"{k}@r{r}", results[r][k], ref[k], verbose=(r == 0))
+    rows = (P + world - 1) // world
     for k in GRAD_KEYS_SR:
-        parity(k, results[0][k], ref[k])
+        if grad_sync == "all_reduce":
+            full = results[0][k]
+        else:       # rank r holds rows [r*rows, (r+1)*rows) and zeros elsewhere
+            full = np.zeros_like(ref[k])
+            for r in range(world):
+                sl = slice(r * rows, min(P, (r + 1) * rows))
+                full[sl] = results[r][k][sl]
+                outside = np.ones(P, bool); outside[sl] = False
+                assert float(np.abs(results[r][k][outside]).max(initial=0.0)) == 0.0
+        parity(k, full, ref[k])

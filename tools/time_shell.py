@@ -1,0 +1,119 @@
+"""Per-rank cost of the range-shell path at world N, measured on ONE GPU: the N virtual ranks first run as threads with an
+in-memory communicator that records every collective's result; then each rank is replayed alone (collectives return the
+recorded tensors instantly) and timed.  Gives compute + host glue per rank, i.e. the frame time at world N minus RCCL time.
+
+    python tools/time_shell.py [world] [cfg] [iters]
+"""
+import os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch
+import lidargs_dist
+import lidargs_scenes as sc
+from test_dist_gpu import ThreadComm
+from util import make_settings, to_torch
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+kind, P, H, W, seed = sc.BASELINE_CONFIGS[cfg]
+scene = sc.make_scene(kind, P, H, seed)
+st = to_torch(scene)
+gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, seed))
+settings = make_settings(st, W, H)
+import math
+tile_rad = (16 * 2 * math.pi / W, 4 * float(st["beams"][-1] - st["beams"][0]) / max(1, H - 1))
+edges = lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"] if os.environ.get("EDGES", "w") == "w" else None,
+                                 tile_rad=tile_rad)
+print("edges", [round(float(e), 2) for e in edges])
+
+
+class RecordComm(ThreadComm):
+    def __init__(self, shared, rank, log):
+        super().__init__(shared, rank); self.log = log
+
+    def _rec(self, name, out):
+        self.log.append((name, out.clone())); return out
+
+    def all_gather(self, t): return self._rec("all_gather", super().all_gather(t))
+    def all_reduce(self, t): return self._rec("all_reduce", super().all_reduce(t))
+    def all_reduce_async(self, t):
+        self.all_reduce(t); return lambda: None
+    def all_to_all_rows(self, t, s, r): return self._rec("all_to_all_rows", super().all_to_all_rows(t, s, r))
+    def reduce_scatter_rows(self, t): return self._rec("reduce_scatter_rows", super().reduce_scatter_rows(t))
+
+
+class ReplayComm:
+    def __init__(self, rank, world, log):
+        self.rank, self.world, self.log, self.i = rank, world, log, 0
+
+    def _next(self, name):
+        n, out = self.log[self.i % len(self.log)]; self.i += 1
+        assert n == name, (n, name)
+        return out
+
+    def all_gather(self, t): return self._next("all_gather")
+    def all_reduce(self, t): t.copy_(self._next("all_reduce")); return t
+    def all_reduce_async(self, t):
+        self.all_reduce(t); return lambda: None
+    def all_to_all_rows(self, t, s, r): return self._next("all_to_all_rows")
+    def reduce_scatter_rows(self, t): return self._next("reduce_scatter_rows")
+    def broadcast(self, t, src=0): return t
+
+
+def frame(mod):
+    outs, saved = lidargs_dist.shell_forward(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
+    return lidargs_dist.shell_backward(mod, saved, gc, gd, go)
+
+
+logs = [[] for _ in range(world)]
+shared = ThreadComm.Shared(world)
+errs = []
+
+
+def record(r):
+    try:
+        torch.cuda.set_device(0)
+        frame(lidargs_dist.ShellRasterizer(settings, RecordComm(shared, r, logs[r]), edges=edges))
+    except Exception as e:
+        errs.append(e); shared.barrier.abort()
+
+
+th = [threading.Thread(target=record, args=(r,)) for r in range(world)]
+for t in th: t.start()
+for t in th: t.join(timeout=300)
+assert not errs, errs
+torch.cuda.synchronize()
+times = []
+for r in range(world):
+    mod = lidargs_dist.ShellRasterizer(settings, ReplayComm(r, world, logs[r]), edges=edges)
+    for _ in range(3):
+        frame(mod)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        frame(mod)
+    torch.cuda.synchronize()
+    times.append(1e3 * (time.perf_counter() - t0) / iters)
+    if r in (0, world - 1):
+        from diff_lidargs_rasterization import _C
+        _C.profile_enable(True)
+        for _ in range(iters):
+            frame(mod)
+        torch.cuda.synchronize()
+        _C.profile_enable(False)
+        sm = _C.profile_summary()
+        print(f"  rank {r} stage ms: " + " ".join(f"{k}={v[0]:.3f}" for k, v in sm.items()) + f"  sum={sum(v[0] for v in sm.values()):.3f}  counters={_C.last_counters()}")
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            frame(mod)
+        t_host = 1e3 * (time.perf_counter() - t0) / iters
+        torch.cuda.synchronize()
+        print(f"  rank {r} host-side issue time per frame: {t_host:.3f} ms")
+    del mod
+print(f"world {world} {cfg}: per-rank ms (no RCCL time): " + " ".join(f"{t:.3f}" for t in times) + f"  max {max(times):.3f}")
+coll = {}
+for n, t in logs[0]:
+    coll.setdefault(n, []).append(t.numel() * t.element_size())
+print("collectives per frame (bytes of the result on a rank):", {k: v for k, v in coll.items()})
