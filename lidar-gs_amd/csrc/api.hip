@@ -83,6 +83,54 @@ int segment_length() {
     return v;
 }
 
+// Depth of the pass-1 rounds, in segments: e.g. LIDARGS_ROUNDS="3,9" walks segments [0,3), then [3,9) of the patches still
+// open, then the rest of those still open after that.
+int pass1_rounds(int* out, int cap) {
+    static int cached[8], n_cached = -1;
+    if (n_cached < 0) {
+        const char* e = getenv("LIDARGS_ROUNDS");
+        if (!e) e = "3";        // one gated round measured best (0.36 -> 0.18 ms on the 2 M street scene); more rounds add launch tails
+        int n = 0, prev = 0;
+        while (*e && n < 8) {
+            const int v = atoi(e);
+            if (v > prev && v < 255) { cached[n++] = v; prev = v; }
+            while (*e && *e != ',') e++;
+            if (*e == ',') e++;
+        }
+        n_cached = n;
+    }
+    int n = 0;
+    for (int i = 0; i < n_cached && n < cap; i++) out[n++] = cached[i];
+    return n;
+}
+bool pass1_gated(int S) {
+    int r[8];
+    const int n = pass1_rounds(r, 8);
+    return n > 0 && r[0] < S;
+}
+
+// Pass 1 in rounds of growing depth: the first segments of every list, then -- only for the patches some pixel of which is
+// still unsaturated -- the next ones, and so on.  In a street scene most patches saturate within a few hundred entries,
+// and pass 1 (which restarts from T = 1 in every segment) would otherwise walk every entry behind that point for nothing.
+// Leaves `ra` covering all segments with the gate armed, which is what pass 2 and the combine expect.
+void run_pass1_rounds(lg::RenderFwdArgs& ra, uint8_t* alive, hipStream_t stream) {
+    const int S = ra.S;
+    int r[8];
+    const int n = pass1_rounds(r, 8);
+    ra.alive = nullptr; ra.front = 0;
+    int lo = 0;
+    for (int i = 0; i < n && r[i] < S; i++) {
+        ra.seg_lo = lo; ra.seg_hi = r[i];
+        lg::launch_render_pass1(ra, stream);       // gated on the limits the previous rounds left (none in the first)
+        ra.alive = alive; ra.front = r[i];
+        lg::launch_render_alive(ra, stream);
+        lo = r[i];
+    }
+    ra.seg_lo = lo; ra.seg_hi = S;
+    lg::launch_render_pass1(ra, stream);
+    ra.seg_lo = 0; ra.seg_hi = S;
+}
+
 int ceil_log2(uint32_t n) {
     int b = 0;
     while ((1u << b) < n && b < 31) b++;
@@ -230,11 +278,13 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = R;
     ra.transmittance_only = transmittance_pass;
+    ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
     if (ra.run_pass1) {
-        lg::launch_render_pass1(ra, stream);
+        run_pass1_rounds(ra, bin.alive, stream);
         LG_STAGE_CHECK("render pass 1");
         g_prof.mark("render_pass1", stream);
     }
+    ra.seg_lo = 0; ra.seg_hi = S;
     if (!transmittance_pass) {
         lg::launch_render_pass2(ra, stream);
         LG_STAGE_CHECK("render pass 2");
@@ -286,6 +336,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
     rb.seg = bin.seg; rb.S = S; rb.seg_len = segment_length();
+    rb.alive = pass1_gated(S) ? bin.alive : nullptr;
     rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = (size_t)R;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
@@ -420,11 +471,13 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
     ra.seg = bin.seg; ra.S = S; ra.seg_len = segment_length();
+    ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0;
+    ra.alive = pass1_gated(S) ? bin.alive : nullptr;              // written, like the flags, by the shell's phase 1
     ra.flags = bin.flags; ra.R = (size_t)R;      // written by the shell's phase 1 (lidargs_forward_shell)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
-    if (ra.run_pass1) lg::launch_render_pass1(ra, stream);
+    if (ra.run_pass1) run_pass1_rounds(ra, bin.alive, stream);
     if (!transmittance_pass) lg::launch_render_pass2(ra, stream);
     lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render shell");

@@ -113,6 +113,7 @@ struct BinView {
     size_t scratch_words;
     float* seg;                          // [patches][S][LG_SEG_PLANES][64]
     uint8_t* flags;                      // [waves_per_tile][R]: pass 1 saw >= 1 pixel of the patch take this entry
+    uint8_t* alive;                      // [patches]: number of list segments pass 1 walked (255 = all)
 };
 
 // List segments: the launch provides `max_segments` workgroups per patch; each tile uses ceil(len / seg_len) of them
@@ -135,6 +136,7 @@ inline size_t bin_carve(char* base, size_t R, size_t patches, int waves_per_tile
     b.scratch = c.take<uint32_t>(b.scratch_words);
     b.seg = c.take<float>(patches * (size_t)S * LG_SEG_PLANES * 64);
     b.flags = c.take<uint8_t>((size_t)waves_per_tile * n + 64);
+    b.alive = c.take<uint8_t>(patches + 64);
     if (v) *v = b;
     return (size_t)(c.p - base) + 128;
 }
@@ -232,11 +234,15 @@ struct RenderFwdArgs {
     float* seg; int S;        // per-(patch, segment) planes, segment slots per list
     int seg_len;              // target entries per segment (a tile uses min(S, ceil(len / seg_len)) segments)
     uint8_t* flags; size_t R; // per-(sub, entry) contribution flags written by pass 1 (nullptr when pass 1 never runs)
+    int seg_lo, seg_hi;       // segment slots [seg_lo, seg_hi) this launch covers
+    int front;                // launch_render_alive: the segment the finished round ends at
+    uint8_t* alive;           // [patches] (nullptr = no gating): number of segments pass 1 walked (255 = all of them)
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
 };
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s);     // T-only walk of every segment
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s);     // full walk from the true T_in
+void launch_render_alive(const RenderFwdArgs& a, hipStream_t s);     // which patches are still unsaturated behind the front segments
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s);   // fold the segments into the image planes
 
 struct RenderBwdArgs {
@@ -247,6 +253,7 @@ struct RenderBwdArgs {
     const float* final_T;
     const float* seg; int S; int seg_len;
     const uint8_t* flags; size_t R;
+    const uint8_t* alive;              // as in RenderFwdArgs: segments >= alive[patch] were never walked
     const float* T_final_global;   // nullptr = final_T (single GPU)
     const float* behind;           // nullptr or f32[3*N]: colour0, colour1, depth sums of farther shells
     const float* dL_dpix; const float* dL_ddepth; const float* dL_docc;

@@ -118,11 +118,13 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
     int patch, seg;                                                    // patch = tile * waves_per_tile + sub
-    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, S, patch, seg)) return;
+    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, a.seg_hi - a.seg_lo, patch, seg)) return;
+    seg += a.seg_lo;
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const uint2 tr = a.ranges[tile];
     const int St = segment_count(tr, S, a.seg_len);
     if (seg >= St) return;
+    if (a.alive && seg >= (int)a.alive[patch]) return;                  // every pixel saturated before this segment (never walked)
     const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
     const uint2 sr = segment_range(tr, St, seg);
     const uint32_t n = sr.y - sr.x;
@@ -228,6 +230,31 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     }
 }
 
+// Pass 1 runs in rounds of growing depth; after the round that ends at segment `front`, a patch stays open (limit 255) if
+// some pixel's transmittance through those segments (product of the T-only walks, i.e. the hand-over value of a walk from
+// T = 1) is still >= 1e-4 and its list goes on; otherwise its limit becomes `front` and nothing behind is ever walked.
+// Pass 1 starts from T = 1 >= the true transmittance, so what is closed here is closed for pass 2 and the backward too.
+__global__ void __launch_bounds__(64) k_render_alive(const RenderFwdArgs a) {
+    const int lane = threadIdx.x;
+    const int S = a.S;
+    const int patch = blockIdx.x;
+    if (a.seg_lo > 0 && a.alive[patch] != 255) return;                 // closed by an earlier round
+    const int wpt = a.grid.waves_per_tile;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const TileGrid& g = a.grid;
+    const int x = (tile % g.tiles_x) * LG_TILE_W + (lane & 15);
+    const int y = (tile / g.tiles_x) * g.TH + sub * LG_WAVE_ROWS + (lane >> 4);
+    const bool inside = x < g.W && y < g.H;
+    const int St = segment_count(a.ranges[tile], S, a.seg_len);
+    const float* sb = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + lane;
+    const size_t stride = LG_SEG_PLANES * 64;
+    float T = 1.f;
+    const int kf = min(a.front, St);
+    for (int k = 0; k < kf && T >= 0.0001f; k++) T *= sb[k * stride + LG_SEG_TPASS * 64];
+    const unsigned long long open = __ballot(inside && T >= 0.0001f);
+    if (lane == 0) a.alive[patch] = (St > a.front && open != 0ull) ? 255 : (uint8_t)min(a.front, 254);
+}
+
 // Per patch: fold the segments (pass 2 results, or pass 1 products when t_only) into the image planes.
 __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     const int lane = threadIdx.x;
@@ -242,12 +269,15 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     const int pix = y * g.W + x;
     const float* sb = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + lane;
     const size_t stride = LG_SEG_PLANES * 64;
-    const int St = segment_count(a.ranges[tile], S, a.seg_len);
+    int St = segment_count(a.ranges[tile], S, a.seg_len);
+    if (a.alive) St = min(St, (int)a.alive[patch]);                    // the planes behind a patch's limit were never written
 
     if (a.transmittance_only) {
         // hand-over value of the whole list: product of the segments' (a tripped segment makes it < 1e-4)
         float T = 1.f;
-        for (int k = 0; k < St; k++) T *= sb[k * stride + LG_SEG_TPASS * 64];
+        // stop at the first product below the threshold: the planes behind it may never have been written (dead patch),
+        // and every consumer of T_pass only asks whether it is < 1e-4
+        for (int k = 0; k < St && T >= 0.0001f; k++) T *= sb[k * stride + LG_SEG_TPASS * 64];
         if (a.T_pass) a.T_pass[pix] = T;
         return;
     }
@@ -273,12 +303,16 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     a.out_occ[pix] = 1.f - T_final;
 }
 
+void launch_render_alive(const RenderFwdArgs& a, hipStream_t s) {
+    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    hipLaunchKernelGGL(k_render_alive, dim3(patches), dim3(64), 0, s, a);
+}
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S);
+    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo);
     hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
 }
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S);
+    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo);
     hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
 }
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
@@ -353,6 +387,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     const uint2 tr = a.ranges[tile];
     const int St = segment_count(tr, S, a.seg_len);
     if (seg >= St) return;
+    if (a.alive && seg >= (int)a.alive[patch]) return;                  // never walked by the forward: nothing blended there
     const float* sb = a.seg + (size_t)patch * S * stride + lane;      // this patch's segment planes, this lane
     const uint32_t n_lane = reinterpret_cast<const uint32_t*>(sb)[(size_t)seg * stride + LG_SEG_LAST * 64];
     uint32_t n_max = n_lane;
@@ -375,7 +410,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     float acc0 = 0.f, acc1 = 0.f, accd = 0.f, acco = 0.f;           // accum_rec[2], accum_red, accum_reo
     {
         float b0 = 0.f, b1 = 0.f, bd = 0.f;
-        for (int k = seg + 1; k < St; k++) {
+        const int Send = a.alive ? min(St, (int)a.alive[patch]) : St;  // nothing was walked behind the patch's limit
+        for (int k = seg + 1; k < Send; k++) {
             b0 += sb[(size_t)k * stride + LG_SEG_C0 * 64];
             b1 += sb[(size_t)k * stride + LG_SEG_C1 * 64];
             bd += sb[(size_t)k * stride + LG_SEG_D * 64];
