@@ -463,11 +463,17 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
             const float A = r1.w, B = r2.w, Cc = r3.x, op = r3.y;
             const float power = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
             const float G = __expf(fminf(power, 0.f));
-            const float alpha = fminf(0.99f, op * G);
+            const float alpha_raw = fminf(0.99f, op * G);
             // :650 skip entries behind the last contributor; :673-679 the forward's skips
-            const bool contrib = rows && (e < n_lane) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+            const bool contrib = rows && (e < n_lane) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
             if (__ballot(contrib) != 0ull) {                           // wave-uniform
-                const float Tn = T / (1.f - alpha);                    // :681
+                // A pixel that does not blend this entry treats it as an alpha = 0 entry: T / (1 - 0) = T, the "colour
+                // behind" recurrences commit the previous entry (the same operation, just earlier) and then carry
+                // (alpha 0, this colour), which the next step folds away exactly (0 * c + 1 * acc) -- bit-identical to
+                // skipping it, and no per-pixel select on any of the nine state registers or the sixteen sums.
+                const float alpha = contrib ? alpha_raw : 0.f;
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; (1 - alpha) >= 0.01
+                const float Tn = T * inv;                              // :681
                 const float w = alpha * Tn;
                 const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
                 const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
@@ -475,7 +481,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 const float ao = last_alpha + (1.f - last_alpha) * acco;
                 float dL_dalpha = (r3.z - a0) * g0 + (r3.w - a1) * g1 + (r0.w - ad) * gd + (1.f - ao) * go;
                 dL_dalpha *= Tn;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;       // :727
+                dL_dalpha -= T_final * inv * bgdot;                    // :727
+                dL_dalpha = contrib ? dL_dalpha : 0.f;                 // every sum below carries dL_dalpha or w as a factor
                 const float dL_dG = op * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 const float gx = dL_dG * (-gdx * A - gdy * B);         // dL/dmean2D.x  (:734,:753)
@@ -503,13 +510,10 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 v[13] = gy * (ex * iu2 + t2 * r2.x);
                 v[14] = gy * (ey * iu2 + t2 * r2.y);
                 v[15] = gy * (ez * iu2 + t2 * r2.z);
-#pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = contrib ? v[k] : 0.f;
-                // commit the per-pixel recurrences only where this pixel really blended the entry
-                T = contrib ? Tn : T;
-                acc0 = contrib ? a0 : acc0; acc1 = contrib ? a1 : acc1; accd = contrib ? ad : accd; acco = contrib ? ao : acco;
-                lc0 = contrib ? r3.z : lc0; lc1 = contrib ? r3.w : lc1; ld = contrib ? r0.w : ld;
-                last_alpha = contrib ? alpha : last_alpha;
+                T = Tn;
+                acc0 = a0; acc1 = a1; accd = ad; acco = ao;
+                lc0 = r3.z; lc1 = r3.w; ld = r0.w;
+                last_alpha = alpha;
                 const float mine = reduce_scatter16(v, lane);
                 if (lane < 16) {
                     const int slot = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);

@@ -29,9 +29,9 @@ class ThreadComm:
     def _exchange(self, t):
         torch.cuda.synchronize()
         self.sh.slots[self.rank] = t
-        self.sh.barrier.wait(timeout=60)
+        self.sh.barrier.wait(timeout=240)
         vals = list(self.sh.slots)
-        self.sh.barrier.wait(timeout=60)
+        self.sh.barrier.wait(timeout=240)
         return vals
 
     def all_gather(self, t):
@@ -103,7 +103,7 @@ def test_shell_path_on_hip_matches_oracle(case, hip_lib_built):
     results = [None] * world
     threads = [threading.Thread(target=_run_rank, args=(shared, r, scene, W, H, grads, grad_sync, results)) for r in range(world)]
     for t in threads: t.start()
-    for t in threads: t.join(timeout=120)
+    for t in threads: t.join(timeout=480)
     assert not any(t.is_alive() for t in threads), "virtual ranks hung"
     for r in results:
         if isinstance(r, Exception):
