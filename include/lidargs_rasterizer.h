@@ -99,7 +99,10 @@ int lidargs_forward(
  * Gaussians with radii <= 0), so they may be passed uninitialised:
  * dL_dmean2D f32[4P], dL_dconic f32[4P], dL_dopacity f32[P], dL_dcolor f32[2P],
  * dL_ddepths f32[P], dL_dmean3D f32[3P], dL_dsphere_means3D f32[3P], dL_dbasis_u1 f32[3P],
- * dL_dbasis_u2 f32[3P], dL_dcov3D f32[6P], dL_dsh (untouched), dL_dscale f32[3P], dL_drot f32[4P]. */
+ * dL_dbasis_u2 f32[3P], dL_dcov3D f32[6P], dL_dsh (untouched), dL_dscale f32[3P], dL_drot f32[4P].
+ * dL_dconic, dL_ddepths, dL_dsphere_means3D, dL_dbasis_u1 and dL_dbasis_u2 are scratch of the reference's two-kernel
+ * backward that its binding never returns (R3/rasterize_points.cu:219); each of them may be NULL, in which case it is
+ * not materialised (56 of 148 bytes per Gaussian less to write). */
 int lidargs_backward(
     int P, int D, int M, int R,
     const float* background,

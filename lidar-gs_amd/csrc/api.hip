@@ -315,9 +315,9 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: bad sizes%s");
     if (P == 0) return 0;   // R3/rasterize_points.cu:177
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "backward: missing forward buffers%s");
-    if (!means3D || !viewmatrix || !radii || !dL_dpix || !dL_dout_depth || !dL_dout_occ || !dL_dmean2D || !dL_dconic ||
-        !dL_dopacity || !dL_dcolor || !dL_ddepths || !dL_dmean3D || !dL_dsphere_means3D || !dL_dbasis_u1 || !dL_dbasis_u2 ||
-        !dL_dcov3D || !dL_dscale || !dL_drot)
+    // dL_dconic, dL_ddepths, dL_dsphere_means3D, dL_dbasis_u1/u2 are the reference's scratch gradients: optional here
+    if (!means3D || !viewmatrix || !radii || !dL_dpix || !dL_dout_depth || !dL_dout_occ || !dL_dmean2D ||
+        !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: NULL required pointer%s");
 
     const int TH = tile_rows();

@@ -326,14 +326,16 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float dist = sqrtf(n2);
     if (!(a.radii[idx] > 0) || dist <= 0.f) {                         // R3/cr/backward.cu:479, :488: no gradient at all
         // every output row is written, so the caller need not pre-zero them (the reference relies on torch::zeros)
-        for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_dconic[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; }
+        for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; if (a.dL_dconic) a.dL_dconic[4 * idx + k] = 0.f; }
         for (int k = 0; k < 3; k++) {
-            a.dL_dmean3D[3 * idx + k] = 0.f; a.dL_dsphere[3 * idx + k] = 0.f; a.dL_dbasis_u1[3 * idx + k] = 0.f;
-            a.dL_dbasis_u2[3 * idx + k] = 0.f; a.dL_dscale[3 * idx + k] = 0.f;
+            a.dL_dmean3D[3 * idx + k] = 0.f; a.dL_dscale[3 * idx + k] = 0.f;
+            if (a.dL_dsphere) a.dL_dsphere[3 * idx + k] = 0.f;
+            if (a.dL_dbasis_u1) a.dL_dbasis_u1[3 * idx + k] = 0.f;
+            if (a.dL_dbasis_u2) a.dL_dbasis_u2[3 * idx + k] = 0.f;
         }
         for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0.f;
         a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f;
-        a.dL_dopacity[idx] = 0.f; a.dL_ddepths[idx] = 0.f;
+        a.dL_dopacity[idx] = 0.f; if (a.dL_ddepths) a.dL_ddepths[idx] = 0.f;
         return;
     }
     const float3 dir = f3(d.x / dist, d.y / dist, d.z / dist);
@@ -367,12 +369,13 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float gdep = q2.y;
     const float3 du1 = f3(q2.z, q2.w, q3.x), du2 = f3(q3.y, q3.z, q3.w);
     a.dL_dmean2D[4 * idx] = gx; a.dL_dmean2D[4 * idx + 1] = gy; a.dL_dmean2D[4 * idx + 2] = q0.z; a.dL_dmean2D[4 * idx + 3] = 0.f;
-    a.dL_dconic[4 * idx] = gA; a.dL_dconic[4 * idx + 1] = gB; a.dL_dconic[4 * idx + 2] = 0.f; a.dL_dconic[4 * idx + 3] = gC;
+    // the reference's scratch gradients (conic, depth, sphere, basis) are materialised only if the caller wants them
+    if (a.dL_dconic) { a.dL_dconic[4 * idx] = gA; a.dL_dconic[4 * idx + 1] = gB; a.dL_dconic[4 * idx + 2] = 0.f; a.dL_dconic[4 * idx + 3] = gC; }
     a.dL_dopacity[idx] = q1.z;
     a.dL_dcolor[2 * idx] = q1.w; a.dL_dcolor[2 * idx + 1] = q2.x;
-    a.dL_ddepths[idx] = gdep;
-    a.dL_dbasis_u1[3 * idx] = du1.x; a.dL_dbasis_u1[3 * idx + 1] = du1.y; a.dL_dbasis_u1[3 * idx + 2] = du1.z;
-    a.dL_dbasis_u2[3 * idx] = du2.x; a.dL_dbasis_u2[3 * idx + 1] = du2.y; a.dL_dbasis_u2[3 * idx + 2] = du2.z;
+    if (a.dL_ddepths) a.dL_ddepths[idx] = gdep;
+    if (a.dL_dbasis_u1) { a.dL_dbasis_u1[3 * idx] = du1.x; a.dL_dbasis_u1[3 * idx + 1] = du1.y; a.dL_dbasis_u1[3 * idx + 2] = du1.z; }
+    if (a.dL_dbasis_u2) { a.dL_dbasis_u2[3 * idx] = du2.x; a.dL_dbasis_u2[3 * idx + 1] = du2.y; a.dL_dbasis_u2[3 * idx + 2] = du2.z; }
 
     // conic -> covariance, with the reference's 1/(denom^2 + 1e-7) damping (R3/cr/backward.cu:237)
     const float denom = __fsub_rn(__fmul_rn(ca, cc), __fmul_rn(cb, cb));
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
     const float i1 = uu1 > 0.f ? 1.f / uu1 : 0.f, i2 = uu2 > 0.f ? 1.f / uu2 : 0.f;
     const float3 gs = add3(scale3(u1, gx * i1), scale3(u2, gy * i2));
-    a.dL_dsphere[3 * idx] = gs.x; a.dL_dsphere[3 * idx + 1] = gs.y; a.dL_dsphere[3 * idx + 2] = gs.z;
+    if (a.dL_dsphere) { a.dL_dsphere[3 * idx] = gs.x; a.dL_dsphere[3 * idx + 1] = gs.y; a.dL_dsphere[3 * idx + 2] = gs.z; }
     const float id3 = 1.0f / sqrtf(n2 * n2 * n2);
     const float dgs = dot3(d, gs);
     float3 v;

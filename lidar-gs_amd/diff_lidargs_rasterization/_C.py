@@ -176,15 +176,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 and sh.ndim > 1 else 0
-    # the reference makes 13 torch::zeros tensors (:163-175); here one slab, sliced.  It is NOT pre-zeroed: the native
-    # backward writes every row of every output (zeros for culled Gaussians), which saves a 148 B x P memset per frame
-    widths = (3, 4, NUM_CHANNELS, 1, 4, 1, 6, 3, 4, 3, 3, 3)
+    # the reference makes 13 torch::zeros tensors (:163-175), five of which are scratch it never returns.  Here: one slab for
+    # the returned ones, NOT pre-zeroed (the native backward writes every row of every output, zeros for culled
+    # Gaussians), and NULL for the scratch ones, which the library then does not materialise.
+    widths = (3, 4, NUM_CHANNELS, 1, 6, 3, 4)
     slab = torch.empty(P * sum(widths), dtype=torch.float32, device=dev)
     parts, o = [], 0
     for w in widths:
         parts.append(slab[o:o + P * w].view(P, w)); o += P * w
-    (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths, dL_dconic, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations,
-     dL_dsphere, dL_du1, dL_du2) = parts
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations = parts
+    dL_ddepths = dL_dconic = dL_dsphere = dL_du1 = dL_du2 = None
     dL_dsh = torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
     if P != 0:
         bg, m3, col = _f32(background, "background"), _f32(means3D, "means3D"), _f32(colors, "colors")

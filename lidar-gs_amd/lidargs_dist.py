@@ -270,12 +270,13 @@ class HipShellBackend:
         inp = st["inp"]
         P, H, W = st["P"], inp["H"], inp["W"]
         dev = behind.device
-        widths = (3, 4, 2, 1, 3, 4, 4, 1, 6, 3, 3, 3)              # the six returned gradients first: they form one [.., 17]-wide block
+        widths = (3, 4, 2, 1, 3, 4, 6)                             # the six returned gradients + dL/dcov3D
         slab = torch.empty(P * sum(widths), dtype=torch.float32, device=dev)      # the library writes every row
         parts, o = [], 0
         for w in widths:
             parts.append(slab[o:o + P * w].view(P, w)); o += P * w
-        (g_m3, g_m2, g_col, g_op, g_sc, g_rot, g_con, g_dep, g_cov, g_sph, g_u1, g_u2) = parts
+        (g_m3, g_m2, g_col, g_op, g_sc, g_rot, g_cov) = parts
+        g_con = g_dep = g_sph = g_u1 = g_u2 = None                 # the reference's scratch gradients: not materialised
         if P:
             p = _C._ptr
             gc, gd, go = (g.contiguous() for g in grads)
