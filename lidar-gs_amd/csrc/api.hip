@@ -144,6 +144,9 @@ int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 int api_check_launch(hipStream_t s, int debug, const char* what) { return check_launch(s, debug, what); }
 int api_tile_rows() { return tile_rows(); }
 int api_ceil_log2(uint32_t n) { return ceil_log2(n); }
+int api_max_segments() { return max_segments(); }
+int api_segment_length() { return segment_length(); }
+int api_pass1_rounds(int* out, int cap) { return pass1_rounds(out, cap); }
 }  // namespace lg
 
 namespace {

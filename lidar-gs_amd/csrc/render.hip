@@ -79,35 +79,6 @@ __device__ __forceinline__ Staged gather_entry(const uint32_t* __restrict__ poin
     return s;
 }
 
-// blockIdx -> (patch, segment): segment-fastest, with S ODD.  Workgroups are dealt round-robin to the 8 XCDs (b % 8) and
-// the work of a frame is front-loaded (pass 2 and the backward retire the segments behind the T < 1e-4 stop at once), so
-// with S a multiple of 8 every first segment lands on the same XCD (measured: backward blend 0.30 -> 2.56 ms at S = 32).
-// With S odd the segment index is decorrelated from b % 8.  Dealing spatial groups of patches to XCDs instead (for L2
-// reuse between neighbouring tiles) measured slower on pass 1 (0.39 vs 0.36 ms), so the plain numbering stays.
-__device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int S, int& patch, int& seg) {
-    seg = (int)(b % (unsigned)S);
-    patch = (int)(b / (unsigned)S);
-    return patch < patches;
-}
-__host__ inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * (unsigned)S; }
-
-// Segments of a tile list: ceil(L / seg_len) of them, at most S (the launch provides S workgroups per patch; the
-// surplus ones retire at once and never touch the segment planes).  A pure function of the tile's range, so every
-// kernel of a frame (and the backward) recomputes the same split.
-__device__ __forceinline__ int segment_count(uint2 range, int S, int seg_len) {
-    const uint32_t L = range.y - range.x;
-    const uint32_t want = (L + (uint32_t)seg_len - 1u) / (uint32_t)seg_len;
-    return (int)min((uint32_t)S, max(1u, want));
-}
-// [start, end) of segment `seg` (< segment_count) of a tile list
-__device__ __forceinline__ uint2 segment_range(uint2 range, int St, int seg) {
-    const uint32_t L = range.y - range.x;
-    const uint32_t len = (L + (uint32_t)St - 1u) / (uint32_t)St;
-    const uint32_t a = min(range.y, range.x + (uint32_t)seg * len);
-    const uint32_t b = min(range.y, a + len);
-    return make_uint2(a, b);
-}
-
 // ------------------------------------------------------------------------------------------------
 // One workgroup = (patch, segment).  T_ONLY: pass 1.  Otherwise pass 2.
 template <bool T_ONLY>

@@ -233,38 +233,74 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
     return o;
 }
 
+// Per-(patch, segment) planes of the surfel blend (each 64 floats).  Lists are cut into segments exactly as in the 3-D
+// variant (render.hip): pass 1 walks every segment from T = 1 for its transmittance product and the contribution flags,
+// pass 2 walks the flagged entries from the true T_in, the combine folds the segments in order.
+enum { SF_SEG_TPASS = 0, SF_SEG_C0, SF_SEG_C1, SF_SEG_D, SF_SEG_N0, SF_SEG_N1, SF_SEG_N2, SF_SEG_M1, SF_SEG_M2, SF_SEG_DIST,
+       SF_SEG_TEND, SF_SEG_TBREAK, SF_SEG_LAST, SF_SEG_MEDC, SF_SEG_MED, SF_SEG_PLANES = 16 };
+
 struct SfFwdArgs {
     TileGrid grid;
     const uint2* ranges; const uint32_t* point_list; const float4* rec; const uint32_t* rowspan;
     const float2* coltab; const float2* rowtab; const float* bg;
     float* accum;          // [3N] final_T, M1, M2
-    uint32_t* n_contrib;   // [2N] last contributor, median contributor
+    uint32_t* n_contrib;   // [2N] last contributor, median contributor (1-based positions in the tile list)
     float* out_color; float* out_others;
+    float* seg; int S; int seg_len;     // [patches][S][SF_SEG_PLANES][64]
+    uint8_t* flags; size_t R;           // [waves_per_tile][R]
+    uint8_t* alive;                     // [patches] segments pass 1 walked (255 = all); nullptr = no gating
+    int seg_lo, seg_hi, front;
 };
 
+// One workgroup = (patch, segment).  T_ONLY: pass 1 (transmittance product + flags).  Otherwise pass 2 (all sums).
+template <bool T_ONLY>
 __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
     __shared__ float4 s_rec[5 * SF_CHUNK];
     __shared__ uint32_t s_span[SF_CHUNK];
     const int lane = threadIdx.x;
-    const int patch = blockIdx.x;
+    const int S = a.S;
+    const int wpt = a.grid.waves_per_tile;
+    int patch, seg;
+    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, a.seg_hi - a.seg_lo, patch, seg)) return;
+    seg += a.seg_lo;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    if (seg >= St) return;
+    if (a.alive && seg >= (int)a.alive[patch]) return;
     const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
-    const uint2 range = a.ranges[patch / a.grid.waves_per_tile];
-    const uint32_t n = range.y - range.x;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    const uint2 sr = segment_range(tr, St, seg);
+    const uint32_t n = sr.y - sr.x;
+    float* segbase = a.seg + ((size_t)patch * S + seg) * (SF_SEG_PLANES * 64);
+
+    float T = 1.f;
+    if (!T_ONLY) {
+        const float* tp = a.seg + (size_t)patch * S * (SF_SEG_PLANES * 64) + SF_SEG_TPASS * 64 + lane;
+        for (int k = 0; k < seg; k++) T *= tp[(size_t)k * (SF_SEG_PLANES * 64)];
+    }
+    float T_break = T;
+    float C0 = 0.f, C1 = 0.f, D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     uint32_t last = 0, med_c = 0;
-    bool done = !px.inside;
+    bool done = !px.inside || (!T_ONLY && T < 0.0001f);
+    uint8_t* fl = a.flags + (size_t)sub * a.R + sr.x;
     const uint32_t nchunks = (n + SF_CHUNK - 1) / SF_CHUNK;
-    if (n > 0) {
-        SfStaged st = sf_gather(a.point_list, a.rec, a.rowspan, range.x + lane, (uint32_t)lane < n);
+    uint32_t c_done = 0;
+    if (__ballot(!done) != 0ull && n > 0) {
+        auto entry_valid = [&](uint32_t k) { return k < n && (T_ONLY || fl[k] != 0); };
+        bool have = entry_valid(lane);
+        SfStaged st = sf_gather(a.point_list, a.rec, a.rowspan, sr.x + lane, have);
         for (uint32_t c = 0; c < nchunks; c++) {
             __syncthreads();
             s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
             s_rec[4 * SF_CHUNK + lane] = st.a4; s_span[lane] = st.span;
+            unsigned long long todo = __ballot(have);
             __syncthreads();
-            if (c + 1 < nchunks) { const uint32_t k = (c + 1) * SF_CHUNK + lane; st = sf_gather(a.point_list, a.rec, a.rowspan, range.x + k, k < n); }
+            if (c + 1 < nchunks) { const uint32_t k = (c + 1) * SF_CHUNK + lane; have = entry_valid(k); st = sf_gather(a.point_list, a.rec, a.rowspan, sr.x + k, have); }
             if (__ballot(!done) == 0ull) break;
-            const uint32_t cnt = min((uint32_t)SF_CHUNK, n - c * SF_CHUNK);
-            for (uint32_t j = 0; j < cnt; j++) {
+            unsigned long long took = 0ull;
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
                 const float4 r0 = s_rec[j], r1 = s_rec[SF_CHUNK + j], r2 = s_rec[2 * SF_CHUNK + j], r3 = s_rec[3 * SF_CHUNK + j], r4 = s_rec[4 * SF_CHUNK + j];
                 const uint32_t span = s_span[j];
                 const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
@@ -273,40 +309,123 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
                 const float test_T = T * (1.f - q.alpha);
                 const bool trip = hit && test_T < 0.0001f;
                 const bool blend = hit && !trip;
-                const float w = blend ? q.alpha * T : 0.f;
-                const float m = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / q.depth);
-                dist += blend ? (m * m * (1.f - T) + M2 - 2.f * m * M1) * w : 0.f;     // :497-499
-                D += blend ? q.depth * w : 0.f;
-                M1 += blend ? m * w : 0.f;
-                M2 += blend ? m * m * w : 0.f;
-                const bool is_med = blend && T > 0.5f;                                 // :503-507
-                med = is_med ? q.depth : med;
-                med_c = is_med ? (c * SF_CHUNK + j + 1) : med_c;
-                N0 += r3.x * w; N1 += r3.y * w; N2 += r3.z * w;
-                C0 += r1.w * w; C1 += r2.w * w;
+                if (!T_ONLY) {
+                    const float w = blend ? q.alpha * T : 0.f;
+                    const float m = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / q.depth);
+                    // distortion with the segment-local prefix sums; the combine adds the terms in the sums of the segments
+                    // in front (the expression is linear in them), R2/cr/forward.cu:497-499
+                    dist += blend ? (m * m * (1.f - T) + M2 - 2.f * m * M1) * w : 0.f;
+                    D += blend ? q.depth * w : 0.f;
+                    M1 += blend ? m * w : 0.f;
+                    M2 += blend ? m * m * w : 0.f;
+                    const bool is_med = blend && T > 0.5f;                             // :503-507
+                    med = is_med ? q.depth : med;
+                    med_c = is_med ? (sr.x - tr.x + c * SF_CHUNK + (uint32_t)j + 1u) : med_c;
+                    N0 += r3.x * w; N1 += r3.y * w; N2 += r3.z * w;
+                    C0 += r1.w * w; C1 += r2.w * w;
+                }
                 T = blend ? test_T : T;
-                last = blend ? (c * SF_CHUNK + j + 1) : last;
+                T_break = hit ? test_T : T_break;
+                last = blend ? (c * SF_CHUNK + (uint32_t)j + 1u) : last;
                 done = done || trip;
+                if (T_ONLY) took |= (__ballot(hit) != 0ull) ? (1ull << j) : 0ull;
+            }
+            if (T_ONLY) {
+                const uint32_t k = c * SF_CHUNK + lane;
+                if (k < n) fl[k] = (uint8_t)((took >> lane) & 1ull);
+                c_done = c + 1;
             }
         }
     }
-    if (px.inside) {
-        const size_t N = (size_t)a.grid.W * a.grid.H;
-        a.accum[px.pix] = T; a.accum[N + px.pix] = M1; a.accum[2 * N + px.pix] = M2;
-        a.n_contrib[px.pix] = last; a.n_contrib[N + px.pix] = med_c;
-        a.out_color[px.pix] = C0 + T * a.bg[0];
-        a.out_color[N + px.pix] = C1 + T * a.bg[1];
-        a.out_others[0 * N + px.pix] = D;
-        a.out_others[1 * N + px.pix] = 1.f - T;
-        a.out_others[2 * N + px.pix] = N0; a.out_others[3 * N + px.pix] = N1; a.out_others[4 * N + px.pix] = N2;
-        a.out_others[5 * N + px.pix] = med;
-        a.out_others[6 * N + px.pix] = dist;
+    if (T_ONLY) {
+        for (uint32_t c = c_done; c < nchunks; c++) { const uint32_t k = c * SF_CHUNK + lane; if (k < n) fl[k] = 0; }
+        segbase[SF_SEG_TPASS * 64 + lane] = T_break;
+    } else {
+        segbase[SF_SEG_C0 * 64 + lane] = C0; segbase[SF_SEG_C1 * 64 + lane] = C1; segbase[SF_SEG_D * 64 + lane] = D;
+        segbase[SF_SEG_N0 * 64 + lane] = N0; segbase[SF_SEG_N1 * 64 + lane] = N1; segbase[SF_SEG_N2 * 64 + lane] = N2;
+        segbase[SF_SEG_M1 * 64 + lane] = M1; segbase[SF_SEG_M2 * 64 + lane] = M2; segbase[SF_SEG_DIST * 64 + lane] = dist;
+        segbase[SF_SEG_TEND * 64 + lane] = T; segbase[SF_SEG_TBREAK * 64 + lane] = T_break;
+        reinterpret_cast<uint32_t*>(segbase)[SF_SEG_LAST * 64 + lane] = last;
+        reinterpret_cast<uint32_t*>(segbase)[SF_SEG_MEDC * 64 + lane] = med_c;
+        segbase[SF_SEG_MED * 64 + lane] = med;
     }
 }
 
-void launch_sf_render_forward(const SfFwdArgs& a, hipStream_t s) {
-    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
-    hipLaunchKernelGGL(k_sf_render_forward, dim3(patches), dim3(64), 0, s, a);
+// After a pass-1 round ending at segment `front`: patches with an unsaturated pixel and more list stay open (255).
+__global__ void __launch_bounds__(64) k_sf_alive(const SfFwdArgs a) {
+    const int lane = threadIdx.x;
+    const int patch = blockIdx.x;
+    if (a.seg_lo > 0 && a.alive[patch] != 255) return;
+    const int wpt = a.grid.waves_per_tile;
+    const int tile = patch / wpt;
+    const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
+    const int St = segment_count(a.ranges[tile], a.S, a.seg_len);
+    const float* sb = a.seg + (size_t)patch * a.S * (SF_SEG_PLANES * 64) + lane;
+    float T = 1.f;
+    const int kf = min(a.front, St);
+    for (int k = 0; k < kf && T >= 0.0001f; k++) T *= sb[(size_t)k * (SF_SEG_PLANES * 64) + SF_SEG_TPASS * 64];
+    const unsigned long long open = __ballot(px.inside && T >= 0.0001f);
+    if (lane == 0) a.alive[patch] = (St > a.front && open != 0ull) ? 255 : (uint8_t)min(a.front, 254);
+}
+
+// Per patch: fold the segments in order into the image planes.
+__global__ void __launch_bounds__(64) k_sf_combine(const SfFwdArgs a) {
+    const int lane = threadIdx.x;
+    const int patch = blockIdx.x;
+    const int wpt = a.grid.waves_per_tile;
+    const int tile = patch / wpt;
+    const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
+    if (!px.inside) return;
+    const uint2 tr = a.ranges[tile];
+    int St = segment_count(tr, a.S, a.seg_len);
+    const int Sfull = St;
+    if (a.alive) St = min(St, (int)a.alive[patch]);
+    const float* sb = a.seg + (size_t)patch * a.S * (SF_SEG_PLANES * 64) + lane;
+    const uint32_t* su = reinterpret_cast<const uint32_t*>(sb);
+    const size_t stride = SF_SEG_PLANES * 64;
+    float C0 = 0.f, C1 = 0.f, D = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
+    float T_final = 1.f, T_start = 1.f;
+    uint32_t last = 0, med_c = 0;
+    bool stopped = false;
+    for (int k = 0; k < St; k++) {
+        if (stopped) break;
+        const float* p = sb + (size_t)k * stride;
+        const float tend = p[SF_SEG_TEND * 64], m1 = p[SF_SEG_M1 * 64], m2 = p[SF_SEG_M2 * 64];
+        const float wsum = T_start - tend;                                 // sum of the blend weights of this segment
+        dist += p[SF_SEG_DIST * 64] + M2 * wsum - 2.f * M1 * m1;           // cross terms with the segments in front
+        C0 += p[SF_SEG_C0 * 64]; C1 += p[SF_SEG_C1 * 64]; D += p[SF_SEG_D * 64];
+        N0 += p[SF_SEG_N0 * 64]; N1 += p[SF_SEG_N1 * 64]; N2 += p[SF_SEG_N2 * 64];
+        M1 += m1; M2 += m2;
+        const uint32_t l = su[(size_t)k * stride + SF_SEG_LAST * 64], mc = su[(size_t)k * stride + SF_SEG_MEDC * 64];
+        if (l) last = segment_range(tr, Sfull, k).x - tr.x + l;
+        if (mc) { med_c = mc; med = p[SF_SEG_MED * 64]; }
+        T_final = tend;
+        T_start *= p[SF_SEG_TPASS * 64];                                    // what pass 2 started the next segment from
+        stopped = p[SF_SEG_TBREAK * 64] < 0.0001f;
+    }
+    const size_t N = (size_t)a.grid.W * a.grid.H;
+    a.accum[px.pix] = T_final; a.accum[N + px.pix] = M1; a.accum[2 * N + px.pix] = M2;
+    a.n_contrib[px.pix] = last; a.n_contrib[N + px.pix] = med_c;
+    a.out_color[px.pix] = C0 + T_final * a.bg[0];
+    a.out_color[N + px.pix] = C1 + T_final * a.bg[1];
+    a.out_others[0 * N + px.pix] = D;
+    a.out_others[1 * N + px.pix] = 1.f - T_final;
+    a.out_others[2 * N + px.pix] = N0; a.out_others[3 * N + px.pix] = N1; a.out_others[4 * N + px.pix] = N2;
+    a.out_others[5 * N + px.pix] = med;
+    a.out_others[6 * N + px.pix] = dist;
+}
+
+void launch_sf_render_pass1(const SfFwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_sf_render_forward<true>, dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
+}
+void launch_sf_render_pass2(const SfFwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_sf_render_forward<false>, dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
+}
+void launch_sf_alive(const SfFwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_sf_alive, dim3((unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile)), dim3(64), 0, s, a);
+}
+void launch_sf_combine(const SfFwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_sf_combine, dim3((unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile)), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,28 +464,44 @@ struct SfBwdArgs {
     const float* accum; const uint32_t* n_contrib;
     const float* dL_dpix; const float* dL_dothers;
     float* gacc;           // [32 P]
+    const float* seg; int S; int seg_len;
+    const uint8_t* flags; size_t R;
+    const uint8_t* alive;
 };
 
+// One workgroup = (patch, segment): back-to-front walk of the segment's flagged entries.  T starts at the segment's own end
+// value; the "what lies behind" recurrences are seeded with the partial sums of the segments behind it, as seen from there.
 __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     __shared__ float4 s_rec[5 * SF_CHUNK];
     __shared__ uint32_t s_span[SF_CHUNK];
     __shared__ uint32_t s_gid[SF_CHUNK];
     const int lane = threadIdx.x;
-    const int patch = blockIdx.x;
-    const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
-    const uint2 range = a.ranges[patch / a.grid.waves_per_tile];
-    const size_t N = (size_t)a.grid.W * a.grid.H;
-    const uint32_t n_lane = px.inside ? a.n_contrib[px.pix] : 0u;
+    const int S = a.S;
+    const int wpt = a.grid.waves_per_tile;
+    int patch, seg;
+    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, S, patch, seg)) return;
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    if (seg >= St) return;
+    if (a.alive && seg >= (int)a.alive[patch]) return;
+    const size_t stride = SF_SEG_PLANES * 64;
+    const float* sb = a.seg + (size_t)patch * S * stride + lane;
+    const uint32_t n_lane = reinterpret_cast<const uint32_t*>(sb)[(size_t)seg * stride + SF_SEG_LAST * 64];
     uint32_t n_max = n_lane;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
     if (n_max == 0) return;
 
+    const SfPixel px = sf_pixel(a.grid, a.coltab, a.rowtab, patch, lane);
+    const uint2 sr = segment_range(tr, St, seg);
+    const uint32_t seg_off = sr.x - tr.x;                               // list position of the segment's first entry
+    const size_t N = (size_t)a.grid.W * a.grid.H;
     const float T_final = px.inside ? a.accum[px.pix] : 0.f;
     const float final_D = px.inside ? a.accum[N + px.pix] : 0.f;
     const float final_A = 1.f - T_final;
     const uint32_t med_c = px.inside ? a.n_contrib[N + px.pix] : 0u;
-    float T = T_final;
+    float T = sb[(size_t)seg * stride + SF_SEG_TEND * 64];
     float g0 = 0.f, g1 = 0.f, g_depth = 0.f, g_alpha = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, g_med = 0.f, g_reg = 0.f;
     if (px.inside) {
         g0 = a.dL_dpix[px.pix]; g1 = a.dL_dpix[N + px.pix];
@@ -376,25 +511,48 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     }
     const float bgdot = a.bg[0] * g0 + a.bg[1] * g1;
     float acc_c0 = 0.f, acc_d = 0.f, acc_a = 0.f, acc_n0 = 0.f, acc_n1 = 0.f, acc_n2 = 0.f;
+    {
+        float b0 = 0.f, bd = 0.f, bn0 = 0.f, bn1 = 0.f, bn2 = 0.f;
+        const int Send = a.alive ? min(St, (int)a.alive[patch]) : St;
+        for (int k = seg + 1; k < Send; k++) {
+            const float* p = sb + (size_t)k * stride;
+            b0 += p[SF_SEG_C0 * 64]; bd += p[SF_SEG_D * 64];
+            bn0 += p[SF_SEG_N0 * 64]; bn1 += p[SF_SEG_N1 * 64]; bn2 += p[SF_SEG_N2 * 64];
+        }
+        if (T > 0.f) {
+            const float inv = 1.f / T;
+            acc_c0 = b0 * inv; acc_d = bd * inv; acc_n0 = bn0 * inv; acc_n1 = bn1 * inv; acc_n2 = bn2 * inv;
+            acc_a = 1.f - T_final * inv;
+        }
+    }
     float last_alpha = 0.f, l_c0 = 0.f, l_d = 0.f, l_n0 = 0.f, l_n1 = 0.f, l_n2 = 0.f;
 
     const int c_last = (int)((n_max - 1) / SF_CHUNK);
-    auto gather = [&](int c) { const uint32_t k = (uint32_t)c * SF_CHUNK + lane; return sf_gather(a.point_list, a.rec, a.rowspan, range.x + k, k < n_max); };
+    const uint8_t* fl = a.flags + (size_t)sub * a.R + sr.x;
+    bool have;
+    auto gather = [&](int c) {
+        const uint32_t k = (uint32_t)c * SF_CHUNK + lane;
+        have = k < n_max && fl[k] != 0;
+        return sf_gather(a.point_list, a.rec, a.rowspan, sr.x + k, have);
+    };
     SfStaged st = gather(c_last);
     for (int c = c_last; c >= 0; c--) {
         __syncthreads();
         s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
         s_rec[4 * SF_CHUNK + lane] = st.a4; s_span[lane] = st.span; s_gid[lane] = st.gid;
+        unsigned long long todo = __ballot(have);
         __syncthreads();
         if (c > 0) st = gather(c - 1);
-        const int hi = (int)min((uint32_t)SF_CHUNK, n_max - (uint32_t)c * SF_CHUNK) - 1;
-        for (int j = hi; j >= 0; j--) {
-            const uint32_t e = (uint32_t)c * SF_CHUNK + j;            // 0-based list position == the reference's `contributor`
+        while (todo) {
+            const int j = 63 - __builtin_clzll(todo);
+            todo &= ~(1ull << j);
+            const uint32_t e_loc = (uint32_t)c * SF_CHUNK + j;       // position inside the segment
+            const uint32_t e = seg_off + e_loc;                       // 0-based list position == the reference's `contributor`
             const float4 r0 = s_rec[j], r1 = s_rec[SF_CHUNK + j], r2 = s_rec[2 * SF_CHUNK + j], r3 = s_rec[3 * SF_CHUNK + j], r4 = s_rec[4 * SF_CHUNK + j];
             const uint32_t span = s_span[j];
             const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
             const SfPair q = sf_pair(px, r0, r1, r2, r3, r4);
-            const bool contrib = rows && (e < n_lane) && q.ok;
+            const bool contrib = rows && (e_loc < n_lane) && q.ok;
             if (__ballot(contrib) == 0ull) continue;
             const float alpha = q.alpha, G = q.G, c_d = q.depth;
             const float Tn = T / (1.f - alpha);
@@ -466,8 +624,7 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
 }
 
 void launch_sf_render_backward(const SfBwdArgs& a, hipStream_t s) {
-    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
-    hipLaunchKernelGGL(k_sf_render_backward, dim3(patches), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_sf_render_backward, dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S)), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

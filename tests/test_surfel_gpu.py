@@ -115,3 +115,31 @@ def test_surfel_missing_colors_raises():
     with pytest.raises(RuntimeError, match="precomputed Gaussian colors"):
         _C.rasterize_gaussians(t["bg"], t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e, t["viewmatrix"],
                                torch.eye(4).cuda(), t["beams"], 16, 512, e, 1, torch.zeros(3).cuda(), False, 80, 0, False)
+
+
+def test_surfel_config5_fullsize_properties():
+    """BASELINE config 5 at full size (2 M surfels, 64 x 2650): size-independent properties of the blend."""
+    import torch
+    import lidargs_scenes as sc
+    kind, P, H, W, seed = sc.BASELINE_CONFIGS["cfg5"]
+    scene = surfel_scene(kind, P, H, seed, random_view=False)
+    g = surfel_upstream_grads(H, W, seed)
+    a = hip_surfel_forward_backward(scene, W, H, g)
+    b = hip_surfel_forward_backward(scene, W, H, g)
+    alpha, depth, nrm, med, dist = a["others"][1], a["others"][0], a["others"][2:5], a["others"][5], a["others"][6]
+    assert np.isfinite(a["color"]).all() and np.isfinite(a["others"]).all()
+    assert (alpha >= 0).all() and (alpha <= 1.0).all() and alpha.mean() > 0.5
+    assert (np.linalg.norm(nrm, axis=0) <= alpha + 1e-4).all()                    # sum of w_i n_i, unit normals
+    assert (depth[alpha > 0] > 0).all() and (depth[alpha == 0] == 0).all()
+    assert ((med == 0) | (med >= 0.2)).all() and (np.abs(dist) < 1e-1).all()
+    # the forward is a deterministic function of its inputs (no atomics): bit-identical on a second run
+    for k in ("color", "others", "radii"):
+        assert np.array_equal(a[k], b[k]), k
+    # gradients: culled surfels get exact zeros, visible ones finite values; atomics make them order-dependent only in the last bits
+    dead = a["radii"] == 0
+    for k in GRAD_KEYS_SURFEL:
+        assert np.isfinite(a[k]).all(), k
+        assert (a[k][dead] == 0).all(), k
+        scale = np.abs(a[k]).max()
+        assert np.abs(a[k] - b[k]).max() <= 1e-4 * scale, k
+    torch.cuda.synchronize()
