@@ -92,6 +92,53 @@ def cpu_baseline(kind, P_full, H, W, seed, budget_s=20.0):
     }
 
 
+def bench_surfel(args, sc, kind, P, H, W, seed):
+    """BASELINE config 5: the 2DGS laser-surfel variant, single GPU, same metric (fwd+bwd frames/s); not the headline line."""
+    import numpy as np
+    assert args.gpus == 1, "config 5 is a single-GPU configuration"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU path"
+    import build_hip
+    build_hip.build()
+    from diff_lidargs_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda", 0)
+    scene = sc.make_scene(kind, P, H, seed)
+    scene["scales"] = np.ascontiguousarray(scene["scales"][:, :2])
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in scene.items()}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=H, image_width=W, bg=st["bg"], scale_modifier=1.0, depth_threshold=0.0, viewmatrix=st["viewmatrix"],
+        projmatrix=torch.eye(4, device=dev), sh_degree=1, campos=torch.zeros(3, device=dev), prefiltered=False,
+        beam_inclinations=st["beams"], lidar_far=80, lidar_near=0, debug=False))
+    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((P, 4), dtype=torch.float32, device=dev, requires_grad=True)
+    rng = np.random.default_rng(seed + 200)
+    gc = torch.from_numpy(rng.normal(size=(2, H, W)).astype(np.float32)).to(dev)
+    go = torch.from_numpy(rng.normal(size=(7, H, W)).astype(np.float32)).to(dev)
+
+    def step():
+        for t in list(leaves.values()) + [means2D]:
+            t.grad = None
+        color, radii, others, _pix = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                          colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+        torch.autograd.backward([color, others], [gc, go])
+        return radii
+    for _ in range(args.warmup):
+        radii = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        radii = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfg5: {P} surfels ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, diff_lidargs_surfel_rasterization "
+                               f"(2DGS laser-surfel variant), lidar_far=80 lidar_near=0, bg=0",
+                   "visible_surfels": int((radii > 0).sum())},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +150,8 @@ def main():
 
     import lidargs_scenes as sc
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
+    if args.workload == "cfg5":
+        return bench_surfel(args, sc, kind, P, H, W, seed)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
