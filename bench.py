@@ -161,9 +161,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LIDARGS_BENCH_FORCE_SHELLS=1 runs the range-shell code path (RCCL collectives included) with a world of one: the only way
+    # to exercise it end to end on a single-GPU box; never set by the driver
+    force_shells = world == 1 and os.environ.get("LIDARGS_BENCH_FORCE_SHELLS", "0") == "1"
+    if world > 1 or force_shells:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if force_shells:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if rank == 0:
         import build_hip
@@ -181,7 +186,7 @@ def main():
     leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     means2D = torch.zeros((P, 4), dtype=torch.float32, device=dev, requires_grad=True)
 
-    if world == 1:
+    if world == 1 and not force_shells:
         rast = GaussianRasterizer(settings)
 
         def step():
@@ -278,7 +283,7 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_shells:
         import torch.distributed as dist
         dist.destroy_process_group()
 
