@@ -1,0 +1,74 @@
+/*
+ * lidargs_neural_gaussians.h -- C ABI of the fused anchor decode.
+ *
+ * Replaces the PyTorch graph of generate_neural_gaussians (/root/reference/gaussian_renderer/__init__.py:17-119): from the
+ * anchors of a Scaffold-style model (feature, position, k offsets, 6 scalings) and four small MLPs
+ * (scene/gaussian_model.py:113-142: Linear(35|36, 32)-ReLU-Linear(32, k | 7k | k | k) with tanh / identity / sigmoid /
+ * sigmoid) to the packed per-Gaussian inputs of the rasterizer: xyz, colour (intensity, ray-drop), opacity, scaling, rotation,
+ * keeping only the offsets whose neural opacity is > 0, in (anchor, offset) order.
+ *
+ * Supported model configuration (the reference's defaults, arguments/__init__.py:51-79): feat_dim 32, hidden 32,
+ * n_offsets in {4,5,6,8,10}, appearance_dim 0, use_feat_bank false, colour channels 2.  Anything else is the caller's job to
+ * reject (the Python front-end does, loudly).
+ *
+ * All pointers are device pointers unless stated otherwise; plain float32 row-major arrays; no torch types.  Functions return 0
+ * or a positive count on success, a negative LIDARGS_ERR_* code on failure (message: lidargs_last_error()).
+ */
+#ifndef LIDARGS_NEURAL_GAUSSIANS_H
+#define LIDARGS_NEURAL_GAUSSIANS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The four MLPs, in the order opacity, cov, color, raydrop.  Weights in nn.Linear layout: W1 [32][din], b1 [32],
+ * W2 [dout][32], b2 [dout] with din = 35 + add_*_dist and dout = k, 7k, k, k. */
+typedef struct lidargs_ng_model {
+    int n_offsets;
+    int add_opacity_dist, add_cov_dist, add_color_dist;
+    const float* W1[4]; const float* b1[4]; const float* W2[4]; const float* b2[4];
+} lidargs_ng_model;
+
+size_t lidargs_ng_scratch_bytes(int N, int n_offsets);
+
+/* Step 1 (:19-68): visible-anchor selection, view direction / distance, opacity MLP, opacity > 0 mask.
+ *   visible_mask   u8[N] (torch.bool) or NULL = all visible
+ *   cam_center     HOST pointer, 3 floats (viewpoint_camera.camera_center)
+ *   neural_opacity f32[N*k]  written for the first n*k entries: tanh output per (visible anchor, offset), anchor order
+ *   mask           u8[N*k]   first n*k entries: neural_opacity > 0
+ *   counts_host    HOST int[2]: n = number of visible anchors, M = number of selected (anchor, offset) pairs
+ * Synchronises the stream once (the counts size the outputs of step 2, like the reference's boolean indexing does). */
+int lidargs_ng_forward_select(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
+                              const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
+                              int* counts_host, char* scratch, size_t scratch_bytes, void* stream);
+
+/* Step 2 (:70-113): colour / ray-drop / covariance MLPs and the post-processing, for the selected pairs only.
+ * Outputs have M rows: xyz f32[M*3], color f32[M*2], opacity f32[M], scaling f32[M*3], rot f32[M*4].
+ * `scaling` input is get_scaling (already exp-activated) f32[N*6]; offset f32[N*k*3]; neural_opacity is what step 1 wrote.
+ * Must follow lidargs_ng_forward_select of the same inputs with the same scratch (the selection lives there). */
+int lidargs_ng_forward_decode(int N, const lidargs_ng_model* model, const float* anchor_feat, const float* anchor,
+                              const float* offset, const float* scaling, const float* cam_center, const float* neural_opacity,
+                              float* out_xyz, float* out_color, float* out_opacity, float* out_scaling, float* out_rot,
+                              char* scratch, size_t scratch_bytes, void* stream);
+
+/* Backward.  Upstream gradients of the M-row outputs; dL_dneural_opacity f32[n*k] (gradient of the un-masked neural_opacity
+ * output) may be NULL -- the reference only uses that output as a statistic (train.py:243).  Writes, for every one of the N anchors (zeros for
+ * invisible ones): dL_danchor_feat f32[N*32], dL_danchor f32[N*3], dL_doffset f32[N*k*3], dL_dscaling f32[N*6]; and for
+ * the n visible anchors, in anchor order, the per-anchor layer inputs and deltas the weight gradients are plain GEMMs of:
+ *   act_x f32[n*36] (feature, view, dist), act_h f32[4][n*32] (ReLU outputs), delta1 f32[4][n*32], delta2 f32[n*(10k)]
+ *   laid out [n][k | 7k | k | k]:  dW2_m = delta2_m^T act_h_m,  dW1_m = delta1_m^T act_x[:, :din_m],  db = column sums.
+ * Must follow forward_select/forward_decode of the same inputs with the same scratch (the selection is reused). */
+int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, const float* anchor_feat, const float* anchor,
+                        const float* offset, const float* scaling, const float* cam_center,
+                        const float* dL_dxyz, const float* dL_dcolor, const float* dL_dopacity, const float* dL_dscaling,
+                        const float* dL_drot, const float* dL_dneural_opacity, float* dL_danchor_feat, float* dL_danchor, float* dL_doffset,
+                        float* dL_dscaling_in, float* act_x, float* act_h, float* delta1, float* delta2,
+                        char* scratch, size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -25,6 +25,7 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "render.hip": [],
+    "neural_gaussians.hip": [],
     "surfel.hip": ["-ffp-contract=off"],   # ray/plane hit point cancels ~3 digits: round as the reference writes it
 }
 

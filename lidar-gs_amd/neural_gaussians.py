@@ -1,0 +1,152 @@
+"""`generate_neural_gaussians` of LiDAR-GS (gaussian_renderer/__init__.py:17-119) on the fused HIP anchor decode.
+
+Same signature and return values as the reference function; a checkout switches to it with one import
+(`from neural_gaussians import generate_neural_gaussians` in gaussian_renderer/__init__.py).  The ~40
+framework ops of the reference become three native calls (include/lidargs_neural_gaussians.h); the eight weight gradients
+are the plain GEMMs torch already does well (hipBLASLt), fed by the per-anchor deltas the backward kernel writes.
+
+Model configurations outside the native kernel's scope (feature bank, appearance embedding, colour channels != 2, feature /
+hidden width != 32, n_offsets not in {4,5,6,8,10}) raise NotImplementedError: there is no silent framework fallback.
+"""
+import ctypes as C
+
+import torch
+
+from diff_lidargs_rasterization import _C as _base
+
+_lib = _base._lib
+MLP_ORDER = ("opacity", "cov", "color", "raydrop")
+
+
+class _Model(C.Structure):
+    _fields_ = [("n_offsets", C.c_int), ("add_opacity_dist", C.c_int), ("add_cov_dist", C.c_int), ("add_color_dist", C.c_int),
+                ("W1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("W2", C.c_void_p * 4), ("b2", C.c_void_p * 4)]
+
+
+for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward"):
+    getattr(_lib, _n).restype = C.c_int
+_lib.lidargs_ng_scratch_bytes.restype = C.c_size_t
+
+
+def _check(rc, what):
+    if rc < 0:
+        _base._raise(rc, what)
+
+
+def _model_struct(k, flags, params):
+    m = _Model()
+    m.n_offsets, m.add_opacity_dist, m.add_cov_dist, m.add_color_dist = k, int(flags[0]), int(flags[1]), int(flags[2])
+    for i in range(4):
+        m.W1[i], m.b1[i], m.W2[i], m.b2[i] = (params[4 * i + j].data_ptr() for j in range(4))
+    return m
+
+
+class _Decode(torch.autograd.Function):
+    """inputs: anchor_feat [N,32], anchor [N,3], offset [N,k,3], scaling [N,6] (get_scaling), then W1,b1,W2,b2 of the opacity, cov,
+    color and raydrop MLPs; cam (3 floats, host), visible_mask (bool[N] or None), flags (3 bools)."""
+
+    @staticmethod
+    def forward(ctx, anchor_feat, anchor, offset, scaling, *rest):
+        params, (cam, visible_mask, flags) = rest[:16], rest[16:]
+        _base._require_device(anchor, "anchor")
+        dev = anchor.device
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        anchor_feat, anchor, offset, scaling = f32(anchor_feat), f32(anchor), f32(offset), f32(scaling)
+        params = tuple(f32(p) for p in params)
+        N, k = int(anchor.shape[0]), int(offset.shape[1])
+        model = _model_struct(k, flags, params)
+        nb = int(_lib.lidargs_ng_scratch_bytes(C.c_int(N), C.c_int(k)))
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        neural_opacity = torch.empty(max(N, 1) * k, dtype=torch.float32, device=dev)
+        mask = torch.empty(max(N, 1) * k, dtype=torch.uint8, device=dev)
+        vis = None if visible_mask is None else visible_mask.to(torch.bool).contiguous().view(torch.uint8)
+        counts = (C.c_int * 2)()
+        camv = (C.c_float * 3)(*[float(c) for c in cam])
+        p = _base._ptr
+        with torch.cuda.device(dev):
+            _check(_lib.lidargs_ng_forward_select(C.c_int(N), C.byref(model), p(vis), p(anchor_feat), p(anchor), camv, p(neural_opacity), p(mask),
+                                                  counts, p(scratch), C.c_size_t(nb), _base._stream(dev)), "lidargs_ng_forward_select")
+            n, M = int(counts[0]), int(counts[1])
+            out = torch.empty(M * 13, dtype=torch.float32, device=dev)
+            xyz, color, opacity = out[:3 * M].view(M, 3), out[3 * M:5 * M].view(M, 2), out[5 * M:6 * M].view(M, 1)
+            scal, rot = out[6 * M:9 * M].view(M, 3), out[9 * M:13 * M].view(M, 4)
+            if N:
+                _check(_lib.lidargs_ng_forward_decode(C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
+                                                      p(neural_opacity), p(xyz), p(color), p(opacity), p(scal), p(rot), p(scratch), C.c_size_t(nb),
+                                                      _base._stream(dev)), "lidargs_ng_forward_decode")
+        ctx.save_for_backward(anchor_feat, anchor, offset, scaling, scratch, *params)
+        ctx.meta = (N, k, n, M, tuple(float(c) for c in cam), tuple(bool(f) for f in flags))
+        neural_opacity = neural_opacity[:n * k].view(n * k, 1)
+        mask_b = mask[:n * k].view(torch.bool)
+        ctx.mark_non_differentiable(mask_b)
+        return xyz, color, opacity, scal, rot, neural_opacity, mask_b
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_color, g_opacity, g_scaling, g_rot, g_no, _g_mask):
+        anchor_feat, anchor, offset, scaling, scratch = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        N, k, n, M, cam, flags = ctx.meta
+        dev = anchor.device
+        model = _model_struct(k, flags, params)
+        camv = (C.c_float * 3)(*cam)
+        f = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous()
+        g_xyz, g_color, g_opacity = f(g_xyz, (M, 3)), f(g_color, (M, 2)), f(g_opacity, (M, 1))
+        g_scaling, g_rot = f(g_scaling, (M, 3)), f(g_rot, (M, 4))
+        g_no = None if g_no is None else g_no.to(torch.float32).contiguous()
+        dense = torch.empty(N * (32 + 3 + 3 * k + 6), dtype=torch.float32, device=dev)          # every row is written by the kernel
+        o = 0
+        d_feat = dense[o:o + N * 32].view(N, 32); o += N * 32
+        d_anchor = dense[o:o + N * 3].view(N, 3); o += N * 3
+        d_offset = dense[o:o + N * 3 * k].view(N, k, 3); o += N * 3 * k
+        d_scaling = dense[o:o + N * 6].view(N, 6)
+        act_x = torch.empty((n, 36), dtype=torch.float32, device=dev)
+        act_h = torch.empty((4, n, 32), dtype=torch.float32, device=dev)
+        delta1 = torch.empty((4, n, 32), dtype=torch.float32, device=dev)
+        delta2 = torch.empty((n, 10 * k), dtype=torch.float32, device=dev)
+        p = _base._ptr
+        if N:
+            with torch.cuda.device(dev):
+                _check(_lib.lidargs_ng_backward(C.c_int(N), C.c_int(n), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
+                                                p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
+                                                p(d_offset), p(d_scaling), p(act_x), p(act_h), p(delta1), p(delta2), p(scratch),
+                                                C.c_size_t(scratch.numel()), _base._stream(dev)), "lidargs_ng_backward")
+        # weight gradients: plain GEMMs of the per-anchor layer inputs and deltas (library GEMMs, not a kernel of ours)
+        cols = {"opacity": (0, k), "cov": (k, 8 * k), "color": (8 * k, 9 * k), "raydrop": (9 * k, 10 * k)}
+        dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
+        g_params = []
+        for i, name in enumerate(MLP_ORDER):
+            d2 = delta2[:, cols[name][0]:cols[name][1]]
+            g_params += [delta1[i].t() @ act_x[:, :dins[i]], delta1[i].sum(0), d2.t() @ act_h[i], d2.sum(0)]
+        return (d_feat, d_anchor, d_offset, d_scaling, *g_params, None, None, None)
+
+
+def _linear_pair(seq, what):
+    import torch.nn as nn
+    lin = [m for m in seq if isinstance(m, nn.Linear)]
+    if len(lin) != 2 or lin[0].out_features != 32 or lin[1].in_features != 32:
+        raise NotImplementedError(f"neural_gaussians: unsupported {what} MLP (the native decode handles Linear(din,32)-ReLU-Linear(32,dout))")
+    return lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias
+
+
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
+    """Drop-in for gaussian_renderer.generate_neural_gaussians (:17-119): same arguments, same 5- or 7-tuple."""
+    if getattr(pc, "use_feat_bank", False):
+        raise NotImplementedError("neural_gaussians: use_feat_bank=True is not supported by the native decode")
+    if getattr(pc, "appearance_dim", 0) > 0:
+        raise NotImplementedError("neural_gaussians: appearance_dim > 0 is not supported by the native decode")
+    if getattr(pc, "color_channel", 2) != 2:
+        raise NotImplementedError("neural_gaussians: colour channels other than 2 (intensity + ray-drop) are not supported")
+    anchor_feat, anchor, offset, scaling = pc._anchor_feat, pc.get_anchor, pc._offset, pc.get_scaling
+    if anchor_feat.shape[1] != 32:
+        raise NotImplementedError("neural_gaussians: feat_dim must be 32")
+    k = int(pc.n_offsets)
+    if k not in (4, 5, 6, 8, 10) or offset.shape[1] != k:
+        raise NotImplementedError("neural_gaussians: n_offsets must be 4, 5, 6, 8 or 10")
+    params = (*_linear_pair(pc.get_opacity_mlp, "opacity"), *_linear_pair(pc.get_cov_mlp, "cov"),
+              *_linear_pair(pc.get_color_mlp, "color"), *_linear_pair(pc.get_raydrop_mlp, "raydrop"))
+    flags = (bool(pc.add_opacity_dist), bool(pc.add_cov_dist), bool(pc.add_color_dist))
+    cam = viewpoint_camera.camera_center.detach().to("cpu", torch.float32).reshape(3).tolist()
+    xyz, color, opacity, scal, rot, neural_opacity, mask = _Decode.apply(anchor_feat, anchor, offset, scaling, *params, cam, visible_mask, flags)
+    if is_training:
+        return xyz, color, opacity, scal, rot, neural_opacity, mask
+    return xyz, color, opacity, scal, rot

@@ -12,18 +12,22 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "lidargs_rasterizer.h")
+HEADERS = [HEADER, os.path.join(ROOT, "include", "lidargs_neural_gaussians.h")]
 
 
 def _declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(lidargs_[a-z_0-9]+)\s*\(", src)) - {"lidargs_alloc_fn"})
+    names = set()
+    for h in HEADERS:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(lidargs_[a-z_0-9]+)\s*\(", src))
+    return sorted(names - {"lidargs_alloc_fn"})
 
 
 def test_header_is_plain_c():
     """The boundary is C: the header must compile as C99 with no C++ or torch types."""
-    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", HEADER], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for h in HEADERS:
+        r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", h], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
     txt = open(HEADER).read()
     assert "torch" not in txt.replace("(torch, or any", "").replace("a torch", "") or True
     assert "std::" not in re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
@@ -32,7 +36,8 @@ def test_header_is_plain_c():
 def test_library_exports_every_declared_symbol(hip_lib_built):
     names = _declared_functions()
     assert {"lidargs_forward", "lidargs_backward", "lidargs_visible_filter", "lidargs_mark_visible", "lidargs_forward_shell",
-            "lidargs_render_shell", "lidargs_backward_shell", "lidargs_last_error", "lidargs_abi_version"} <= set(names)
+            "lidargs_render_shell", "lidargs_backward_shell", "lidargs_last_error", "lidargs_abi_version", "lidargs_ng_forward_select",
+            "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_surfel_forward", "lidargs_shell_select"} <= set(names)
     lib = ctypes.CDLL(hip_lib_built)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing

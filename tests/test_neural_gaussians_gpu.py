@@ -1,0 +1,125 @@
+"""GPU parity of the fused anchor decode: the product function `neural_gaussians.generate_neural_gaussians`
+(C ABI lidargs_ng_*) against (i) the golden vectors produced by executing the reference function + torch autograd, and (ii) the
+numpy oracle on larger random cases.  Tolerance: 1e-4 relative fp32 (tests/util.py parity metric)."""
+import types
+
+import numpy as np
+import pytest
+
+from oracle import neural_gaussians as ng
+from test_neural_gaussians_cpu import PARAM_KEYS, load_case
+from util import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pc(p, device="cuda"):
+    import torch
+    from torch import nn
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    pc = types.SimpleNamespace()
+    k = p["offset"].shape[1]
+    pc.use_feat_bank, pc.appearance_dim, pc.n_offsets, pc.color_channel = False, 0, k, 2
+    pc.add_opacity_dist, pc.add_cov_dist, pc.add_color_dist = p["add_opacity_dist"], p["add_cov_dist"], p["add_color_dist"]
+    for name, act in (("opacity", nn.Tanh()), ("cov", None), ("color", nn.Sigmoid()), ("raydrop", nn.Sigmoid())):
+        W1, W2 = p[name + "_W1"], p[name + "_W2"]
+        seq = nn.Sequential(nn.Linear(W1.shape[1], 32), nn.ReLU(True), nn.Linear(32, W2.shape[0]), *([act] if act else [])).to(device)
+        with torch.no_grad():
+            seq[0].weight.copy_(t(W1)); seq[0].bias.copy_(t(p[name + "_b1"])); seq[2].weight.copy_(t(W2)); seq[2].bias.copy_(t(p[name + "_b2"]))
+        setattr(pc, "mlp_" + name, seq); setattr(pc, f"get_{name}_mlp", seq)
+    pc._anchor_feat = t(p["anchor_feat"]).requires_grad_(True)
+    pc._anchor = t(p["anchor"]).requires_grad_(True); pc.get_anchor = pc._anchor
+    pc._offset = t(p["offset"]).requires_grad_(True)
+    pc.get_scaling = t(p["scaling"]).requires_grad_(True)
+    return pc
+
+
+def run_hip(p, cam, vis, ups=None):
+    import torch
+    from neural_gaussians import generate_neural_gaussians
+    pc = build_pc(p)
+    camera = types.SimpleNamespace(camera_center=torch.from_numpy(np.asarray(cam, np.float32)).cuda(), uid=0)
+    vmask = None if vis is None else torch.from_numpy(np.asarray(vis)).cuda()
+    xyz, color, opacity, scaling, rot, neural_opacity, mask = generate_neural_gaussians(camera, pc, vmask, is_training=True)
+    out = dict(xyz=xyz, color=color, opacity=opacity, scaling=scaling, rot=rot, neural_opacity=neural_opacity)
+    res = {k: v.detach().cpu().numpy() for k, v in out.items()}
+    res["mask"] = mask.cpu().numpy()
+    if ups is not None:
+        torch.autograd.backward([xyz, color, opacity, scaling, rot], [torch.from_numpy(u).cuda() for u in ups])
+        res.update(g_anchor_feat=pc._anchor_feat.grad.cpu().numpy(), g_anchor=pc._anchor.grad.cpu().numpy(),
+                   g_offset=pc._offset.grad.cpu().numpy(), g_scaling=pc.get_scaling.grad.cpu().numpy())
+        for name in ng.MLPS:
+            seq = getattr(pc, "mlp_" + name)
+            res[f"g_{name}_W1"], res[f"g_{name}_b1"] = seq[0].weight.grad.cpu().numpy(), seq[0].bias.grad.cpu().numpy()
+            res[f"g_{name}_W2"], res[f"g_{name}_b2"] = seq[2].weight.grad.cpu().numpy(), seq[2].bias.grad.cpu().numpy()
+    return res
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_decode_matches_reference_golden(tag, hip_lib_built):
+    p, cam, vis, exp = load_case(tag)
+    ups = [exp["up_" + k] for k in ("xyz", "color", "opacity", "scaling", "rot")]
+    r = run_hip(p, cam, vis, ups)
+    flips = int((r["mask"] != exp["out_mask"]).sum())
+    assert flips == 0, f"{flips} opacity-sign flips"
+    for k in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
+        parity(k, r[k], exp["out_" + k])
+    for k in ("anchor_feat", "anchor", "offset", "scaling"):
+        parity("d" + k, r["g_" + k], exp["g_" + k])
+    for k in PARAM_KEYS:
+        parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4)       # fp32 GEMM accumulation order, see the CPU test
+
+
+def random_case(N, k, seed, flags=(True, True, True)):
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.normal(size=s).astype(np.float32)
+    p = dict(anchor_feat=0.5 * f(N, 32), anchor=10.0 * f(N, 3), offset=0.3 * f(N, k, 3), scaling=np.exp(0.3 * f(N, 6) - 1.0).astype(np.float32),
+             add_opacity_dist=flags[0], add_cov_dist=flags[1], add_color_dist=flags[2])
+    dins = dict(opacity=35 + flags[0], cov=35 + flags[1], color=35 + flags[2], raydrop=35 + flags[2])
+    douts = dict(opacity=k, cov=7 * k, color=k, raydrop=k)
+    for m in ng.MLPS:
+        p[m + "_W1"], p[m + "_b1"] = f(32, dins[m]) / np.float32(6.0), 0.1 * f(32)
+        p[m + "_W2"], p[m + "_b2"] = f(douts[m], 32) / np.float32(5.6), 0.1 * f(douts[m])
+    return p, np.array([0.5, -1.0, 2.0], np.float32), rng.random(N) > 0.3, rng
+
+
+@pytest.mark.parametrize("N,k,flags", [(20000, 6, (True, True, True)), (7001, 10, (False, True, True)), (5000, 4, (True, False, False)),
+                                       (3000, 5, (False, False, False)), (3000, 8, (True, True, False))])
+def test_decode_matches_oracle_random(N, k, flags, hip_lib_built):
+    p, cam, vis, rng = random_case(N, k, 100 + k, flags)
+    f = ng.forward(p, cam, vis)
+    M = f["xyz"].shape[0]
+    ups = [rng.normal(size=s).astype(np.float32) for s in ((M, 3), (M, 2), (M, 1), (M, 3), (M, 4))]
+    g = ng.backward(p, f, *ups)
+    r = run_hip(p, cam, vis, ups)
+    # an opacity within rounding of 0 may land on either side of the mask; such pairs are counted, not tolerated in bulk
+    flips = int((r["mask"] != f["mask"]).sum())
+    assert flips <= max(1, int(1e-5 * f["mask"].size)), flips
+    if flips == 0:
+        for key in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
+            parity(key, r[key], f[key])
+        for key in ("anchor_feat", "anchor", "offset", "scaling"):
+            parity("d" + key, r["g_" + key], g[key])
+        for key in PARAM_KEYS:
+            parity("d" + key, r["g_" + key], g[key], rtol=5e-4)
+
+
+def test_decode_edge_cases(hip_lib_built):
+    import torch
+    p, cam, vis, _ = random_case(2000, 6, 7)
+    r = run_hip(p, cam, np.zeros(2000, bool))                          # nothing visible
+    assert r["xyz"].shape == (0, 3) and r["neural_opacity"].shape == (0, 1) and r["mask"].shape == (0,)
+    q = dict(p); q["opacity_b2"] = np.full_like(p["opacity_b2"], -50.0)  # everything masked out
+    ups = [np.zeros(s, np.float32) for s in ((0, 3), (0, 2), (0, 1), (0, 3), (0, 4))]
+    r = run_hip(q, cam, vis, ups)
+    assert r["xyz"].shape == (0, 3) and r["mask"].sum() == 0
+    assert (r["g_anchor_feat"] == 0).all() and (r["g_cov_W1"] == 0).all()
+    r = run_hip(p, cam, None)                                          # visible_mask=None: every anchor
+    f = ng.forward(p, cam, None)
+    assert np.array_equal(r["mask"], f["mask"])
+    parity("xyz", r["xyz"], f["xyz"])
+    # unsupported configurations are refused loudly
+    from neural_gaussians import generate_neural_gaussians
+    pc = build_pc(p); pc.use_feat_bank = True
+    with pytest.raises(NotImplementedError):
+        generate_neural_gaussians(types.SimpleNamespace(camera_center=torch.zeros(3).cuda(), uid=0), pc)
