@@ -25,11 +25,13 @@ extern "C" {
 #endif
 
 /* The four MLPs, in the order opacity, cov, color, raydrop.  Weights in nn.Linear layout: W1 [32][din], b1 [32],
- * W2 [dout][32], b2 [dout] with din = 35 + add_*_dist and dout = k, 7k, k, k. */
+ * W2 [dout][32], b2 [dout] with din = 35 + add_*_dist and dout = k, 7k, k, k.  W2T [32][dout] is W2 transposed: read by
+ * lidargs_ng_backward only (rows of it are what the back-propagation through the second layer walks); may be NULL elsewhere. */
 typedef struct lidargs_ng_model {
     int n_offsets;
     int add_opacity_dist, add_cov_dist, add_color_dist;
     const float* W1[4]; const float* b1[4]; const float* W2[4]; const float* b2[4];
+    const float* W2T[4];
 } lidargs_ng_model;
 
 size_t lidargs_ng_scratch_bytes(int N, int n_offsets);

@@ -19,7 +19,7 @@ namespace lg {
 #define NG_HID 32
 #define NG_IN 36      // feature 32 + view 3 + distance 1
 
-struct NgModel { int k; int din[4]; const float* W1[4]; const float* b1[4]; const float* W2[4]; const float* b2[4]; };
+struct NgModel { int k; int din[4]; const float* W1[4]; const float* b1[4]; const float* W2[4]; const float* b2[4]; const float* W2T[4]; };
 enum { NG_OPA = 0, NG_COV = 1, NG_COL = 2, NG_RD = 3 };
 
 struct NgScratch { uint32_t* vis_flags; uint32_t* vis_idx; uint32_t* sel_flags; uint32_t* slot; uint32_t* totals; uint32_t* scan; };
@@ -143,36 +143,65 @@ __global__ void __launch_bounds__(64) k_ng_decode(int N, NgModel m, float3 cam, 
     }
 }
 
-// delta1 = relu'(h) * (W2^T delta2);  dx += W1^T delta1
+// ---- backward ---------------------------------------------------------------------------------------------------------------
+// The hidden activations of the MLP being processed live in LDS (one column per lane), so the loops over the 32 hidden units
+// are real loops: the fully unrolled formulation (32 x 36 + 32 x 42 FMAs, four times) overwhelmed the register allocator
+// (512 VGPRs + 1600 spilled).  Inputs x, their gradient dx and the output-layer deltas stay in registers.
+#define NG_BLOCK 64
+
+// forward recompute of one MLP: hidden units -> LDS, outputs -> registers
 template <int DOUT>
-__device__ __forceinline__ void ng_mlp_backward(const float* __restrict__ W1, const float* __restrict__ W2, int din, const float (&h)[NG_HID],
-                                                const float (&d2)[DOUT], float (&d1)[NG_HID], float (&dx)[NG_IN]) {
+__device__ __forceinline__ void ng_recompute(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2T,
+                                             const float* __restrict__ b2, int din, const float (&x)[NG_IN], float* __restrict__ s_h, int lane,
+                                             float (&y)[DOUT]) {
+#pragma unroll 1
+    for (int o = 0; o < NG_HID; o++) {
+        const float* w = W1 + o * din;
+        float acc = b1[o];
 #pragma unroll
-    for (int t = 0; t < NG_HID; t++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int o = 0; o < DOUT; o++) acc += W2[o * NG_HID + t] * d2[o];
-        d1[t] = h[t] > 0.f ? acc : 0.f;
+        for (int i = 0; i < NG_IN - 1; i++) acc += w[i] * x[i];
+        if (din == NG_IN) acc += w[NG_IN - 1] * x[NG_IN - 1];
+        s_h[o * NG_BLOCK + lane] = fmaxf(acc, 0.f);
     }
 #pragma unroll
+    for (int o = 0; o < DOUT; o++) y[o] = b2[o];
+#pragma unroll 1
     for (int t = 0; t < NG_HID; t++) {
-        const float* w = W1 + t * din;
-        const float d = d1[t];
+        const float ht = s_h[t * NG_BLOCK + lane];
+        const float* w = W2T + t * DOUT;
 #pragma unroll
-        for (int i = 0; i < NG_IN - 1; i++) dx[i] += w[i] * d;
-        if (din == NG_IN) dx[NG_IN - 1] += w[NG_IN - 1] * d;
+        for (int o = 0; o < DOUT; o++) y[o] += w[o] * ht;
     }
 }
 
-// one of the three k-output MLPs of the backward: WHICH 0 = opacity (tanh), 1 = colour, 2 = ray-drop (sigmoid)
+// delta1 = relu'(h) * (W2^T delta2) -> global (with h);  dx += W1^T delta1
+template <int DOUT>
+__device__ __forceinline__ void ng_backprop(const float* __restrict__ W1, const float* __restrict__ W2T, int din, const float* __restrict__ s_h, int lane,
+                                            const float (&d2)[DOUT], float (&dx)[NG_IN], float* __restrict__ act_h_row, float* __restrict__ delta1_row) {
+#pragma unroll 1
+    for (int t = 0; t < NG_HID; t++) {
+        const float* w2 = W2T + t * DOUT;
+        float acc = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; o++) acc += w2[o] * d2[o];
+        const float ht = s_h[t * NG_BLOCK + lane];
+        const float d = ht > 0.f ? acc : 0.f;
+        act_h_row[t] = ht; delta1_row[t] = d;
+        const float* w1 = W1 + t * din;
+#pragma unroll
+        for (int i = 0; i < NG_IN - 1; i++) dx[i] += w1[i] * d;
+        if (din == NG_IN) dx[NG_IN - 1] += w1[NG_IN - 1] * d;
+    }
+}
+
+// one of the three k-output MLPs: WHICH 0 = opacity (tanh), 1 = colour, 2 = ray-drop (sigmoid)
 template <int K, int MM, int WHICH>
-__device__ __forceinline__ void ng_bw_small(const NgModel& m, const float (&x)[NG_IN], float (&dx)[NG_IN], int i, size_t c, size_t nv,
+__device__ __forceinline__ void ng_bw_small(const NgModel& m, const float (&x)[NG_IN], float (&dx)[NG_IN], int i, size_t c, size_t nv, float* s_h, int lane,
                                             const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
                                             const float* __restrict__ g_opacity, const float* __restrict__ g_color, const float* __restrict__ g_no,
                                             float* __restrict__ act_h, float* __restrict__ delta1, float* __restrict__ d2row) {
-    float h[NG_HID], d1[NG_HID], y[K], d2[K];
-    ng_hidden(m.W1[MM], m.b1[MM], m.din[MM], x, h);
-    ng_output<K>(m.W2[MM], m.b2[MM], h, y);
+    float y[K], d2[K];
+    ng_recompute<K>(m.W1[MM], m.b1[MM], m.W2T[MM], m.b2[MM], m.din[MM], x, s_h, lane, y);
 #pragma unroll
     for (int j = 0; j < K; j++) {
         const bool sel = sel_flags[(size_t)i * K + j] != 0u;
@@ -183,16 +212,14 @@ __device__ __forceinline__ void ng_bw_small(const NgModel& m, const float (&x)[N
         if (WHICH == 0) { const float o = tanhf(y[j]); d2[j] = g * (1.f - o * o); }
         else { const float sg = ng_sigmoid(y[j]); d2[j] = g * sg * (1.f - sg); }
     }
-    ng_mlp_backward<K>(m.W1[MM], m.W2[MM], m.din[MM], h, d2, d1, dx);
-#pragma unroll
-    for (int q = 0; q < NG_HID; q++) { act_h[(MM * nv + c) * NG_HID + q] = h[q]; delta1[(MM * nv + c) * NG_HID + q] = d1[q]; }
+    ng_backprop<K>(m.W1[MM], m.W2T[MM], m.din[MM], s_h, lane, d2, dx, act_h + (MM * nv + c) * NG_HID, delta1 + (MM * nv + c) * NG_HID);
     constexpr int col0 = WHICH == 0 ? 0 : (WHICH == 1 ? 8 * K : 9 * K);          // layout [k | 7k | k | k] = opacity, cov, color, raydrop
 #pragma unroll
     for (int j = 0; j < K; j++) d2row[col0 + j] = d2[j];
 }
 
 template <int K>
-__global__ void __launch_bounds__(64) k_ng_backward(int N, int n_vis, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
+__global__ void __launch_bounds__(NG_BLOCK) k_ng_backward(int N, int n_vis, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
                                                     const float* __restrict__ offset, const float* __restrict__ scaling,
                                                     const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
                                                     const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
@@ -201,6 +228,8 @@ __global__ void __launch_bounds__(64) k_ng_backward(int N, int n_vis, NgModel m,
                                                     float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_offset,
                                                     float* __restrict__ d_scaling, float* __restrict__ act_x, float* __restrict__ act_h,
                                                     float* __restrict__ delta1, float* __restrict__ delta2) {
+    __shared__ float s_h[NG_HID * NG_BLOCK];
+    const int lane = threadIdx.x;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float* df = d_feat + (size_t)i * NG_FEAT;
@@ -213,7 +242,7 @@ __global__ void __launch_bounds__(64) k_ng_backward(int N, int n_vis, NgModel m,
         return;
     }
     const size_t c = vis_idx[i];
-    float x[NG_IN], h[NG_HID], d1[NG_HID], dx[NG_IN];
+    float x[NG_IN], dx[NG_IN];
     ng_input(feat, anchor, cam, i, x);
 #pragma unroll
     for (int q = 0; q < NG_IN; q++) { dx[q] = 0.f; act_x[c * NG_IN + q] = x[q]; }
@@ -226,8 +255,7 @@ __global__ void __launch_bounds__(64) k_ng_backward(int N, int n_vis, NgModel m,
     // --- covariance MLP: scaling = s[3:6] * sigmoid(sr[0:3]), rot = normalize(sr[3:7]); and the direct paths of xyz / scaling
     {
         float sr[7 * K], d2[7 * K];
-        ng_hidden(m.W1[NG_COV], m.b1[NG_COV], m.din[NG_COV], x, h);
-        ng_output<7 * K>(m.W2[NG_COV], m.b2[NG_COV], h, sr);
+        ng_recompute<7 * K>(m.W1[NG_COV], m.b1[NG_COV], m.W2T[NG_COV], m.b2[NG_COV], m.din[NG_COV], x, s_h, lane, sr);
 #pragma unroll
         for (int j = 0; j < K; j++) {
             const bool sel = sel_flags[(size_t)i * K + j] != 0u;
@@ -253,16 +281,15 @@ __global__ void __launch_bounds__(64) k_ng_backward(int N, int n_vis, NgModel m,
             d2[7 * j + 3] = (gr0 - r0 * dotp) / qn; d2[7 * j + 4] = (gr1 - r1 * dotp) / qn;
             d2[7 * j + 5] = (gr2 - r2 * dotp) / qn; d2[7 * j + 6] = (gr3 - r3 * dotp) / qn;
         }
-        ng_mlp_backward<7 * K>(m.W1[NG_COV], m.W2[NG_COV], m.din[NG_COV], h, d2, d1, dx);
-#pragma unroll
-        for (int q = 0; q < NG_HID; q++) { act_h[(NG_COV * nv + c) * NG_HID + q] = h[q]; delta1[(NG_COV * nv + c) * NG_HID + q] = d1[q]; }
+        ng_backprop<7 * K>(m.W1[NG_COV], m.W2T[NG_COV], m.din[NG_COV], s_h, lane, d2, dx, act_h + (NG_COV * nv + c) * NG_HID,
+                           delta1 + (NG_COV * nv + c) * NG_HID);
 #pragma unroll
         for (int q = 0; q < 7 * K; q++) d2row[K + q] = d2[q];
     }
     // --- opacity (tanh), colour and ray-drop (sigmoid) MLPs
-    ng_bw_small<K, NG_OPA, 0>(m, x, dx, i, c, nv, sel_flags, slot, g_opacity, g_color, g_no, act_h, delta1, d2row);
-    ng_bw_small<K, NG_COL, 1>(m, x, dx, i, c, nv, sel_flags, slot, g_opacity, g_color, g_no, act_h, delta1, d2row);
-    ng_bw_small<K, NG_RD, 2>(m, x, dx, i, c, nv, sel_flags, slot, g_opacity, g_color, g_no, act_h, delta1, d2row);
+    ng_bw_small<K, NG_OPA, 0>(m, x, dx, i, c, nv, s_h, lane, sel_flags, slot, g_opacity, g_color, g_no, act_h, delta1, d2row);
+    ng_bw_small<K, NG_COL, 1>(m, x, dx, i, c, nv, s_h, lane, sel_flags, slot, g_opacity, g_color, g_no, act_h, delta1, d2row);
+    ng_bw_small<K, NG_RD, 2>(m, x, dx, i, c, nv, s_h, lane, sel_flags, slot, g_opacity, g_color, g_no, act_h, delta1, d2row);
     // --- input: feature directly; view = ob/|ob|, dist = |ob| back to the anchor position
 #pragma unroll
     for (int q = 0; q < NG_FEAT; q++) df[q] = dx[q];
@@ -291,7 +318,7 @@ int ng_model(const lidargs_ng_model* in, lg::NgModel* out) {
     out->din[lg::NG_COL] = out->din[lg::NG_RD] = 35 + (in->add_color_dist ? 1 : 0);
     for (int m = 0; m < 4; m++) {
         if (!in->W1[m] || !in->b1[m] || !in->W2[m] || !in->b2[m]) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "neural_gaussians: NULL weight pointer");
-        out->W1[m] = in->W1[m]; out->b1[m] = in->b1[m]; out->W2[m] = in->W2[m]; out->b2[m] = in->b2[m];
+        out->W1[m] = in->W1[m]; out->b1[m] = in->b1[m]; out->W2[m] = in->W2[m]; out->b2[m] = in->b2[m]; out->W2T[m] = in->W2T[m];
     }
     return 0;
 }
@@ -362,6 +389,7 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
     if (N <= 0) return 0;
     if (!anchor_feat || !anchor || !offset || !scaling || !cam_center || !dL_danchor_feat || !dL_danchor || !dL_doffset || !dL_dscaling_in || !scratch)
         return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward: NULL pointer");
+    for (int q = 0; q < 4; q++) if (!m.W2T[q]) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward: model.W2T (transposed second-layer weights) is required");
     if (n_visible > 0 && (!act_x || !act_h || !delta1 || !delta2)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward: NULL activation buffer");
     if (scratch_bytes < lidargs_ng_scratch_bytes(N, m.k)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward: scratch too small");
     lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)m.k, &s);

@@ -20,7 +20,7 @@ MLP_ORDER = ("opacity", "cov", "color", "raydrop")
 
 class _Model(C.Structure):
     _fields_ = [("n_offsets", C.c_int), ("add_opacity_dist", C.c_int), ("add_cov_dist", C.c_int), ("add_color_dist", C.c_int),
-                ("W1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("W2", C.c_void_p * 4), ("b2", C.c_void_p * 4)]
+                ("W1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("W2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("W2T", C.c_void_p * 4)]
 
 
 for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward"):
@@ -33,11 +33,12 @@ def _check(rc, what):
         _base._raise(rc, what)
 
 
-def _model_struct(k, flags, params):
+def _model_struct(k, flags, params, w2t=None):
     m = _Model()
     m.n_offsets, m.add_opacity_dist, m.add_cov_dist, m.add_color_dist = k, int(flags[0]), int(flags[1]), int(flags[2])
     for i in range(4):
         m.W1[i], m.b1[i], m.W2[i], m.b2[i] = (params[4 * i + j].data_ptr() for j in range(4))
+        m.W2T[i] = w2t[i].data_ptr() if w2t is not None else None
     return m
 
 
@@ -87,7 +88,8 @@ class _Decode(torch.autograd.Function):
         params = ctx.saved_tensors[5:]
         N, k, n, M, cam, flags = ctx.meta
         dev = anchor.device
-        model = _model_struct(k, flags, params)
+        w2t = [params[4 * i + 2].t().contiguous() for i in range(4)]        # the backward walks W2 by columns
+        model = _model_struct(k, flags, params, w2t)
         camv = (C.c_float * 3)(*cam)
         f = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous()
         g_xyz, g_color, g_opacity = f(g_xyz, (M, 3)), f(g_color, (M, 2)), f(g_opacity, (M, 1))
@@ -114,9 +116,17 @@ class _Decode(torch.autograd.Function):
         cols = {"opacity": (0, k), "cov": (k, 8 * k), "color": (8 * k, 9 * k), "raydrop": (9 * k, 10 * k)}
         dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
         g_params = []
+        # [n, a]^T [n, b] with n ~ 1e5..1e6 and a, b <= 70 is a reduction, not a GEMM shape: a plain mm picks a one-tile kernel
+        # that walks all of n serially (0.5 ms each).  Split n into chunks -> batched GEMM of partial products + a small sum.
+        def tn(a, b):
+            rows = a.shape[0]
+            S = max(1, min(512, rows // 512))
+            cut = (rows // S) * S
+            out = torch.bmm(a[:cut].view(S, cut // S, a.shape[1]).transpose(1, 2), b[:cut].view(S, cut // S, b.shape[1])).sum(0)
+            return out + a[cut:].t() @ b[cut:] if cut < rows else out
         for i, name in enumerate(MLP_ORDER):
-            d2 = delta2[:, cols[name][0]:cols[name][1]]
-            g_params += [delta1[i].t() @ act_x[:, :dins[i]], delta1[i].sum(0), d2.t() @ act_h[i], d2.sum(0)]
+            d2 = delta2[:, cols[name][0]:cols[name][1]].contiguous()
+            g_params += [tn(delta1[i], act_x[:, :dins[i]].contiguous()), delta1[i].sum(0), tn(d2, act_h[i]), d2.sum(0)]
         return (d_feat, d_anchor, d_offset, d_scaling, *g_params, None, None, None)
 
 
