@@ -140,6 +140,79 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
         "roofline": None, "cpu_baseline": None}))
 
 
+def bench_decode(args):
+    """the fused anchor decode (generate_neural_gaussians), forward + backward, single GPU.
+    333 334 anchors x 6 offsets = the 2 M candidate Gaussians of the headline frame; not the headline line."""
+    import types
+    import numpy as np
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    from neural_gaussians import generate_neural_gaussians
+    from test_neural_gaussians_gpu import build_pc, random_case
+    N, k = 333_334, 6
+    p, cam, vis, _rng = random_case(N, k, 5)
+    pc = build_pc(p)
+    camera = types.SimpleNamespace(camera_center=torch.from_numpy(cam).cuda(), uid=0)
+    vmask = torch.from_numpy(vis).cuda()
+    mlps = [getattr(pc, "mlp_" + m) for m in ("opacity", "cov", "color", "raydrop")]
+    leaves = [pc._anchor_feat, pc._anchor, pc._offset, pc.get_scaling] + [t for m in mlps for t in m.parameters()]
+
+    def step(fn):
+        for t in leaves:
+            t.grad = None
+        xyz, color, opacity, scaling, rot = fn()[:5]
+        (xyz.sum() + color.sum() + opacity.sum() + scaling.sum() + rot.sum()).backward()
+        return xyz.shape[0]
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            M = step(fn)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            M = step(fn)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, M
+
+    t_hip, M = timed(lambda: generate_neural_gaussians(camera, pc, vmask, is_training=True), args.steps, args.warmup)
+    n_vis = int(vis.sum())
+    # algorithmic bytes: inputs once per visible anchor + the bool mask, outputs once, and the same again (+ upstream gradients,
+    # dense input gradients) for the backward; the per-anchor activations the weight-gradient GEMMs read are NOT counted
+    fwd_b = N + n_vis * (128 + 12 + 12 * k + 24) + n_vis * k * 5 + M * 52
+    bwd_b = n_vis * (128 + 12 + 12 * k + 24) + M * 52 + N * (128 + 12 + 12 * k + 24)
+    out = {"metric": "anchor decode (generate_neural_gaussians) fwd+bwd per second", "value": 1.0 / t_hip, "unit": "decodes/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_hip * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"decode: {N} anchors x {k} offsets, {n_vis} visible, {M} Gaussians out, feat 32, hidden 32, "
+                                  f"add_*_dist on (the reference's default model, arguments/__init__.py:51-79)"},
+           "roofline": {"bound": "hbm", "kernel": "k_ng_opacity + k_ng_decode + k_ng_backward + weight-gradient GEMMs (whole step)",
+                        "achieved": (fwd_b + bwd_b) / t_hip / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (fwd_b + bwd_b) / t_hip / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    if not args.no_cpu_baseline:
+        from oracle import neural_gaussians as ng
+        from oracle import neural_gaussians_torch as ngt
+        params = {m: (seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias) for m, seq in zip(("opacity", "cov", "color", "raydrop"), mlps)}
+        flags = (p["add_opacity_dist"], p["add_cov_dist"], p["add_color_dist"])
+        t_eager, _ = timed(lambda: ngt.generate(pc._anchor_feat, pc._anchor, pc._offset, pc.get_scaling, params, camera.camera_center, vmask, flags),
+                           max(3, args.steps // 5), 2)
+        Ns = N // 20
+        ps, cams, viss, rng = random_case(Ns, k, 5)
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 10.0:
+            f = ng.forward(ps, cams, viss)
+            Ms = f["xyz"].shape[0]
+            ng.backward(ps, f, *[np.ones(sh, np.float32) for sh in ((Ms, 3), (Ms, 2), (Ms, 1), (Ms, 3), (Ms, 4))])
+            reps += 1
+        t_cpu = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": 1.0 / (t_cpu * 20), "unit": "decodes/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{reps} fwd+bwd of a {Ns}-anchor (1/20) case with oracle/neural_gaussians.py (numpy, BLAS threads as configured), "
+                                         f"scaled linearly to the full size",
+                               "framework_ops_same_gpu_ms": t_eager * 1e3}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +222,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.workload == "decode":
+        return bench_decode(args)
     import lidargs_scenes as sc
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
     if args.workload == "cfg5":
