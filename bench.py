@@ -213,6 +213,61 @@ def bench_decode(args):
     print(json.dumps(out))
 
 
+def bench_loss(args):
+    """the fused per-frame image loss + its gradient at the headline image size (64 x 2650)."""
+    import numpy as np
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    from lidar_loss import image_loss
+    H, W = 64, 2650
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    image = t(rng.random((2, H, W), dtype=np.float32)).requires_grad_(True)
+    depth = t((rng.random((1, H, W), dtype=np.float32) * 70).astype(np.float32)).requires_grad_(True)
+    gt = t(np.stack([(rng.random((H, W)) > 0.2).astype(np.float32), rng.random((H, W), dtype=np.float32),
+                     np.cumsum(rng.normal(scale=0.004, size=(H, W)), axis=1).astype(np.float32) + 20.0]))
+
+    def step(fn):
+        image.grad = None; depth.grad = None
+        fn().backward()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            step(fn)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            step(fn)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    t_hip = timed(lambda: image_loss(image, depth, gt, 0.2)["loss"], args.steps, args.warmup)
+    N = H * W
+    bytes_alg = (6 + 3) * 4 * N          # three inputs planes + three gt planes read once, three gradient planes written once
+    out = {"metric": "per-frame image loss + gradient (train.py:150-203) per second", "value": 1.0 / t_hip, "unit": "losses/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_hip * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"loss: L1 intensity + L1 depth + 10 MSE ray-drop + (1 - SSIM 11x11) + masked depth-difference L1 on a {H}x{W} frame, "
+                                  f"value and gradient, lambda_dssim 0.2"},
+           "roofline": {"bound": "hbm", "kernel": "k_loss_pointwise + 4 separable SSIM passes + k_loss_finish (whole step, launch-latency bound)",
+                        "achieved": bytes_alg / t_hip / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_alg / t_hip / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None}}
+    if not args.no_cpu_baseline:
+        from oracle import lidar_loss as ol
+        from oracle import lidar_loss_torch as olt
+        t_eager = timed(lambda: olt.image_loss(image, depth, gt, 0.2), max(5, args.steps // 3), 3)
+        im, dp, g = image.detach().cpu().numpy(), depth.detach().cpu().numpy(), gt.cpu().numpy()
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            ol.forward_backward(im, dp, g, 0.2); reps += 1
+        out["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "losses/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} full-size evaluations of oracle/lidar_loss.py (numpy, one thread)",
+                               "framework_ops_same_gpu_ms": t_eager * 1e3}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +279,8 @@ def main():
 
     if args.workload == "decode":
         return bench_decode(args)
+    if args.workload == "loss":
+        return bench_loss(args)
     import lidargs_scenes as sc
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
     if args.workload == "cfg5":

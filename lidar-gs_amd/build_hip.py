@@ -26,6 +26,7 @@ SOURCES = {
     "binning.hip": [],
     "render.hip": [],
     "neural_gaussians.hip": [],
+    "lidar_loss.hip": [],
     "surfel.hip": ["-ffp-contract=off"],   # ray/plane hit point cancels ~3 digits: round as the reference writes it
 }
 
