@@ -268,6 +268,77 @@ def bench_loss(args):
     print(json.dumps(out))
 
 
+def bench_train_step(args):
+    """The three fused components chained as a training step would run them: anchor decode (f1) -> rasterizer -> image loss (f2)
+    -> backward down to anchor features, offsets and MLP weights.  666 667 anchors of the 2 M street scene x 6 offsets."""
+    import types
+    import numpy as np
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    import lidargs_scenes as sc
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from lidar_loss import image_loss
+    from neural_gaussians import generate_neural_gaussians
+    from test_neural_gaussians_gpu import build_pc, random_case
+    from util import make_settings
+    kind, P, H, W, seed = sc.BASELINE_CONFIGS["cfg3"]
+    N, k = 666_667, 6
+    scene = sc.make_scene(kind, N, H, seed)
+    p, _cam, _vis, rng = random_case(N, k, seed)
+    p["anchor"] = scene["means3D"].astype(np.float32)
+    p["offset"] = (0.5 * rng.normal(size=(N, k, 3))).astype(np.float32)
+    p["scaling"] = np.concatenate([np.full((N, 3), 0.3, np.float32), scene["scales"].astype(np.float32) * 2.0], 1)   # sigmoid halves them on average
+    pc = build_pc(p)
+    camera = types.SimpleNamespace(camera_center=torch.zeros(3).cuda(), uid=0)
+    st = {k_: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k_, v in scene.items() if k_ in ("viewmatrix", "beams", "bg")}
+    rast = GaussianRasterizer(make_settings(st, W, H))
+    gt = torch.from_numpy(np.stack([(rng.random((H, W)) > 0.2).astype(np.float32), rng.random((H, W), dtype=np.float32),
+                                    (rng.random((H, W)) * 60).astype(np.float32)])).cuda()
+    mlps = [getattr(pc, "mlp_" + m) for m in ("opacity", "cov", "color", "raydrop")]
+    leaves = [pc._anchor_feat, pc._anchor, pc._offset, pc.get_scaling] + [t for m in mlps for t in m.parameters()]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    acc = [0.0, 0.0, 0.0, 0.0]
+    info = {}
+
+    def step(record):
+        for t in leaves:
+            t.grad = None
+        ev[0].record()
+        xyz, color, opacity, scaling, rot, _no, _m = generate_neural_gaussians(camera, pc, None, is_training=True)
+        ev[1].record()
+        means2D = torch.zeros((xyz.shape[0], 4), device="cuda", requires_grad=True)
+        image, depth, _occ, radii = rast(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color, scales=scaling, rotations=rot)
+        ev[2].record()
+        loss = image_loss(image, depth, gt, 0.2)["loss"] + 0.01 * scaling.prod(dim=1).mean()
+        ev[3].record()
+        loss.backward()
+        ev[4].record()
+        if record:
+            torch.cuda.synchronize()
+            for q in range(4):
+                acc[q] += ev[q].elapsed_time(ev[q + 1])
+            info.update(gaussians=int(xyz.shape[0]), visible=int((radii > 0).sum()))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / args.steps
+    for _ in range(5):
+        step(True)
+    print(json.dumps({
+        "metric": "training-step core (decode + rasterize + loss, fwd+bwd) per second", "value": 1.0 / t_step, "unit": "steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"train_step: {N} anchors x {k} offsets -> {info.get('gaussians')} Gaussians ({info.get('visible')} on screen) @ {H}x{W}; "
+                               f"generate_neural_gaussians + GaussianRasterizer + image loss, backward to anchors and MLP weights"},
+        "stage_ms": {"decode_fwd": acc[0] / 5, "rasterize_fwd": acc[1] / 5, "loss_fwd+grad": acc[2] / 5, "backward(raster+decode)": acc[3] / 5},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +352,8 @@ def main():
         return bench_decode(args)
     if args.workload == "loss":
         return bench_loss(args)
+    if args.workload == "train_step":
+        return bench_train_step(args)
     import lidargs_scenes as sc
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
     if args.workload == "cfg5":

@@ -47,7 +47,7 @@ def to_torch(scene, device="cuda"):
 def make_settings(scene_t, W, H, far=80, near=0, scale_modifier=1.0, debug=False):
     import torch
     from diff_lidargs_rasterization import GaussianRasterizationSettings
-    dev = scene_t["means3D"].device
+    dev = scene_t["viewmatrix"].device
     # same construction as gaussian_renderer/__init__.py:150-166
     return GaussianRasterizationSettings(
         image_height=int(H), image_width=int(W), tanfovx=1.0, tanfovy=1.0, bg=scene_t["bg"], scale_modifier=scale_modifier,
