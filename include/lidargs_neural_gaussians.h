@@ -60,8 +60,11 @@ int lidargs_ng_forward_decode(int N, const lidargs_ng_model* model, const float*
  * output) may be NULL -- the reference only uses that output as a statistic (train.py:243).  Writes, for every one of the N anchors (zeros for
  * invisible ones): dL_danchor_feat f32[N*32], dL_danchor f32[N*3], dL_doffset f32[N*k*3], dL_dscaling f32[N*6]; and for
  * the n visible anchors, in anchor order, the per-anchor layer inputs and deltas the weight gradients are plain GEMMs of:
- *   act_x f32[n*36] (feature, view, dist), act_h f32[4][n*32] (ReLU outputs), delta1 f32[4][n*32], delta2 f32[n*(10k)]
- *   laid out [n][k | 7k | k | k]:  dW2_m = delta2_m^T act_h_m,  dW1_m = delta1_m^T act_x[:, :din_m],  db = column sums.
+ *   act_x  f32[n][40]   the 36 inputs (feature, view, dist), a constant 1, three zeros
+ *   act_h  f32[n][132]  the ReLU outputs of the four MLPs (opacity, cov, color, raydrop: 32 each), a constant 1, three zeros
+ *   delta1 f32[n][128]  hidden-layer deltas of the four MLPs;   delta2 f32[n][10k]  output deltas laid out [k | 7k | k | k]
+ * so that  G1 = delta1^T act_x  [128 x 40]  holds dW1_m in rows 32m..32m+31, columns 0..din_m-1, and db1_m in column 36;
+ *          G2 = delta2^T act_h  [10k x 132] holds dW2_m in its row block, columns 32m..32m+31, and db2_m in column 128.
  * Must follow forward_select/forward_decode of the same inputs with the same scratch (the selection is reused). */
 int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, const float* anchor_feat, const float* anchor,
                         const float* offset, const float* scaling, const float* cam_center,

@@ -148,6 +148,8 @@ __global__ void __launch_bounds__(64) k_ng_decode(int N, NgModel m, float3 cam, 
 // are real loops: the fully unrolled formulation (32 x 36 + 32 x 42 FMAs, four times) overwhelmed the register allocator
 // (512 VGPRs + 1600 spilled).  Inputs x, their gradient dx and the output-layer deltas stay in registers.
 #define NG_BLOCK 64
+#define NG_XS 40     // row stride of act_x: 36 inputs, a constant 1 (bias gradients fall out of the same GEMM), 3 zeros
+#define NG_HS 132    // row stride of act_h: 4 x 32 hidden units, a constant 1, 3 zeros
 
 // forward recompute of one MLP: hidden units -> LDS, outputs -> registers
 template <int DOUT>
@@ -212,7 +214,7 @@ __device__ __forceinline__ void ng_bw_small(const NgModel& m, const float (&x)[N
         if (WHICH == 0) { const float o = tanhf(y[j]); d2[j] = g * (1.f - o * o); }
         else { const float sg = ng_sigmoid(y[j]); d2[j] = g * sg * (1.f - sg); }
     }
-    ng_backprop<K>(m.W1[MM], m.W2T[MM], m.din[MM], s_h, lane, d2, dx, act_h + (MM * nv + c) * NG_HID, delta1 + (MM * nv + c) * NG_HID);
+    ng_backprop<K>(m.W1[MM], m.W2T[MM], m.din[MM], s_h, lane, d2, dx, act_h + c * NG_HS + MM * NG_HID, delta1 + c * (4 * NG_HID) + MM * NG_HID);
     constexpr int col0 = WHICH == 0 ? 0 : (WHICH == 1 ? 8 * K : 9 * K);          // layout [k | 7k | k | k] = opacity, cov, color, raydrop
 #pragma unroll
     for (int j = 0; j < K; j++) d2row[col0 + j] = d2[j];
@@ -245,7 +247,9 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward(int N, int n_vis, NgMo
     float x[NG_IN], dx[NG_IN];
     ng_input(feat, anchor, cam, i, x);
 #pragma unroll
-    for (int q = 0; q < NG_IN; q++) { dx[q] = 0.f; act_x[c * NG_IN + q] = x[q]; }
+    for (int q = 0; q < NG_IN; q++) { dx[q] = 0.f; act_x[c * NG_XS + q] = x[q]; }
+    act_x[c * NG_XS + 36] = 1.f; act_x[c * NG_XS + 37] = 0.f; act_x[c * NG_XS + 38] = 0.f; act_x[c * NG_XS + 39] = 0.f;
+    act_h[c * NG_HS + 128] = 1.f; act_h[c * NG_HS + 129] = 0.f; act_h[c * NG_HS + 130] = 0.f; act_h[c * NG_HS + 131] = 0.f;
     const float* sc = scaling + 6 * (size_t)i;
     const float s0 = sc[0], s1 = sc[1], s2 = sc[2], s3 = sc[3], s4 = sc[4], s5 = sc[5];
     float ds[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, da[3] = {0.f, 0.f, 0.f};
@@ -281,8 +285,8 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward(int N, int n_vis, NgMo
             d2[7 * j + 3] = (gr0 - r0 * dotp) / qn; d2[7 * j + 4] = (gr1 - r1 * dotp) / qn;
             d2[7 * j + 5] = (gr2 - r2 * dotp) / qn; d2[7 * j + 6] = (gr3 - r3 * dotp) / qn;
         }
-        ng_backprop<7 * K>(m.W1[NG_COV], m.W2T[NG_COV], m.din[NG_COV], s_h, lane, d2, dx, act_h + (NG_COV * nv + c) * NG_HID,
-                           delta1 + (NG_COV * nv + c) * NG_HID);
+        ng_backprop<7 * K>(m.W1[NG_COV], m.W2T[NG_COV], m.din[NG_COV], s_h, lane, d2, dx, act_h + c * NG_HS + NG_COV * NG_HID,
+                           delta1 + c * (4 * NG_HID) + NG_COV * NG_HID);
 #pragma unroll
         for (int q = 0; q < 7 * K; q++) d2row[K + q] = d2[q];
     }

@@ -101,9 +101,9 @@ class _Decode(torch.autograd.Function):
         d_anchor = dense[o:o + N * 3].view(N, 3); o += N * 3
         d_offset = dense[o:o + N * 3 * k].view(N, k, 3); o += N * 3 * k
         d_scaling = dense[o:o + N * 6].view(N, 6)
-        act_x = torch.empty((n, 36), dtype=torch.float32, device=dev)
-        act_h = torch.empty((4, n, 32), dtype=torch.float32, device=dev)
-        delta1 = torch.empty((4, n, 32), dtype=torch.float32, device=dev)
+        act_x = torch.empty((n, 40), dtype=torch.float32, device=dev)
+        act_h = torch.empty((n, 132), dtype=torch.float32, device=dev)
+        delta1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
         delta2 = torch.empty((n, 10 * k), dtype=torch.float32, device=dev)
         p = _base._ptr
         if N:
@@ -112,21 +112,24 @@ class _Decode(torch.autograd.Function):
                                                 p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
                                                 p(d_offset), p(d_scaling), p(act_x), p(act_h), p(delta1), p(delta2), p(scratch),
                                                 C.c_size_t(scratch.numel()), _base._stream(dev)), "lidargs_ng_backward")
-        # weight gradients: plain GEMMs of the per-anchor layer inputs and deltas (library GEMMs, not a kernel of ours)
-        cols = {"opacity": (0, k), "cov": (k, 8 * k), "color": (8 * k, 9 * k), "raydrop": (9 * k, 10 * k)}
-        dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
-        g_params = []
-        # [n, a]^T [n, b] with n ~ 1e5..1e6 and a, b <= 70 is a reduction, not a GEMM shape: a plain mm picks a one-tile kernel
-        # that walks all of n serially (0.5 ms each).  Split n into chunks -> batched GEMM of partial products + a small sum.
+        # Weight and bias gradients: two [a x n] [n x b] reductions (library GEMMs, not a kernel of ours).  With n ~ 1e5..1e6 and
+        # a, b <= 132 a plain mm picks a one-tile kernel that walks all of n serially (0.5 ms each), so n is split into chunks:
+        # a batched GEMM of partial products plus a small sum.
         def tn(a, b):
             rows = a.shape[0]
+            if rows == 0:
+                return torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float32, device=dev)
             S = max(1, min(512, rows // 512))
             cut = (rows // S) * S
             out = torch.bmm(a[:cut].view(S, cut // S, a.shape[1]).transpose(1, 2), b[:cut].view(S, cut // S, b.shape[1])).sum(0)
             return out + a[cut:].t() @ b[cut:] if cut < rows else out
-        for i, name in enumerate(MLP_ORDER):
-            d2 = delta2[:, cols[name][0]:cols[name][1]].contiguous()
-            g_params += [tn(delta1[i], act_x[:, :dins[i]].contiguous()), delta1[i].sum(0), tn(d2, act_h[i]), d2.sum(0)]
+        G1, G2 = tn(delta1, act_x), tn(delta2, act_h)                  # [128, 40], [10k, 132]
+        cols = ((0, k), (k, 8 * k), (8 * k, 9 * k), (9 * k, 10 * k))
+        dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
+        g_params = []
+        for i in range(4):
+            r0, r1 = cols[i]
+            g_params += [G1[32 * i:32 * i + 32, :dins[i]], G1[32 * i:32 * i + 32, 36], G2[r0:r1, 32 * i:32 * i + 32], G2[r0:r1, 128]]
         return (d_feat, d_anchor, d_offset, d_scaling, *g_params, None, None, None)
 
 
