@@ -339,6 +339,51 @@ def bench_train_step(args):
         "roofline": None, "cpu_baseline": None}))
 
 
+def bench_chamfer(args):
+    """nearest-neighbour (chamfer) distances between two 169 600-point clouds (one 64 x 2650 frame each),
+    both directions, as PointsMeter evaluates them (utils/lidar_utils.py:261-275)."""
+    import numpy as np
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    import chamfer_3D
+    n = m = 64 * 2650
+    rng = np.random.default_rng(9)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = (d * rng.uniform(3, 70, size=(n, 1))).astype(np.float32)
+    b = (a + rng.normal(scale=0.05, size=a.shape)).astype(np.float32)[rng.permutation(n)]
+    ta, tb = torch.from_numpy(a[None]).cuda(), torch.from_numpy(b[None]).cuda()
+    d1, d2 = torch.empty(1, n, device="cuda"), torch.empty(1, m, device="cuda")
+    i1, i2 = torch.empty(1, n, dtype=torch.int32, device="cuda"), torch.empty(1, m, dtype=torch.int32, device="cuda")
+    for _ in range(max(1, args.warmup // 3)):
+        chamfer_3D.forward(ta, tb, d1, d2, i1, i2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = max(3, args.steps // 5)
+    for _ in range(steps):
+        chamfer_3D.forward(ta, tb, d1, d2, i1, i2)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    pairs = 2.0 * n * m
+    out = {"metric": "chamfer nearest-neighbour evaluations (both directions) per second", "value": 1.0 / t, "unit": "evaluations/s", "n_gpus": 1,
+           "steps": steps, "warmup": max(1, args.warmup // 3), "ms_per_step": t * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"chamfer: two clouds of {n} points (one 64x2650 frame each), squared distance + index of the nearest neighbour, both directions",
+                      "chamfer_distance": float(d1.mean() + d2.mean())},
+           "roofline": {"bound": "valu", "kernel": "k_chamfer_nn (x2)", "achieved": pairs * 8 / t / 1e12, "peak": 78.6, "unit": "TFLOP/s (fp32 vector, unpacked; 8 flop per point pair as the reference writes it)",
+                        "frac": pairs * 8 / t / 1e12 / 78.6, "traffic": None}}
+    if not args.no_cpu_baseline:
+        from oracle import chamfer3d
+        ns = 4000
+        t0 = time.perf_counter()
+        chamfer3d.nearest(a[:ns], b)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / (tc * (n / ns) * 2), "unit": "evaluations/s", "cores": 1, "kind": "port",
+                               "sample": f"{ns} queries against the full {m}-point cloud with oracle/chamfer3d.py (numpy), scaled to 2 x {n} queries"}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,6 +399,8 @@ def main():
         return bench_loss(args)
     if args.workload == "train_step":
         return bench_train_step(args)
+    if args.workload == "chamfer":
+        return bench_chamfer(args)
     import lidargs_scenes as sc
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
     if args.workload == "cfg5":

@@ -244,6 +244,23 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward(int N, int n_vis, NgMo
         return;
     }
     const size_t c = vis_idx[i];
+    if (!g_no) {
+        // an anchor none of whose offsets survived the opacity mask receives no gradient at all: every output-layer delta is 0
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < K; j++) any = any || sel_flags[(size_t)i * K + j] != 0u;
+        if (!any) {
+            for (int q = 0; q < NG_FEAT; q++) df[q] = 0.f;
+            for (int q = 0; q < 3 * K; q++) dofs[q] = 0.f;
+            for (int q = 0; q < 3; q++) d_anchor[3 * (size_t)i + q] = 0.f;
+            for (int q = 0; q < 6; q++) d_scaling[6 * (size_t)i + q] = 0.f;
+            for (int q = 0; q < NG_XS; q++) act_x[c * NG_XS + q] = 0.f;
+            for (int q = 0; q < NG_HS; q++) act_h[c * NG_HS + q] = 0.f;
+            for (int q = 0; q < 4 * NG_HID; q++) delta1[c * (4 * NG_HID) + q] = 0.f;
+            for (int q = 0; q < 10 * K; q++) delta2[c * (size_t)(10 * K) + q] = 0.f;
+            return;
+        }
+    }
     float x[NG_IN], dx[NG_IN];
     ng_input(feat, anchor, cam, i, x);
 #pragma unroll
