@@ -12,6 +12,7 @@ from diff_lidargs_rasterization import _C as _base
 _lib = _base._lib
 _lib.lidargs_chamfer_forward.restype = C.c_int
 _lib.lidargs_chamfer_backward.restype = C.c_int
+_lib.lidargs_chamfer_scratch_bytes.restype = C.c_size_t
 
 
 def _chk(t, name, dtype):
@@ -27,9 +28,11 @@ def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     _chk(idx1, "idx1", torch.int32); _chk(idx2, "idx2", torch.int32)
     B, n, m = int(xyz1.shape[0]), int(xyz1.shape[1]), int(xyz2.shape[1])
     p = _base._ptr
+    nb = int(_lib.lidargs_chamfer_scratch_bytes(C.c_int(B), C.c_int(n), C.c_int(m)))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
         rc = _lib.lidargs_chamfer_forward(C.c_int(B), C.c_int(n), C.c_int(m), p(xyz1), p(xyz2), p(dist1), p(dist2), p(idx1), p(idx2),
-                                          _base._stream(xyz1.device))
+                                          p(scratch), C.c_size_t(nb), _base._stream(xyz1.device))
     if rc < 0:
         _base._raise(rc, "chamfer_3D.forward")
     return 1
