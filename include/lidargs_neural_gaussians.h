@@ -73,6 +73,17 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
                         float* dL_dscaling_in, float* act_x, float* act_h, float* delta1, float* delta2,
                         char* scratch, size_t scratch_bytes, void* stream);
 
+/* Densification statistics -- GaussianModel.training_statis (scene/gaussian_model.py:599-622), in place, one launch chain, no host
+ * read.  anchor_visible_mask u8[N]; offset_selection_mask u8[n*k] and neural_opacity f32[n*k] in visible-anchor order (what
+ * generate_neural_gaussians returned); update_filter u8[M] (radii > 0) and viewspace_grad f32[M*4] (means2D.grad) in the order of
+ * the selected pairs.  Updates opacity_accum f32[N] += sum_j max(opacity, 0), anchor_demon f32[N] += 1 (visible anchors),
+ * offset_gradient_accum f32[N*k] += |grad[2:4]| and offset_denom f32[N*k] += 1 (selected pairs whose Gaussian was on screen).
+ * scratch: lidargs_ng_scratch_bytes(N, k). */
+int lidargs_ng_training_stats(int N, int n_offsets, const uint8_t* anchor_visible_mask, const uint8_t* offset_selection_mask,
+                              const uint8_t* update_filter, const float* neural_opacity, const float* viewspace_grad,
+                              float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
+                              char* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -325,6 +325,41 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward(int N, int n_vis, NgMo
     for (int q = 0; q < 6; q++) d_scaling[6 * (size_t)i + q] = ds[q];
 }
 
+// ---- densification statistics (scene/gaussian_model.py:599-622) ------------------------------------------------------------
+// flags of the selected pairs in GLOBAL (anchor, offset) order, from the compact mask the decode returned
+__global__ void __launch_bounds__(256) k_ng_stats_flags(int N, int K, const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
+                                                        const uint8_t* __restrict__ sel_mask, uint32_t* __restrict__ sel_flags) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)N * K) return;
+    const size_t i = t / K, j = t - i * K;
+    sel_flags[t] = (vis_flags[i] && sel_mask[(size_t)vis_idx[i] * K + j]) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_ng_stats(int N, int K, const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
+                                                  const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
+                                                  const uint8_t* __restrict__ update_filter, const float* __restrict__ opacity,
+                                                  const float* __restrict__ grad, float* __restrict__ opacity_accum, float* __restrict__ anchor_demon,
+                                                  float* __restrict__ grad_accum, float* __restrict__ denom) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || !vis_flags[i]) return;
+    const size_t c = vis_idx[i];
+    float osum = 0.f;
+    for (int j = 0; j < K; j++) {
+        osum += fmaxf(opacity[c * K + j], 0.f);                         // :601-604
+        const size_t p = (size_t)i * K + j;
+        if (sel_flags[p]) {
+            const size_t r = slot[p];
+            if (update_filter[r]) {                                     // :614-620
+                const float gx = grad[4 * r + 2], gy = grad[4 * r + 3];
+                grad_accum[p] += sqrtf(gx * gx + gy * gy);
+                denom[p] += 1.f;
+            }
+        }
+    }
+    opacity_accum[i] += osum;                                           // :605
+    anchor_demon[i] += 1.f;                                             // :608
+}
+
 }  // namespace lg
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -418,6 +453,29 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
     NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, n_visible, m, cam, anchor_feat, anchor, offset,
                                         scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
                                         dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, act_x, act_h, delta1, delta2));
+    NG_HIP(hipGetLastError());
+    return 0;
+}
+
+int lidargs_ng_training_stats(int N, int n_offsets, const uint8_t* anchor_visible_mask, const uint8_t* offset_selection_mask,
+                              const uint8_t* update_filter, const float* neural_opacity, const float* viewspace_grad,
+                              float* opacity_accum, float* anchor_demon, float* offset_gradient_accum, float* offset_denom,
+                              char* scratch, size_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int k = n_offsets;
+    if (N < 0 || k < 1) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_training_stats: bad sizes");
+    if (N == 0) return 0;
+    if (!opacity_accum || !anchor_demon || !offset_gradient_accum || !offset_denom || !scratch)
+        return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_training_stats: NULL pointer");
+    if (scratch_bytes < lidargs_ng_scratch_bytes(N, k)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_training_stats: scratch too small");
+    lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)k, &s);
+    hipLaunchKernelGGL(lg::k_ng_visflags, dim3((N + 255) / 256), dim3(256), 0, stream, N, anchor_visible_mask, s.vis_flags);
+    lg::launch_exclusive_scan(s.vis_flags, s.vis_idx, (size_t)N, s.totals, s.scan, stream);
+    const size_t NK = (size_t)N * k;
+    hipLaunchKernelGGL(lg::k_ng_stats_flags, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, stream, N, k, s.vis_flags, s.vis_idx, offset_selection_mask, s.sel_flags);
+    lg::launch_exclusive_scan(s.sel_flags, s.slot, NK, s.totals + 1, s.scan, stream);
+    hipLaunchKernelGGL(lg::k_ng_stats, dim3((N + 255) / 256), dim3(256), 0, stream, N, k, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, update_filter,
+                       neural_opacity, viewspace_grad, opacity_accum, anchor_demon, offset_gradient_accum, offset_denom);
     NG_HIP(hipGetLastError());
     return 0;
 }

@@ -23,7 +23,7 @@ class _Model(C.Structure):
                 ("W1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("W2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("W2T", C.c_void_p * 4)]
 
 
-for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward"):
+for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_ng_training_stats"):
     getattr(_lib, _n).restype = C.c_int
 _lib.lidargs_ng_scratch_bytes.restype = C.c_size_t
 
@@ -163,3 +163,26 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     if is_training:
         return xyz, color, opacity, scal, rot, neural_opacity, mask
     return xyz, color, opacity, scal, rot
+
+
+def training_statis(pc, viewspace_point_tensor, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
+    """Drop-in for GaussianModel.training_statis (scene/gaussian_model.py:599-622), as a function of the model: updates
+    pc.opacity_accum, pc.anchor_demon, pc.offset_gradient_accum and pc.offset_denom in place with one native call (no masks
+    expanded, no boolean indexing, no host read).  Call it as `training_statis(gaussians, ...)` where train.py:243 calls the method."""
+    dev = pc.opacity_accum.device
+    _base._require_device(pc.opacity_accum, "opacity_accum")
+    N, k = int(pc.opacity_accum.shape[0]), int(pc.n_offsets)
+    u8 = lambda t: t.to(torch.bool).contiguous().view(torch.uint8)
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    for t in (pc.opacity_accum, pc.anchor_demon, pc.offset_gradient_accum, pc.offset_denom):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("training_statis: the accumulators must be contiguous float32 tensors")
+    vis, sel, upd = u8(anchor_visible_mask), u8(offset_selection_mask), u8(update_filter)
+    op, grad = f32(opacity), f32(viewspace_point_tensor.grad)
+    nb = int(_lib.lidargs_ng_scratch_bytes(C.c_int(N), C.c_int(k)))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    p = _base._ptr
+    with torch.no_grad(), torch.cuda.device(dev):
+        _check(_lib.lidargs_ng_training_stats(C.c_int(N), C.c_int(k), p(vis), p(sel), p(upd), p(op), p(grad), p(pc.opacity_accum), p(pc.anchor_demon),
+                                              p(pc.offset_gradient_accum), p(pc.offset_denom), p(scratch), C.c_size_t(nb), _base._stream(dev)),
+               "lidargs_ng_training_stats")
