@@ -149,10 +149,10 @@ def bench_decode(args):
     import build_hip
     build_hip.build()
     from neural_gaussians import generate_neural_gaussians
-    from test_neural_gaussians_gpu import build_pc, random_case
+    import lidargs_scenes as sc
     N, k = 333_334, 6
-    p, cam, vis, _rng = random_case(N, k, 5)
-    pc = build_pc(p)
+    p, cam, vis, _rng = sc.make_anchor_model(N, k, 5)
+    pc = sc.anchor_model_to_torch(p)
     camera = types.SimpleNamespace(camera_center=torch.from_numpy(cam).cuda(), uid=0)
     vmask = torch.from_numpy(vis).cuda()
     mlps = [getattr(pc, "mlp_" + m) for m in ("opacity", "cov", "color", "raydrop")]
@@ -196,7 +196,7 @@ def bench_decode(args):
         t_eager, _ = timed(lambda: ngt.generate(pc._anchor_feat, pc._anchor, pc._offset, pc.get_scaling, params, camera.camera_center, vmask, flags),
                            max(3, args.steps // 5), 2)
         Ns = N // 20
-        ps, cams, viss, rng = random_case(Ns, k, 5)
+        ps, cams, viss, rng = sc.make_anchor_model(Ns, k, 5)
         t0 = time.perf_counter(); reps = 0
         while time.perf_counter() - t0 < 10.0:
             f = ng.forward(ps, cams, viss)
@@ -280,19 +280,17 @@ def bench_train_step(args):
     from diff_lidargs_rasterization import GaussianRasterizer
     from lidar_loss import image_loss
     from neural_gaussians import generate_neural_gaussians
-    from test_neural_gaussians_gpu import build_pc, random_case
-    from util import make_settings
     kind, P, H, W, seed = sc.BASELINE_CONFIGS["cfg3"]
     N, k = 666_667, 6
     scene = sc.make_scene(kind, N, H, seed)
-    p, _cam, _vis, rng = random_case(N, k, seed)
+    p, _cam, _vis, rng = sc.make_anchor_model(N, k, seed)
     p["anchor"] = scene["means3D"].astype(np.float32)
     p["offset"] = (0.5 * rng.normal(size=(N, k, 3))).astype(np.float32)
     p["scaling"] = np.concatenate([np.full((N, 3), 0.3, np.float32), scene["scales"].astype(np.float32) * 2.0], 1)   # sigmoid halves them on average
-    pc = build_pc(p)
+    pc = sc.anchor_model_to_torch(p)
     camera = types.SimpleNamespace(camera_center=torch.zeros(3).cuda(), uid=0)
     st = {k_: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k_, v in scene.items() if k_ in ("viewmatrix", "beams", "bg")}
-    rast = GaussianRasterizer(make_settings(st, W, H))
+    rast = GaussianRasterizer(sc.raster_settings(st, W, H))
     gt = torch.from_numpy(np.stack([(rng.random((H, W)) > 0.2).astype(np.float32), rng.random((H, W), dtype=np.float32),
                                     (rng.random((H, W)) * 60).astype(np.float32)])).cuda()
     mlps = [getattr(pc, "mlp_" + m) for m in ("opacity", "cov", "color", "raydrop")]
@@ -429,7 +427,8 @@ def main():
         import torch.distributed as dist
         dist.barrier()
     from diff_lidargs_rasterization import GaussianRasterizer, _C
-    from util import make_settings, to_torch
+    to_torch = lambda sd, device: {k_: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k_, v in sd.items()}
+    make_settings = sc.raster_settings
 
     scene = sc.make_scene(kind, P, H, seed)
     st = to_torch(scene, dev)

@@ -121,3 +121,59 @@ def upstream_grads(H, W, seed):
     return (rng.normal(size=(2, H, W)).astype(np.float32),
             rng.normal(size=(1, H, W)).astype(np.float32),
             rng.normal(size=(1, H, W)).astype(np.float32))
+
+
+# ---- anchor models for the decode (generate_neural_gaussians) workloads ---------------------------------------------------
+ANCHOR_MLPS = ("opacity", "cov", "color", "raydrop")
+
+
+def make_anchor_model(N, k, seed, flags=(True, True, True)):
+    """Random Scaffold-style anchor model in the reference's default configuration (feat 32, hidden 32, k offsets, 2 colour
+    channels): dict of numpy arrays (anchor_feat, anchor, offset, scaling = exp-activated, {mlp}_W1/_b1/_W2/_b2, add_*_dist),
+    a camera centre, a visible-anchor mask and the generator (for further draws)."""
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.normal(size=s).astype(np.float32)
+    p = dict(anchor_feat=0.5 * f(N, 32), anchor=10.0 * f(N, 3), offset=0.3 * f(N, k, 3), scaling=np.exp(0.3 * f(N, 6) - 1.0).astype(np.float32),
+             add_opacity_dist=flags[0], add_cov_dist=flags[1], add_color_dist=flags[2])
+    dins = dict(opacity=35 + flags[0], cov=35 + flags[1], color=35 + flags[2], raydrop=35 + flags[2])
+    douts = dict(opacity=k, cov=7 * k, color=k, raydrop=k)
+    for m in ANCHOR_MLPS:
+        p[m + "_W1"], p[m + "_b1"] = f(32, dins[m]) / np.float32(6.0), 0.1 * f(32)
+        p[m + "_W2"], p[m + "_b2"] = f(douts[m], 32) / np.float32(5.6), 0.1 * f(douts[m])
+    return p, np.array([0.5, -1.0, 2.0], np.float32), rng.random(N) > 0.3, rng
+
+
+def anchor_model_to_torch(p, device="cuda"):
+    """The object generate_neural_gaussians reads (`pc`): tensors with requires_grad and the four nn.Sequential MLPs declared as
+    GaussianModel.__init__ declares them (scene/gaussian_model.py:113-142)."""
+    import types
+    import torch
+    from torch import nn
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    pc = types.SimpleNamespace()
+    k = p["offset"].shape[1]
+    pc.use_feat_bank, pc.appearance_dim, pc.n_offsets, pc.color_channel = False, 0, k, 2
+    pc.add_opacity_dist, pc.add_cov_dist, pc.add_color_dist = p["add_opacity_dist"], p["add_cov_dist"], p["add_color_dist"]
+    for name, act in (("opacity", nn.Tanh()), ("cov", None), ("color", nn.Sigmoid()), ("raydrop", nn.Sigmoid())):
+        W1, W2 = p[name + "_W1"], p[name + "_W2"]
+        seq = nn.Sequential(nn.Linear(W1.shape[1], 32), nn.ReLU(True), nn.Linear(32, W2.shape[0]), *([act] if act else [])).to(device)
+        with torch.no_grad():
+            seq[0].weight.copy_(t(W1)); seq[0].bias.copy_(t(p[name + "_b1"])); seq[2].weight.copy_(t(W2)); seq[2].bias.copy_(t(p[name + "_b2"]))
+        setattr(pc, "mlp_" + name, seq); setattr(pc, f"get_{name}_mlp", seq)
+    pc._anchor_feat = t(p["anchor_feat"]).requires_grad_(True)
+    pc._anchor = t(p["anchor"]).requires_grad_(True); pc.get_anchor = pc._anchor
+    pc._offset = t(p["offset"]).requires_grad_(True)
+    pc.get_scaling = t(p["scaling"]).requires_grad_(True)
+    return pc
+
+
+def raster_settings(scene_t, W, H, far=80, near=0, scale_modifier=1.0, debug=False):
+    """GaussianRasterizationSettings for a scene dict of device tensors, built as gaussian_renderer/__init__.py:150-166 does."""
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizationSettings
+    dev = scene_t["viewmatrix"].device
+    return GaussianRasterizationSettings(
+        image_height=int(H), image_width=int(W), tanfovx=1.0, tanfovy=1.0, bg=scene_t["bg"], scale_modifier=scale_modifier,
+        viewmatrix=scene_t["viewmatrix"], projmatrix=torch.eye(4, device=dev), sh_degree=1,
+        campos=torch.zeros(3, device=dev), prefiltered=False, beam_inclinations=scene_t["beams"], debug=debug,
+        lidar_far=int(far), lidar_near=int(near))

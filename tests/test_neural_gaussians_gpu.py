@@ -6,6 +6,8 @@ import types
 import numpy as np
 import pytest
 
+import lidargs_scenes as sc
+
 from oracle import neural_gaussians as ng
 from test_neural_gaussians_cpu import PARAM_KEYS, load_case
 from util import parity
@@ -14,24 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def build_pc(p, device="cuda"):
-    import torch
-    from torch import nn
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    pc = types.SimpleNamespace()
-    k = p["offset"].shape[1]
-    pc.use_feat_bank, pc.appearance_dim, pc.n_offsets, pc.color_channel = False, 0, k, 2
-    pc.add_opacity_dist, pc.add_cov_dist, pc.add_color_dist = p["add_opacity_dist"], p["add_cov_dist"], p["add_color_dist"]
-    for name, act in (("opacity", nn.Tanh()), ("cov", None), ("color", nn.Sigmoid()), ("raydrop", nn.Sigmoid())):
-        W1, W2 = p[name + "_W1"], p[name + "_W2"]
-        seq = nn.Sequential(nn.Linear(W1.shape[1], 32), nn.ReLU(True), nn.Linear(32, W2.shape[0]), *([act] if act else [])).to(device)
-        with torch.no_grad():
-            seq[0].weight.copy_(t(W1)); seq[0].bias.copy_(t(p[name + "_b1"])); seq[2].weight.copy_(t(W2)); seq[2].bias.copy_(t(p[name + "_b2"]))
-        setattr(pc, "mlp_" + name, seq); setattr(pc, f"get_{name}_mlp", seq)
-    pc._anchor_feat = t(p["anchor_feat"]).requires_grad_(True)
-    pc._anchor = t(p["anchor"]).requires_grad_(True); pc.get_anchor = pc._anchor
-    pc._offset = t(p["offset"]).requires_grad_(True)
-    pc.get_scaling = t(p["scaling"]).requires_grad_(True)
-    return pc
+    return sc.anchor_model_to_torch(p, device)
 
 
 def run_hip(p, cam, vis, ups=None):
@@ -71,16 +56,7 @@ def test_decode_matches_reference_golden(tag, hip_lib_built):
 
 
 def random_case(N, k, seed, flags=(True, True, True)):
-    rng = np.random.default_rng(seed)
-    f = lambda *s: rng.normal(size=s).astype(np.float32)
-    p = dict(anchor_feat=0.5 * f(N, 32), anchor=10.0 * f(N, 3), offset=0.3 * f(N, k, 3), scaling=np.exp(0.3 * f(N, 6) - 1.0).astype(np.float32),
-             add_opacity_dist=flags[0], add_cov_dist=flags[1], add_color_dist=flags[2])
-    dins = dict(opacity=35 + flags[0], cov=35 + flags[1], color=35 + flags[2], raydrop=35 + flags[2])
-    douts = dict(opacity=k, cov=7 * k, color=k, raydrop=k)
-    for m in ng.MLPS:
-        p[m + "_W1"], p[m + "_b1"] = f(32, dins[m]) / np.float32(6.0), 0.1 * f(32)
-        p[m + "_W2"], p[m + "_b2"] = f(douts[m], 32) / np.float32(5.6), 0.1 * f(douts[m])
-    return p, np.array([0.5, -1.0, 2.0], np.float32), rng.random(N) > 0.3, rng
+    return sc.make_anchor_model(N, k, seed, flags)
 
 
 @pytest.mark.parametrize("N,k,flags", [(20000, 6, (True, True, True)), (7001, 10, (False, True, True)), (5000, 4, (True, False, False)),

@@ -45,15 +45,8 @@ def to_torch(scene, device="cuda"):
 
 
 def make_settings(scene_t, W, H, far=80, near=0, scale_modifier=1.0, debug=False):
-    import torch
-    from diff_lidargs_rasterization import GaussianRasterizationSettings
-    dev = scene_t["viewmatrix"].device
-    # same construction as gaussian_renderer/__init__.py:150-166
-    return GaussianRasterizationSettings(
-        image_height=int(H), image_width=int(W), tanfovx=1.0, tanfovy=1.0, bg=scene_t["bg"], scale_modifier=scale_modifier,
-        viewmatrix=scene_t["viewmatrix"], projmatrix=torch.eye(4, device=dev), sh_degree=1,
-        campos=torch.zeros(3, device=dev), prefiltered=False, beam_inclinations=scene_t["beams"], debug=debug,
-        lidar_far=int(far), lidar_near=int(near))
+    import lidargs_scenes as sc
+    return sc.raster_settings(scene_t, W, H, far, near, scale_modifier, debug)
 
 
 def hip_forward_backward(scene, W, H, grads=None, cov3D_precomp=None, far=80, near=0, scale_modifier=1.0, device="cuda"):

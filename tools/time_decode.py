@@ -6,7 +6,8 @@ for p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests"))
     sys.path.insert(0, p)
 import numpy as np
 import torch
-from test_neural_gaussians_gpu import build_pc, random_case
+import lidargs_scenes as _sc
+build_pc, random_case = _sc.anchor_model_to_torch, _sc.make_anchor_model
 from neural_gaussians import generate_neural_gaussians
 from oracle import neural_gaussians_torch as ngt
 
