@@ -554,8 +554,15 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             const SfPair q = sf_pair(px, r0, r1, r2, r3, r4);
             const bool contrib = rows && (e_loc < n_lane) && q.ok;
             if (__ballot(contrib) == 0ull) continue;
-            const float alpha = q.alpha, G = q.G, c_d = q.depth;
-            const float Tn = T / (1.f - alpha);
+            // A pixel that does not blend this entry treats it as an alpha = 0 entry (as in render.hip): T / (1 - 0) = T, the
+            // recurrences commit the previous entry and then carry (alpha 0, this entry), which the next step folds away
+            // exactly -- so no select on the state registers; and every sum carries dL_dalpha, w or dL_dz as a factor, so
+            // zeroing those three zeroes the 23 sums.  (Selects, not products: a skipped pair's depth may be 0 or huge.)
+            const float alpha = contrib ? q.alpha : 0.f;
+            const float G = q.G;
+            const float c_d = contrib ? q.depth : 1.f;
+            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);       // 1 ulp; (1 - alpha) >= 0.01
+            const float Tn = T * inv;
             const float w = alpha * Tn;
             // recurrences of "what lies behind" (R2/cr/backward.cu:349-410)
             const float a_c0 = last_alpha * l_c0 + (1.f - last_alpha) * acc_c0;
@@ -565,26 +572,30 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             const float a_n1 = last_alpha * l_n1 + (1.f - last_alpha) * acc_n1;
             const float a_n2 = last_alpha * l_n2 + (1.f - last_alpha) * acc_n2;
             float dL_dalpha = (r1.w - a_c0) * g0;                      // only channel 0 (:358-359)
-            const float m_d = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / c_d);
-            const float dmd_dd = (SF_FAR_N * SF_NEAR_N) / ((SF_FAR_N - SF_NEAR_N) * c_d * c_d);
-            float dL_dz = (e + 1u == med_c) ? g_med : 0.f;             // contributor == median_contributor - 1 (:371)
-            dL_dz += 2.0f * (Tn * alpha) * (m_d * final_A - final_D) * g_reg * dmd_dd;     // DETACH_WEIGHT: only the m_d path (:375-388)
+            const float icd = __builtin_amdgcn_rcpf(c_d);
+            const float m_d = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N * icd);
+            const float dmd_dd = (SF_FAR_N * SF_NEAR_N) / (SF_FAR_N - SF_NEAR_N) * icd * icd;
+            float dL_dz = (contrib && e + 1u == med_c) ? g_med : 0.f;   // contributor == median_contributor - 1 (:371)
+            dL_dz += 2.0f * w * (m_d * final_A - final_D) * g_reg * dmd_dd;     // DETACH_WEIGHT: only the m_d path (:375-388)
             dL_dalpha += (c_d - a_d) * g_depth + (1.f - a_a) * g_alpha;
             dL_dalpha += (r3.x - a_n0) * gn0 + (r3.y - a_n1) * gn1 + (r3.z - a_n2) * gn2;
             dL_dalpha *= Tn;
-            dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
+            dL_dalpha -= T_final * inv * bgdot;
+            dL_dalpha = contrib ? dL_dalpha : 0.f;
             const float dL_dG = r0.w * dL_dalpha;
             dL_dz += w * g_depth;                                       // :420
-            // 3-D branch: gradient through s = (dp.Tu', dp.Tv'), dp = lam2 p - Tw, lam2 = (Tw.n)/(p.n)   (:427-563)
-            const float ga = -dL_dG * G * q.sx, gb = -dL_dG * G * q.sy;   // dL/ds
+            // 3-D branch: gradient through s = (dp.Tu', dp.Tv'), dp = lam2 p - Tw, lam2 = (Tw.n)/(p.n)   (:427-563); its three
+            // roots are zeroed for a 2-D-branch pair, the 2-D branch's two for a 3-D one
+            const bool in3d = q.in3d;
+            const float ga = in3d ? -dL_dG * G * q.sx : 0.f, gb = in3d ? -dL_dG * G * q.sy : 0.f;   // dL/ds
             const float iu = r0.x * r0.x + r0.y * r0.y + r0.z * r0.z;     // 1/(Tu.Tu)
             const float iv = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
             // dL/dTu = ga (dp - 2 sx Tu)/(Tu.Tu) = ga (dp * iu - 2 sx Tu')
             const float3 gTu = sf3(ga * (q.dp.x * iu - 2.f * q.sx * r0.x), ga * (q.dp.y * iu - 2.f * q.sx * r0.y), ga * (q.dp.z * iu - 2.f * q.sx * r0.z));
             const float3 gTv = sf3(gb * (q.dp.x * iv - 2.f * q.sy * r1.x), gb * (q.dp.y * iv - 2.f * q.sy * r1.y), gb * (q.dp.z * iv - 2.f * q.sy * r1.z));
             const float3 gdp = sf3(ga * r0.x + gb * r1.x, ga * r0.y + gb * r1.y, ga * r0.z + gb * r1.z);
-            const float g_lam = sdot(gdp, px.p) + dL_dz;
-            const float icos = 1.f / (q.cos2 != 0.f ? q.cos2 : 1.f);
+            const float g_lam = in3d ? sdot(gdp, px.p) + dL_dz : 0.f;
+            const float icos = __builtin_amdgcn_rcpf(q.cos2 != 0.f ? q.cos2 : 1.f);
             const float3 gTw = sf3(-gdp.x + g_lam * r3.x * icos, -gdp.y + g_lam * r3.y * icos, -gdp.z + g_lam * r3.z * icos);
             // d lam2 / d n = (Tw (p.n) - (Tw.n) p) / (p.n)^2 = -dp / (p.n): evaluated as the reference writes it (:452-461), the
             // difference of two ~range-sized vectors, so that its rounding (3 digits of cancellation) is the reference's
@@ -592,28 +603,24 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             const float3 gN = sf3(g_lam * ((r2.x * q.cos2 - r4.w * px.p.x) * icos2), g_lam * ((r2.y * q.cos2 - r4.w * px.p.y) * icos2),
                                   g_lam * ((r2.z * q.cos2 - r4.w * px.p.z) * icos2));
             // 2-D branch (:578-599)
-            const float m2x = dL_dG * (-G * 2.0f * 40.f * q.dxp), m2y = dL_dG * (-G * 2.0f * 100.f * q.dyp);
-            const bool b3 = contrib && q.in3d, b2 = contrib && !q.in3d;
+            const float dL_dG2 = in3d ? 0.f : dL_dG;
+            const float m2x = dL_dG2 * (-G * 2.0f * 40.f * q.dxp), m2y = dL_dG2 * (-G * 2.0f * 100.f * q.dyp);
             float v[32];
 #pragma unroll
             for (int k = 0; k < 32; k++) v[k] = 0.f;
-            v[SFA_COL0] = contrib ? w * g0 : 0.f; v[SFA_COL1] = contrib ? w * g1 : 0.f;
-            v[SFA_OPA] = contrib ? G * dL_dalpha : 0.f;
-            v[SFA_N0] = (contrib ? w * gn0 : 0.f) + (b3 ? gN.x : 0.f);
-            v[SFA_N1] = (contrib ? w * gn1 : 0.f) + (b3 ? gN.y : 0.f);
-            v[SFA_N2] = (contrib ? w * gn2 : 0.f) + (b3 ? gN.z : 0.f);
-            v[SFA_TU0] = b3 ? gTu.x : 0.f; v[SFA_TU1] = b3 ? gTu.y : 0.f; v[SFA_TU2] = b3 ? gTu.z : 0.f;
-            v[SFA_TV0] = b3 ? gTv.x : 0.f; v[SFA_TV1] = b3 ? gTv.y : 0.f; v[SFA_TV2] = b3 ? gTv.z : 0.f;
-            v[SFA_TW0] = b3 ? gTw.x : 0.f; v[SFA_TW1] = b3 ? gTw.y : 0.f; v[SFA_TW2] = b3 ? gTw.z : 0.f;
-            v[SFA_AW0] = b3 ? fabsf(gTw.x) : 0.f; v[SFA_AW1] = b3 ? fabsf(gTw.y) : 0.f; v[SFA_AW2] = b3 ? fabsf(gTw.z) : 0.f;
-            v[SFA_M2X] = b2 ? m2x : 0.f; v[SFA_M2Y] = b2 ? m2y : 0.f; v[SFA_M2AX] = b2 ? fabsf(m2x) : 0.f; v[SFA_M2AY] = b2 ? fabsf(m2y) : 0.f;
-            v[SFA_Z2D] = b2 ? dL_dz : 0.f;
-            // commit the per-pixel state where this pixel really blended the entry
-            T = contrib ? Tn : T;
-            acc_c0 = contrib ? a_c0 : acc_c0; acc_d = contrib ? a_d : acc_d; acc_a = contrib ? a_a : acc_a;
-            acc_n0 = contrib ? a_n0 : acc_n0; acc_n1 = contrib ? a_n1 : acc_n1; acc_n2 = contrib ? a_n2 : acc_n2;
-            l_c0 = contrib ? r1.w : l_c0; l_d = contrib ? c_d : l_d; l_n0 = contrib ? r3.x : l_n0; l_n1 = contrib ? r3.y : l_n1; l_n2 = contrib ? r3.z : l_n2;
-            last_alpha = contrib ? alpha : last_alpha;
+            v[SFA_COL0] = w * g0; v[SFA_COL1] = w * g1;
+            v[SFA_OPA] = G * dL_dalpha;
+            v[SFA_N0] = w * gn0 + gN.x; v[SFA_N1] = w * gn1 + gN.y; v[SFA_N2] = w * gn2 + gN.z;
+            v[SFA_TU0] = gTu.x; v[SFA_TU1] = gTu.y; v[SFA_TU2] = gTu.z;
+            v[SFA_TV0] = gTv.x; v[SFA_TV1] = gTv.y; v[SFA_TV2] = gTv.z;
+            v[SFA_TW0] = gTw.x; v[SFA_TW1] = gTw.y; v[SFA_TW2] = gTw.z;
+            v[SFA_AW0] = fabsf(gTw.x); v[SFA_AW1] = fabsf(gTw.y); v[SFA_AW2] = fabsf(gTw.z);
+            v[SFA_M2X] = m2x; v[SFA_M2Y] = m2y; v[SFA_M2AX] = fabsf(m2x); v[SFA_M2AY] = fabsf(m2y);
+            v[SFA_Z2D] = in3d ? 0.f : dL_dz;
+            T = Tn;
+            acc_c0 = a_c0; acc_d = a_d; acc_a = a_a; acc_n0 = a_n0; acc_n1 = a_n1; acc_n2 = a_n2;
+            l_c0 = r1.w; l_d = c_d; l_n0 = r3.x; l_n1 = r3.y; l_n2 = r3.z;
+            last_alpha = alpha;
             const float mine = sf_reduce_scatter32(v, lane);
             if (lane < 32) {
                 const int slot = 16 * (lane & 1) + 8 * ((lane >> 1) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 4) & 1);
