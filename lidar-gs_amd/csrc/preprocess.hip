@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     } while (false);
 
     a.radii[idx] = out_radius;
-    if (live) { a.radii_xy[2 * idx] = rx; a.radii_xy[2 * idx + 1] = ry; }
+    a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;      // every row written: callers need not pre-zero
     if (FILTER) return;
     a.dkey[idx] = key;
     a.ids[idx] = (uint32_t)idx;

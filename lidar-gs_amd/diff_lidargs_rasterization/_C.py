@@ -131,11 +131,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _require_device(means3D, "means3D")
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
-    out_occ = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    radii_xy = torch.zeros((2 * P,), dtype=torch.int32, device=dev)
+    # the reference fills these with zeros (R3/rasterize_points.cu:63-68) and its kernels overwrite them; the native forward
+    # writes every pixel and every radii row, so for P > 0 five fill launches are saved by not pre-zeroing
+    mk = torch.empty if P != 0 else torch.zeros
+    out_color = mk((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = mk((1, H, W), dtype=torch.float32, device=dev)
+    out_occ = mk((1, H, W), dtype=torch.float32, device=dev)
+    radii = mk((P,), dtype=torch.int32, device=dev)
+    radii_xy = mk((2 * P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     rendered = 0
     if P != 0:
