@@ -247,7 +247,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_prof.mark("scan+readback", stream);
 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const int S = lg::choose_segments(R, grid.num_tiles(), max_segments());
+    const int S = lg::choose_segments(R, max_segments());
     char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, patches, grid.waves_per_tile, S, nullptr));
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
     lg::BinView bin; lg::bin_carve(bin_p, R, patches, grid.waves_per_tile, S, &bin);
@@ -326,7 +326,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     const int TH = tile_rows();
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const int S = lg::choose_segments((size_t)R, grid.num_tiles(), max_segments());
+    const int S = lg::choose_segments((size_t)R, max_segments());
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
     lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
@@ -464,7 +464,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     if (P <= 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "render_shell: missing forward buffers%s");
     const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const int S = lg::choose_segments((size_t)R, grid.num_tiles(), max_segments());
+    const int S = lg::choose_segments((size_t)R, max_segments());
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
     lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);

@@ -20,7 +20,7 @@
 //     tile keys ping/pong u32[R], Gaussian ids ping/pong u32[R], sort scratch
 //     -> point_list u32[R]: Gaussian ids sorted by (tile, range, id)
 //   image buffer     (sized by W*H)
-//     final_T f32[N], n_contrib u32[N], ranges uint2[tiles], per-row / per-column ray tables
+//     final_T f32[N], T_pass f32[N], ranges uint2[tiles], per-row / per-column ray tables
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -120,8 +120,7 @@ struct BinView {
 // (render.hip segment_count), so long lists of a skewed frame (far range shells, street canyons) are split as finely as
 // the short ones are left alone.  The count is a pure function of the tile's range: backward recomputes it.
 #define LG_SEG_LEN_DEFAULT 128
-inline int choose_segments(size_t R, int tiles, int max_segments) {
-    (void)tiles;
+inline int choose_segments(size_t R, int max_segments) {
     if (R == 0) return 1;
     return max_segments < 1 ? 1 : max_segments;
 }
@@ -143,7 +142,6 @@ inline size_t bin_carve(char* base, size_t R, size_t patches, int waves_per_tile
 
 struct ImgView {
     float* final_T;       // T at the end of this call's list (after early-out)
-    uint32_t* n_contrib;  // (unused since the segmented blend: per-segment counts live in the binning buffer)
     float* T_pass;        // transmittance handed to the next range shell (multi-GPU only)
     uint2* ranges;        // [tiles]
     float2* coltab;       // [W]  (cos beta, sin beta)
@@ -155,7 +153,6 @@ inline size_t img_carve(char* base, int W, int H, int tiles, ImgView* v) {
     ImgView m;
     size_t N = (size_t)W * H;
     m.final_T = c.take<float>(N);
-    m.n_contrib = c.take<uint32_t>(N);
     m.T_pass = c.take<float>(N);
     m.ranges = c.take<uint2>(tiles);
     m.coltab = c.take<float2>(W);
