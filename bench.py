@@ -453,9 +453,9 @@ def main():
         import math
         beams = st["beams"]
         tile_rad = (16 * 2 * math.pi / W, 4 * float(beams[-1] - beams[0]) / max(1, H - 1))      # 16 columns x 4 rows per tile
-        edges = comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
-                                                        tile_rad=tile_rad), 0)
-        rast = lidargs_dist.ShellRasterizer(settings, comm, edges=edges)
+        cut = lambda shares: comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
+                                                                     tile_rad=tile_rad, shares=shares), 0)
+        rast = lidargs_dist.ShellRasterizer(settings, comm, edges=cut(None))
 
         def step():
             for t in list(leaves.values()) + [means2D]:
@@ -471,6 +471,22 @@ def main():
         torch.cuda.synchronize()
 
     _C.profile_enable(True)             # pre-creates the event pool (one-off cost, outside the timed region)
+    if world > 1 or force_shells:
+        # Measured load balancing of the (static) cut, outside the timed region: a few frames per round, every rank's own kernel
+        # time (its HIP-event stage sums, which do not include waiting for the other ranks) -> thinner shells for the slow ranks.
+        import torch.distributed as dist
+        shares = [1.0 / world] * world
+        for _round in range(4):
+            _C.profile_enable(True)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            mine = torch.tensor([sum(v[0] for v in _C.profile_summary().values())], dtype=torch.float64, device=dev)
+            times = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(times, mine)
+            shares = lidargs_dist.rebalance_shares(shares, [float(t) for t in times], fixed=0.25)
+            rast.edges = cut(shares)
+        _C.profile_enable(True)
     for _ in range(args.warmup):
         step()
     barrier()

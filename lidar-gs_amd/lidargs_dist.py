@@ -113,7 +113,7 @@ class SingleComm:
         return t.clone()
 
 
-def shell_edges(means3D, viewmatrix, world, near, far, bins=2048, scales=None, tile_rad=None):
+def shell_edges(means3D, viewmatrix, world, near, far, bins=2048, scales=None, tile_rad=None, shares=None):
     """Range-shell boundaries: world+1 ascending floats, first = -inf, last = +inf, interior edges = quantiles of
     |p_view| from a histogram over (near, far).
 
@@ -121,7 +121,9 @@ def shell_edges(means3D, viewmatrix, world, near, far, bins=2048, scales=None, t
     instances, and a near Gaussian covers several times the tiles of a far one; with `scales` [P,3] and `tile_rad` = (tile
     width, tile height) in radians each Gaussian is weighted by a per-Gaussian + per-instance cost estimate from the tiles
     its 3-sigma disc spans, (2a/tw + 1)(2a/th + 1) with a = 3 max(scale)/range, so the shells get thinner towards the
-    sensor.  This is load balancing only: any ascending edges give the same image and gradients."""
+    sensor.  `shares` (world positive numbers, default equal) are the fractions of the total weight the shells should get:
+    the handle `rebalance_shares` turns measured per-rank times into.  This is load balancing only: any ascending edges give
+    the same image and gradients."""
     V = viewmatrix.reshape(4, 4).to(means3D.dtype)
     p = means3D.detach() @ V[:3, :3] + V[3, :3]
     r = torch.linalg.vector_norm(p, dim=1)
@@ -140,7 +142,11 @@ def shell_edges(means3D, viewmatrix, world, near, far, bins=2048, scales=None, t
     cum = torch.cumsum(hist, 0)
     total = cum[-1].clamp(min=1e-30)
     edges = [float("-inf")]
-    targets = torch.arange(1, world, device=r.device, dtype=cum.dtype) * (total / world)
+    if shares is None:
+        targets = torch.arange(1, world, device=r.device, dtype=cum.dtype) * (total / world)
+    else:
+        sh = torch.as_tensor(shares, dtype=cum.dtype, device=r.device).clamp(min=1e-6)
+        targets = torch.cumsum(sh / sh.sum(), 0)[:-1] * total
     idx = torch.searchsorted(cum, targets)
     prev = float(near)
     for i in idx.tolist():
@@ -148,6 +154,19 @@ def shell_edges(means3D, viewmatrix, world, near, far, bins=2048, scales=None, t
         edges.append(e); prev = e
     edges.append(float("inf"))
     return torch.tensor(edges, dtype=torch.float32, device=means3D.device)
+
+
+def rebalance_shares(shares, times, damping=0.5, fixed=0.0):
+    """One step of measured load balancing: the weight share of shell g is scaled by (mean time / its time), i.e. a slow rank
+    gets a thinner shell.  `times` are per-rank compute times of a frame cut with `shares`; `fixed` is the part of a frame that
+    does not depend on the shell's size (launch overhead), `damping` in (0, 1] limits the step."""
+    import numpy as np
+    sh = np.asarray(shares, np.float64)
+    t = np.maximum(np.asarray(times, np.float64) - fixed, 1e-3)
+    new = sh * (t.mean() / t)
+    new = sh + damping * (new / new.sum() - sh / sh.sum())
+    new = np.maximum(new, 1e-4)
+    return (new / new.sum()).tolist()
 
 
 class HipShellBackend:

@@ -24,9 +24,7 @@ gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, seed))
 settings = make_settings(st, W, H)
 import math
 tile_rad = (16 * 2 * math.pi / W, 4 * float(st["beams"][-1] - st["beams"][0]) / max(1, H - 1))
-edges = lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"] if os.environ.get("EDGES", "w") == "w" else None,
-                                 tile_rad=tile_rad)
-print("edges", [round(float(e), 2) for e in edges])
+
 
 
 class RecordComm(ThreadComm):
@@ -67,52 +65,56 @@ def frame(mod):
     return lidargs_dist.shell_backward(mod, saved, gc, gd, go)
 
 
-logs = [[] for _ in range(world)]
-shared = ThreadComm.Shared(world)
-errs = []
+def measure(edges):
+    """(per-rank wall ms without RCCL, per-rank sum of kernel-stage ms) for the given cut, by record + replay."""
+    from diff_lidargs_rasterization import _C
+    logs = [[] for _ in range(world)]
+    shared = ThreadComm.Shared(world)
+    errs = []
 
+    def record(r):
+        try:
+            torch.cuda.set_device(0)
+            frame(lidargs_dist.ShellRasterizer(settings, RecordComm(shared, r, logs[r]), edges=edges))
+        except Exception as e:
+            errs.append(e); shared.barrier.abort()
 
-def record(r):
-    try:
-        torch.cuda.set_device(0)
-        frame(lidargs_dist.ShellRasterizer(settings, RecordComm(shared, r, logs[r]), edges=edges))
-    except Exception as e:
-        errs.append(e); shared.barrier.abort()
-
-
-th = [threading.Thread(target=record, args=(r,)) for r in range(world)]
-for t in th: t.start()
-for t in th: t.join(timeout=300)
-assert not errs, errs
-torch.cuda.synchronize()
-times = []
-for r in range(world):
-    mod = lidargs_dist.ShellRasterizer(settings, ReplayComm(r, world, logs[r]), edges=edges)
-    for _ in range(3):
-        frame(mod)
+    th = [threading.Thread(target=record, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    assert not errs, errs
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        frame(mod)
-    torch.cuda.synchronize()
-    times.append(1e3 * (time.perf_counter() - t0) / iters)
-    if r in (0, world - 1):
-        from diff_lidargs_rasterization import _C
+    walls, stages = [], []
+    for r in range(world):
+        mod = lidargs_dist.ShellRasterizer(settings, ReplayComm(r, world, logs[r]), edges=edges)
+        for _ in range(3):
+            frame(mod)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            frame(mod)
+        torch.cuda.synchronize()
+        walls.append(1e3 * (time.perf_counter() - t0) / iters)
         _C.profile_enable(True)
         for _ in range(iters):
             frame(mod)
         torch.cuda.synchronize()
         _C.profile_enable(False)
-        sm = _C.profile_summary()
-        print(f"  rank {r} stage ms: " + " ".join(f"{k}={v[0]:.3f}" for k, v in sm.items()) + f"  sum={sum(v[0] for v in sm.values()):.3f}  counters={_C.last_counters()}")
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            frame(mod)
-        t_host = 1e3 * (time.perf_counter() - t0) / iters
-        torch.cuda.synchronize()
-        print(f"  rank {r} host-side issue time per frame: {t_host:.3f} ms")
-    del mod
-print(f"world {world} {cfg}: per-rank ms (no RCCL time): " + " ".join(f"{t:.3f}" for t in times) + f"  max {max(times):.3f}")
+        stages.append(sum(v[0] for v in _C.profile_summary().values()))
+        del mod
+    return walls, stages, logs
+
+
+shares = [1.0 / world] * world
+rounds = int(os.environ.get("TUNE", "0"))
+for it in range(rounds + 1):
+    edges = lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"] if os.environ.get("EDGES", "w") == "w" else None,
+                                     tile_rad=tile_rad, shares=shares)
+    walls, stages, logs = measure(edges)
+    print(f"world {world} {cfg} round {it}: edges " + " ".join(f"{float(e):.1f}" for e in edges[1:-1]))
+    print("   per-rank ms (no RCCL time): " + " ".join(f"{t:.3f}" for t in walls) + f"  max {max(walls):.3f}")
+    print("   per-rank kernel-stage ms:   " + " ".join(f"{t:.3f}" for t in stages) + f"  max {max(stages):.3f}")
+    shares = lidargs_dist.rebalance_shares(shares, stages, fixed=float(os.environ.get("FIXED", "0.25")))
 coll = {}
 for n, t in logs[0]:
     coll.setdefault(n, []).append(t.numel() * t.element_size())
