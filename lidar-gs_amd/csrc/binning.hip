@@ -134,18 +134,39 @@ __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__
     for (int d = tid; d < BINS; d += 256) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
 }
 
-__global__ void __launch_bounds__(256) k_radix_digit_prefix(uint32_t* __restrict__ hist, unsigned nblocks, int bins,
-                                                            uint32_t* __restrict__ tot) {
+// One wave per (digit, chunk of `chunk` blocks): exclusive prefix of the block histograms inside the chunk, in place, and the
+// chunk's sum -> part[digit][chunk].  With a single chunk (chunk >= nblocks) the sum is the digit total itself.
+__global__ void __launch_bounds__(256) k_radix_digit_prefix(uint32_t* __restrict__ hist, unsigned nblocks, int bins, unsigned chunk,
+                                                            unsigned chunks, uint32_t* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned d = w / chunks, c = w - d * chunks;
+    if (d >= (unsigned)bins) return;
+    uint32_t* row = hist + (size_t)d * nblocks;
+    const unsigned lo = c * chunk, hi = min(nblocks, lo + chunk);
+    uint32_t carry = 0;
+    for (unsigned b0 = lo; b0 < hi; b0 += 64) {
+        const unsigned b = b0 + lane;
+        const uint32_t v = b < hi ? row[b] : 0u;
+        const uint32_t inc = wave_incl_scan(v, lane);
+        if (b < hi) row[b] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) part[(size_t)d * chunks + c] = carry;
+}
+// Second level (only when there is more than one chunk): exclusive prefix of the chunk sums per digit, in place; digit total.
+// A single wave used to walk all the blocks of a digit: 33 k blocks at 138 M keys = 0.3 ms per pass on 128 waves.
+__global__ void __launch_bounds__(256) k_radix_chunk_prefix(uint32_t* __restrict__ part, int bins, unsigned chunks, uint32_t* __restrict__ tot) {
     const int lane = threadIdx.x & 63;
     const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (d >= bins) return;
-    uint32_t* row = hist + (size_t)d * nblocks;
+    uint32_t* row = part + (size_t)d * chunks;
     uint32_t carry = 0;
-    for (unsigned b0 = 0; b0 < nblocks; b0 += 64) {
-        const unsigned b = b0 + lane;
-        const uint32_t v = b < nblocks ? row[b] : 0u;
+    for (unsigned c0 = 0; c0 < chunks; c0 += 64) {
+        const unsigned c = c0 + lane;
+        const uint32_t v = c < chunks ? row[c] : 0u;
         const uint32_t inc = wave_incl_scan(v, lane);
-        if (b < nblocks) row[b] = carry + inc - v;
+        if (c < chunks) row[c] = carry + inc - v;
         carry += __shfl(inc, 63);
     }
     if (lane == 0) tot[d] = carry;
@@ -155,7 +176,8 @@ template <int BITS>
 __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        size_t n, int shift, const uint32_t* __restrict__ hist,
-                                                       const uint32_t* __restrict__ tot, unsigned nblocks) {
+                                                       const uint32_t* __restrict__ tot, unsigned nblocks,
+                                                       const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t run[SORT_WAVES][BINS];   // per-wave running digit counts, then wave bases
     __shared__ uint32_t dbase[BINS];             // block-local start of each digit run
@@ -176,7 +198,10 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     }
     // global digit bases: exclusive scan of the digit totals (every block repeats this tiny scan)
     uint32_t my_tot = 0, my_hist = 0;
-    if (tid < BINS) { my_tot = tot[tid]; my_hist = hist[(size_t)tid * nblocks + blockIdx.x]; }
+    if (tid < BINS) {
+        my_tot = tot[tid]; my_hist = hist[(size_t)tid * nblocks + blockIdx.x];
+        if (part) my_hist += part[(size_t)tid * chunks + blockIdx.x / chunk];      // two-level cross-block prefix
+    }
     {
         const uint32_t inc = wave_incl_scan(my_tot, lane);
         if (lane == 63) wsum[w] = inc;
@@ -256,9 +281,16 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
     constexpr int BINS = 1 << BITS;
     uint32_t* hist = scratch;
     uint32_t* tot = scratch + (size_t)SORT_BINS * nb;
+    uint32_t* part = tot + SORT_BINS;
+    const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
+    const bool two_level = chunks_all > 2;
+    const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
     hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
-    hipLaunchKernelGGL(k_radix_digit_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, hist, nb, BINS, tot);
-    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, shift, hist, tot, nb);
+    // single level: the chunk sums ARE the digit totals, written straight to `tot`
+    hipLaunchKernelGGL(k_radix_digit_prefix, dim3((BINS * chunks + 3) / 4), dim3(256), 0, s, hist, nb, BINS, chunk, chunks, two_level ? part : tot);
+    if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
+    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, shift, hist, tot, nb,
+                       two_level ? part : (const uint32_t*)nullptr, chunk, chunks);
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,

@@ -64,9 +64,11 @@ constexpr int SCAN_BLOCK = 1024;                // elements per scan block (256 
 inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
 inline size_t scan_blocks(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
 // u32 words of scratch needed to sort n pairs: digit histogram [BINS x blocks] + per-digit totals
+constexpr unsigned SORT_PREFIX_CHUNK = 1024;     // blocks per wave in the two-level cross-block prefix (used above 2 chunks)
 inline size_t sort_scratch_words(size_t n) {
     size_t h = (size_t)SORT_BINS * sort_blocks(n);
-    return h + SORT_BINS + 64;
+    size_t chunks = (sort_blocks(n) + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
+    return h + SORT_BINS + (size_t)SORT_BINS * chunks + 64;
 }
 inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 
