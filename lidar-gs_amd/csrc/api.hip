@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits>
+#include <mutex>
 
 namespace {
 
@@ -52,14 +53,51 @@ int check_launch(hipStream_t s, int debug, const char* what) {
         if (rc_) return rc_;                                  \
     } while (0)
 
-int tile_rows() {
+// LIDARGS_TILE_ROWS forces the list-tile height (4, 8, 16 or 32 pixel rows); unset = chosen per frame (choose_tile_rows).
+int forced_tile_rows() {
     static int th = [] {
         const char* e = getenv("LIDARGS_TILE_ROWS");
-        int v = e ? atoi(e) : 4;
-        if (v != 4 && v != 8 && v != 16 && v != 32) v = 4;
-        return v;
+        const int v = e ? atoi(e) : 0;
+        return (v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
     }();
     return th;
+}
+int tile_rows() { return forced_tile_rows() ? forced_tile_rows() : 4; }      // what non-adaptive callers (surfel variant) use
+
+// Tile height from the instance totals the preprocess accumulated for heights 4 / 8 / 16.  The blend costs the same for every
+// height (per-lane row test + contribution flags), the binning costs ~18 ns per 1000 instances, and a taller tile makes pass 1
+// visit entries that do not reach a patch's rows.  Measured: street scenes (instances shrink 1.27x / 1.46x at 8 / 16 rows) are
+// fastest at 4 rows, an 8 M-Gaussian shell scene with tall footprints (1.74x / 2.77x) at 16 (4.5 -> 3.0 ms).
+int choose_tile_rows(const unsigned long long (&inst)[3]) {
+    if (const int f = forced_tile_rows()) return f;
+    const double r4 = (double)inst[0];
+    if (inst[2] > 0 && r4 / (double)inst[2] >= 2.2) return 16;
+    if (inst[1] > 0 && r4 / (double)inst[1] >= 1.6) return 8;
+    return 4;
+}
+
+// The tile height a forward chose, for the calls that follow it on the same buffers (backward, shell phase 2): a host-side ring
+// keyed by the geometry buffer's address (the buffer cannot be asked without a device read).  4096 forwards may lie between a
+// forward and its backward before an entry is overwritten; a miss is an error, never a guess.
+struct ThEntry { const void* geom; int th; };
+constexpr unsigned TH_RING = 4096;
+std::mutex g_th_mutex;
+ThEntry g_th_ring[TH_RING];
+unsigned g_th_next = 0;
+void remember_tile_rows(const void* geom, int th) {
+    std::lock_guard<std::mutex> lk(g_th_mutex);
+    const unsigned last = (g_th_next + TH_RING - 1) % TH_RING;
+    if (g_th_ring[last].geom == geom) { g_th_ring[last].th = th; return; }       // the training loop re-uses one allocation
+    g_th_ring[g_th_next] = ThEntry{geom, th};
+    g_th_next = (g_th_next + 1) % TH_RING;
+}
+int recall_tile_rows(const void* geom) {
+    std::lock_guard<std::mutex> lk(g_th_mutex);
+    for (unsigned k = 1; k <= TH_RING; k++) {                          // most recent first
+        const ThEntry& e = g_th_ring[(g_th_next + TH_RING - k) % TH_RING];
+        if (e.geom == geom && e.th) return e.th;
+    }
+    return 0;
 }
 
 int max_segments() {
@@ -202,19 +240,19 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: NULL allocator%s");
     if (P == 0) return 0;   // R3/rasterize_points.cu:87: outputs stay as the caller initialised them
 
-    const int TH = tile_rows();
-    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    const lg::TileGrid grid4 = lg::make_grid(width, height, 4);        // the image buffer is laid out for the finest tiling
     g_prof.begin(stream);
 
     char* geom_p = geometry_alloc(geometry_user, lg::geom_carve(nullptr, (size_t)P, nullptr));
     if (!geom_p) return fail(LIDARGS_ERR_ALLOC, "geometry allocator returned NULL%s");
-    char* img_p = image_alloc(image_user, lg::img_carve(nullptr, width, height, grid.num_tiles(), nullptr));
+    char* img_p = image_alloc(image_user, lg::img_carve(nullptr, width, height, grid4.num_tiles(), nullptr));
     if (!img_p) return fail(LIDARGS_ERR_ALLOC, "image allocator returned NULL%s");
     lg::GeomView geom; lg::geom_carve(geom_p, (size_t)P, &geom);
-    lg::ImgView img; lg::img_carve(img_p, width, height, grid.num_tiles(), &img);
+    lg::ImgView img; lg::img_carve(img_p, width, height, grid4.num_tiles(), &img);
+    LG_HIP(hipMemsetAsync(geom.totals, 0, 32 * sizeof(uint32_t), stream));
 
     lg::PreprocessParams pp;
-    pp.P = P; pp.W = width; pp.H = height; pp.TH = TH; pp.tiles_x = grid.tiles_x; pp.tiles_y = grid.tiles_y;
+    pp.P = P; pp.W = width; pp.H = height; pp.TH = 4; pp.tiles_x = grid4.tiles_x; pp.tiles_y = grid4.tiles_y;
     pp.scale_modifier = scale_modifier;
     pp.near_f = near_f; pp.far_f = far_f; pp.shell_lo = shell_lo; pp.shell_hi = shell_hi;
     const float pi_f = 3.14159265358979323846f;
@@ -234,16 +272,32 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     LG_STAGE_CHECK("range sort");
     g_prof.mark("range_sort", stream);
 
-    // 2. instance offsets in range order, total -> host
-    lg::launch_gather_counts(ids_sorted, geom.tcount, geom.cnt_sorted, (size_t)P, stream);
+    // 2. instance offsets in range order for the likeliest tile height (queued before the host wait, so that the device has work
+    //    while the host decides), then the one host wait (R3/cr/rasterizer_impl.cu:292): the instance totals for tile heights
+    //    4 / 8 / 16 -> tile height, R.  Only if another height wins are the offsets recomputed.
     uint32_t* scan_scratch = geom.scratch + lg::sort_scratch_words((size_t)P);
+    const int th_guess = forced_tile_rows() ? forced_tile_rows() : 4;
+    if (th_guess == 4) lg::launch_gather_counts(ids_sorted, geom.tcount, geom.cnt_sorted, (size_t)P, stream);      // one 4-byte gather
+    else lg::launch_gather_counts_spans(ids_sorted, geom.rowspan, geom.xspan, th_guess, geom.cnt_sorted, (size_t)P, stream);
     lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
     LG_STAGE_CHECK("instance scan");
-    uint32_t totals_h[4] = {0, 0, 0, 0};
-    LG_HIP(hipMemcpyAsync(totals_h, geom.totals, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LG_HIP(hipStreamSynchronize(stream));                              // the one host wait (R3/cr/rasterizer_impl.cu:292)
-    const size_t R = totals_h[0];
-    if (R > (size_t)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
+    uint32_t totals_h[16];                                             // [0] scan total, [8..13] the three 64-bit instance totals
+    LG_HIP(hipMemcpyAsync(totals_h, geom.totals, sizeof totals_h, hipMemcpyDeviceToHost, stream));
+    LG_HIP(hipStreamSynchronize(stream));
+    unsigned long long inst[3];
+    memcpy(inst, totals_h + 8, sizeof inst);
+    const uint32_t scan_total = totals_h[0];
+    const unsigned long long inst3[3] = {inst[0], inst[1], inst[2]};
+    const int TH = choose_tile_rows(inst3);
+    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (unsigned long long)scan_total));
+    if (R64 > (unsigned long long)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
+    const size_t R = (size_t)R64;
+    if (TH != th_guess) {
+        lg::launch_gather_counts_spans(ids_sorted, geom.rowspan, geom.xspan, TH, geom.cnt_sorted, (size_t)P, stream);
+        lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
+    }
+    remember_tile_rows(geom_p, TH);
     g_prof.mark("scan+readback", stream);
 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
@@ -323,13 +377,14 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
         !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: NULL required pointer%s");
 
-    const int TH = tile_rows();
+    lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
+    const int TH = recall_tile_rows(geom_buffer);
+    if (!TH) return fail(LIDARGS_ERR_STATE, "backward: these buffers do not come from a forward of this library instance%s");
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
     const int S = lg::choose_segments((size_t)R, max_segments());
-    lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
     lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
-    lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
+    lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     g_prof.begin(stream);
 
     LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
@@ -462,12 +517,14 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
                          float* out_occ, float* T_out, float* T_end_out, int debug, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "render_shell: missing forward buffers%s");
-    const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());
+    lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
+    const int TH = recall_tile_rows(geom_buffer);
+    if (!TH) return fail(LIDARGS_ERR_STATE, "render_shell: these buffers do not come from a forward of this library instance%s");
+    const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
     const int S = lg::choose_segments((size_t)R, max_segments());
-    lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
     lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
-    lg::ImgView img; lg::img_carve(image_buffer, width, height, grid.num_tiles(), &img);
+    lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     lg::RenderFwdArgs ra;
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = bin.val_a; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;

@@ -328,6 +328,23 @@ __global__ void __launch_bounds__(256) k_gather_counts(const uint32_t* __restric
     if (i < P) cnt_sorted[i] = tcount[ids_sorted[i]];
 }
 
+// tiles of a pruned rect for tile height TH: (column span) x (rows of tiles the row span touches); an empty column span = 0
+__global__ void __launch_bounds__(256) k_gather_counts_spans(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ rowspan,
+                                                             const uint32_t* __restrict__ xspan, int TH, uint32_t* __restrict__ cnt_sorted, size_t P) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t g = ids_sorted[i];
+    const uint32_t xs = xspan[g];
+    const uint32_t cols = (xs >> 16) - (xs & 0xFFFFu);
+    uint32_t c = 0;
+    if (cols) { const uint32_t rs = rowspan[g]; c = cols * (((rs >> 16) - 1u) / (uint32_t)TH - (rs & 0xFFFFu) / (uint32_t)TH + 1u); }
+    cnt_sorted[i] = c;
+}
+void launch_gather_counts_spans(const uint32_t* ids_sorted, const uint32_t* rowspan, const uint32_t* xspan, int TH, uint32_t* cnt_sorted, size_t P,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_counts_spans, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, rowspan, xspan, TH, cnt_sorted, P);
+}
+
 void launch_gather_counts(const uint32_t* ids_sorted, const uint32_t* tcount, uint32_t* cnt_sorted, size_t P, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, tcount, cnt_sorted, P);
 }

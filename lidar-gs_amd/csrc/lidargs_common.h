@@ -13,7 +13,6 @@
 //     rowspan  u32[P]      ymin | ymax<<16 of the reference's pixel-row rect (R3/cr/auxiliary.h:80-92)
 //     xspan    u32[P]      xmin | xmax<<16 of the same rect, in 16-pixel tile columns
 //     key_a    u32[P]      float bits of the range (sort key), 0xFFFFFFFF when culled
-//     tcount   u32[P]      #(16 x TH) tiles touched
 //     ref_tiles u32[P]     the reference's 16x1 tiles_touched (statistics only: R_ref)
 //     sort ping/pong, sorted ids, per-sorted-Gaussian instance offsets, scan/sort scratch
 //   binning buffer   (sized by R = #instances)
@@ -76,11 +75,11 @@ struct GeomView {
     float4* rec;
     uint32_t* rowspan;
     uint32_t* xspan;
-    uint32_t* tcount;
     uint32_t* ref_tiles;
     uint32_t* key_a; uint32_t* key_b;   // range keys ping/pong
     uint32_t* id_a; uint32_t* id_b;     // Gaussian ids ping/pong (id_sorted ends in id_a)
-    uint32_t* cnt_sorted;               // tcount gathered in range order
+    uint32_t* tcount;                   // (16 x 4) tiles touched: the instance count for the default tile height
+    uint32_t* cnt_sorted;               // tiles touched for the chosen tile height, in range order
     uint32_t* off_sorted;               // exclusive scan of cnt_sorted
     uint32_t* totals;                   // [0]=#instances, [1]=#visible, [2..3]=R_ref (u64)
     float* gacc;                        // [16P] packed per-Gaussian gradient accumulators (backward)
@@ -94,8 +93,8 @@ inline size_t geom_carve(char* base, size_t P, GeomView* v) {
     g.rec = c.take<float4>(4 * P);
     g.rowspan = c.take<uint32_t>(P);
     g.xspan = c.take<uint32_t>(P);
-    g.tcount = c.take<uint32_t>(P);
     g.ref_tiles = c.take<uint32_t>(P);
+    g.tcount = c.take<uint32_t>(P);
     g.key_a = c.take<uint32_t>(P); g.key_b = c.take<uint32_t>(P);
     g.id_a = c.take<uint32_t>(P); g.id_b = c.take<uint32_t>(P);
     g.cnt_sorted = c.take<uint32_t>(P);
@@ -220,6 +219,8 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s);
 void launch_gather_counts(const uint32_t* ids_sorted, const uint32_t* tcount, uint32_t* cnt_sorted, size_t P, hipStream_t s);
+void launch_gather_counts_spans(const uint32_t* ids_sorted, const uint32_t* rowspan, const uint32_t* xspan, int TH, uint32_t* cnt_sorted, size_t P,
+                                hipStream_t s);
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* cnt_sorted, const uint32_t* off_sorted,
                            const uint32_t* rowspan, const uint32_t* xspan, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s);
