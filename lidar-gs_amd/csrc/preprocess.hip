@@ -112,6 +112,16 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const PreprocessParams& pp = a.pp;
     const bool in_range = idx < pp.P;                                  // no early return: the whole wave takes part in the sums at the end
+    // the beam table is binary-searched three times per Gaussian (6 dependent reads each): keep it in LDS when it fits
+    constexpr int BEAMS_LDS = 1024;
+    __shared__ float s_beams[BEAMS_LDS];
+    const bool lds_beams = pp.H <= BEAMS_LDS;
+    if (lds_beams) {
+        for (int q = threadIdx.x; q < pp.H; q += blockDim.x) s_beams[q] = a.beams[q];
+        __syncthreads();
+    }
+    const float* __restrict__ beams = a.beams;
+    auto beam = [&](int q) { return lds_beams ? s_beams[q] : beams[q]; };
 
     int out_radius = 0, rx = 0, ry = 0;
     uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0, t4 = 0, t8 = 0, t16 = 0;
@@ -171,21 +181,21 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // beam row: clamp at the ends, else first beam >= alpha (R3/cr/auxiliary.h:41-63)
         const int H = pp.H;
         int bi;
-        if (alpha >= a.beams[H - 1]) bi = H - 1;
-        else if (alpha <= a.beams[0]) bi = 0;
+        if (alpha >= beam(H - 1)) bi = H - 1;
+        else if (alpha <= beam(0)) bi = 0;
         else {
             int lo = 0, hi = H;
-            while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] < alpha) lo = md + 1; else hi = md; }
+            while (lo < hi) { const int md = (lo + hi) >> 1; if (beam(md) < alpha) lo = md + 1; else hi = md; }
             bi = lo;
         }
         float before, after, p_r;
         const float guard = 0.002f * 2;                                // Ray_Divergence_Angle*2, :22/:347/:356
         if (bi > 0) {
-            before = a.beams[bi - 1]; after = a.beams[bi];
+            before = beam(bi - 1); after = beam(bi);
             p_r = (float)(bi - 1) + (alpha - before) / (after - before);
             if (alpha > (after + guard)) break;
         } else {
-            before = a.beams[0]; after = a.beams[1];
+            before = beam(0); after = beam(1);
             p_r = (float)(bi + 1) + (alpha - after) / (after - before);
             if (alpha < (before - guard)) break;
         }
@@ -227,7 +237,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         else {
             const float tau2 = 2.f * (logf(255.f * op) + 0.02f);
             const float hx = sqrtf(tau2 * ca) * 1.002f + 1e-6f, hy = sqrtf(tau2 * cc) * 1.002f + 1e-6f;
-            const float cfan = fminf(cosf(a.beams[0]), cosf(a.beams[H - 1])) * 0.999f;   // min cos(elevation) of any pixel row
+            const float cfan = fminf(cosf(beam(0)), cosf(beam(H - 1))) * 0.999f;   // min cos(elevation) of any pixel row
             const float sb = hx / cfan;                                // bound on |sin(dbeta)|
             float one_m_cos = 2.f;                                     // 1 - cos(dbeta_max): worst case if unbounded
             if (sb < 0.7f) {
@@ -242,10 +252,10 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
                 const float dalpha = asinf(sa) * 1.002f + 2e-5f;
                 const float e_lo = alpha - dalpha, e_hi = alpha + dalpha;
                 int lo = 0, hi = H;                                    // first beam >= e_lo
-                while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] < e_lo) lo = md + 1; else hi = md; }
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (beam(md) < e_lo) lo = md + 1; else hi = md; }
                 const int i_lo = lo;
                 lo = 0; hi = H;                                        // first beam > e_hi
-                while (lo < hi) { const int md = (lo + hi) >> 1; if (a.beams[md] <= e_hi) lo = md + 1; else hi = md; }
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (beam(md) <= e_hi) lo = md + 1; else hi = md; }
                 const int i_hi = lo;                                   // beams [i_lo, i_hi) are in reach
                 ty_lo = max(ty_lo, H - i_hi);                          // pixel row y = H-1-i
                 ty_hi = min(ty_hi, H - i_lo);
