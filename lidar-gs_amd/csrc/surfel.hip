@@ -92,6 +92,15 @@ struct SfPreArgs {
 template <bool FILTER>
 __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // the beam table is binary-searched five times per surfel: keep it in LDS when it fits (as k_preprocess does)
+    constexpr int BEAMS_LDS = 1024;
+    __shared__ float s_beams[BEAMS_LDS];
+    const bool lds_beams = a.H <= BEAMS_LDS;
+    if (lds_beams) {
+        for (int q = threadIdx.x; q < a.H; q += blockDim.x) s_beams[q] = a.beams[q];
+        __syncthreads();
+    }
+    const float* __restrict__ beams_tab = lds_beams ? s_beams : a.beams;
     if (idx >= a.P) return;
     int out_radius = 0, rx = 0, ry = 0;
     uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0;
@@ -105,7 +114,7 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         const float dist = sqrtf(pv.x * pv.x + pv.y * pv.y + pv.z * pv.z);
         if (dist >= a.far_f || dist <= a.near_f) break;
         float2 pim;
-        if (!sf_pix(pv, a.W, a.H, a.beams, true, a.col_step, pim)) break;
+        if (!sf_pix(pv, a.W, a.H, beams_tab, true, a.col_step, pim)) break;
 
         const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
         float3 c0, c1, c2;
@@ -122,10 +131,10 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         }
         // extent: +-3 sigma axis end points through the beam model, at least one pixel (:177-215)
         float2 e0, e1, e2, e3;
-        sf_pix(sf3(pv.x + 3.f * Tu.x, pv.y + 3.f * Tu.y, pv.z + 3.f * Tu.z), a.W, a.H, a.beams, false, a.col_step, e0);
-        sf_pix(sf3(pv.x - 3.f * Tu.x, pv.y - 3.f * Tu.y, pv.z - 3.f * Tu.z), a.W, a.H, a.beams, false, a.col_step, e1);
-        sf_pix(sf3(pv.x + 3.f * Tv.x, pv.y + 3.f * Tv.y, pv.z + 3.f * Tv.z), a.W, a.H, a.beams, false, a.col_step, e2);
-        sf_pix(sf3(pv.x - 3.f * Tv.x, pv.y - 3.f * Tv.y, pv.z - 3.f * Tv.z), a.W, a.H, a.beams, false, a.col_step, e3);
+        sf_pix(sf3(pv.x + 3.f * Tu.x, pv.y + 3.f * Tu.y, pv.z + 3.f * Tu.z), a.W, a.H, beams_tab, false, a.col_step, e0);
+        sf_pix(sf3(pv.x - 3.f * Tu.x, pv.y - 3.f * Tu.y, pv.z - 3.f * Tu.z), a.W, a.H, beams_tab, false, a.col_step, e1);
+        sf_pix(sf3(pv.x + 3.f * Tv.x, pv.y + 3.f * Tv.y, pv.z + 3.f * Tv.z), a.W, a.H, beams_tab, false, a.col_step, e2);
+        sf_pix(sf3(pv.x - 3.f * Tv.x, pv.y - 3.f * Tv.y, pv.z - 3.f * Tv.z), a.W, a.H, beams_tab, false, a.col_step, e3);
         const float ax = fmaxf(fabsf(e0.x - pim.x), fabsf(e1.x - pim.x)), ay = fmaxf(fabsf(e0.y - pim.y), fabsf(e1.y - pim.y));
         const float bx = fmaxf(fabsf(e2.x - pim.x), fabsf(e3.x - pim.x)), by = fmaxf(fabsf(e2.y - pim.y), fabsf(e3.y - pim.y));
         rx = (int)ceilf(fmaxf(fmaxf(ax, bx), 1.0f));
