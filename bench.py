@@ -382,6 +382,17 @@ def bench_chamfer(args):
     print(json.dumps(out))
 
 
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that buffer is only written at
+    process exit, i.e. AFTER the JSON line.  Flushing it early keeps the JSON line the last thing on stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -490,6 +501,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    _flush_c_stdio()                    # every rank: whatever the collectives' bring-up printed goes out now, not at exit
     _C.profile_enable(True)             # reset: from here on only hipEventRecord per stage, no host waits
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
@@ -549,7 +561,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kind, P, H, W, seed)
         elif world == 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
     if world > 1 or force_shells:
         import torch.distributed as dist
         dist.destroy_process_group()
