@@ -518,6 +518,18 @@ def main():
 
     allocs1 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     stages = _C.profile_summary()
+    spread = None
+    if world == 1 and not force_shells:
+        # per-frame distribution (median and p10 / p90), after and outside the contract's timed region: one event per
+        # frame on torch's current stream, which is the stream the op launches on
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        ev[0].record()
+        for i in range(args.steps):
+            step()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
+        spread = {"p10": float(np.percentile(per, 10)), "median": float(np.median(per)), "p90": float(np.percentile(per, 90))}
     cnt = _C.last_counters()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -555,6 +567,7 @@ def main():
                          "frame_algorithmic_bytes": fwd_b + bwd_b,
                          "frame_achieved_GBs": (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9},
             "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+            "frame_ms_spread": spread,
             "hipmalloc_calls_in_timed_region": int(allocs1 - allocs0),
         }
         if not args.no_cpu_baseline and world == 1:

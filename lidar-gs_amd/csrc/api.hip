@@ -79,16 +79,16 @@ int choose_tile_rows(const unsigned long long (&inst)[3]) {
 // The tile height a forward chose, for the calls that follow it on the same buffers (backward, shell phase 2): a host-side ring
 // keyed by the geometry buffer's address (the buffer cannot be asked without a device read).  4096 forwards may lie between a
 // forward and its backward before an entry is overwritten; a miss is an error, never a guess.
-struct ThEntry { const void* geom; int th; };
+struct ThEntry { const void* geom; int th; bool grads_zeroed; };
 constexpr unsigned TH_RING = 4096;
 std::mutex g_th_mutex;
 ThEntry g_th_ring[TH_RING];
 unsigned g_th_next = 0;
-void remember_tile_rows(const void* geom, int th) {
+void remember_tile_rows(const void* geom, int th, bool grads_zeroed) {
     std::lock_guard<std::mutex> lk(g_th_mutex);
     const unsigned last = (g_th_next + TH_RING - 1) % TH_RING;
-    if (g_th_ring[last].geom == geom) { g_th_ring[last].th = th; return; }       // the training loop re-uses one allocation
-    g_th_ring[g_th_next] = ThEntry{geom, th};
+    if (g_th_ring[last].geom == geom) { g_th_ring[last].th = th; g_th_ring[last].grads_zeroed = grads_zeroed; return; }   // the training loop re-uses one allocation
+    g_th_ring[g_th_next] = ThEntry{geom, th, grads_zeroed};
     g_th_next = (g_th_next + 1) % TH_RING;
 }
 int recall_tile_rows(const void* geom) {
@@ -99,6 +99,33 @@ int recall_tile_rows(const void* geom) {
     }
     return 0;
 }
+// The forward zeroes the per-Gaussian gradient lines while the host waits for the instance count (the device would idle
+// there); the first backward on those buffers takes that over, a second one (retain_graph) has to zero them itself.
+bool take_zeroed_gradients(const void* geom) {
+    std::lock_guard<std::mutex> lk(g_th_mutex);
+    for (unsigned k = 1; k <= TH_RING; k++) {
+        ThEntry& e = g_th_ring[(g_th_next + TH_RING - k) % TH_RING];
+        if (e.geom == geom && e.th) { const bool z = e.grads_zeroed; e.grads_zeroed = false; return z; }
+    }
+    return false;
+}
+
+// One pinned 64-byte landing buffer and one event per host thread and device: the host waits for the copy alone, not for what
+// was queued behind it.
+struct HostRead {
+    uint32_t* words = nullptr; hipEvent_t copied = nullptr; int device = -1;
+    bool ready() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (words && dev == device) return true;
+        if (copied) { (void)hipEventDestroy(copied); copied = nullptr; }
+        if (!words && hipHostMalloc((void**)&words, 64, hipHostMallocDefault) != hipSuccess) { words = nullptr; return false; }
+        if (hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess) { copied = nullptr; return false; }
+        device = dev;
+        return true;
+    }
+};
+thread_local HostRead t_host_read;
 
 int max_segments() {
     static int v = [] {
@@ -185,6 +212,17 @@ int api_ceil_log2(uint32_t n) { return ceil_log2(n); }
 int api_max_segments() { return max_segments(); }
 int api_segment_length() { return segment_length(); }
 int api_pass1_rounds(int* out, int cap) { return pass1_rounds(out, cap); }
+int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s) {
+    if (n > 16 || !t_host_read.ready()) return (int)hipErrorOutOfMemory;
+    hipError_t e = hipMemcpyAsync(t_host_read.words, dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(t_host_read.copied, s);
+    if (e == hipSuccess && zero && zero_bytes) e = hipMemsetAsync(zero, 0, zero_bytes, s);
+    if (e == hipSuccess) e = hipEventSynchronize(t_host_read.copied);
+    if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
+    return (int)e;
+}
+void api_remember_forward(const void* geom, int tile_rows, bool grads_zeroed) { remember_tile_rows(geom, tile_rows, grads_zeroed); }
+bool api_take_zeroed_gradients(const void* geom) { return take_zeroed_gradients(geom); }
 }  // namespace lg
 
 namespace {
@@ -282,8 +320,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
     LG_STAGE_CHECK("instance scan");
     uint32_t totals_h[16];                                             // [0] scan total, [8..13] the three 64-bit instance totals
-    LG_HIP(hipMemcpyAsync(totals_h, geom.totals, sizeof totals_h, hipMemcpyDeviceToHost, stream));
-    LG_HIP(hipStreamSynchronize(stream));
+    // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
+    LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, 16, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
     unsigned long long inst[3];
     memcpy(inst, totals_h + 8, sizeof inst);
     const uint32_t scan_total = totals_h[0];
@@ -297,7 +335,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         lg::launch_gather_counts_spans(ids_sorted, geom.rowspan, geom.xspan, TH, geom.cnt_sorted, (size_t)P, stream);
         lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
     }
-    remember_tile_rows(geom_p, TH);
+    remember_tile_rows(geom_p, TH, true);
     g_prof.mark("scan+readback", stream);
 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
@@ -387,7 +425,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     g_prof.begin(stream);
 
-    LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
+    if (!take_zeroed_gradients(geom_buffer)) LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
     g_prof.mark("bwd_zero", stream);
 
     lg::RenderBwdArgs rb;

@@ -199,6 +199,11 @@ int api_ceil_log2(uint32_t n);
 int api_max_segments();
 int api_segment_length();
 int api_pass1_rounds(int* out, int cap);
+// Device -> host read of `n` (<= 16) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
+// for the copy only.  Returns a hipError_t.
+int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s);
+void api_remember_forward(const void* geom, int tile_rows, bool grads_zeroed);
+bool api_take_zeroed_gradients(const void* geom);
 
 // kernels / launchers (defined in the .hip files)
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);

@@ -195,3 +195,31 @@ def test_random_small_scenes(seed, hip_lib_built):
     small = H * W < 4000 or P < 200                       # tiny problems: the outlier budget is a count of 2, judge them absolutely
     for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
         parity(k, hip[k], ref[k], outlier_frac=(5e-3 if small else 2e-3))
+
+
+def test_backward_twice_on_one_forward(hip_lib_built):
+    """retain_graph: the forward pre-zeroes the per-Gaussian gradient lines for ONE backward; a second backward on the same
+    buffers has to start from zero as well (same gradients, not doubled), also when another forward ran in between."""
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import to_torch, make_settings
+    H, W = 32, 500
+    scene = sc.make_scene("street", 8000, H, 31, random_view=True)
+    st = to_torch(scene)
+    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((8000, 4), device="cuda", requires_grad=True)
+    rast = GaussianRasterizer(make_settings(st, W, H))
+    gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, 31))
+    call = lambda: rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                        scales=leaves["scales"], rotations=leaves["rotations"])
+    color, depth, occ, _ = call()
+    inputs = list(leaves.values()) + [means2D]
+    first = torch.autograd.grad([color, depth, occ], inputs, [gc, gd, go], retain_graph=True)
+    other = call()                                       # a forward on other buffers in between
+    second = torch.autograd.grad([color, depth, occ], inputs, [gc, gd, go], retain_graph=True)
+    third = torch.autograd.grad(list(other[:3]), inputs, [gc, gd, go])
+    for a, b, c in zip(first, second, third):
+        assert torch.isfinite(a).all()
+        # float atomics order the sums differently from launch to launch: compare at the parity tolerance
+        parity("second backward", b.cpu().numpy(), a.cpu().numpy(), verbose=False)
+        parity("other forward's backward", c.cpu().numpy(), a.cpu().numpy(), verbose=False)
