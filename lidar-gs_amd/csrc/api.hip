@@ -110,16 +110,17 @@ bool take_zeroed_gradients(const void* geom) {
     return false;
 }
 
-// One pinned 64-byte landing buffer and one event per host thread and device: the host waits for the copy alone, not for what
+// One pinned 4-KB landing buffer and one event per host thread and device: the host waits for the copy alone, not for what
 // was queued behind it.
 struct HostRead {
+    static constexpr int WORDS = 1024;
     uint32_t* words = nullptr; hipEvent_t copied = nullptr; int device = -1;
     bool ready() {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (words && dev == device) return true;
         if (copied) { (void)hipEventDestroy(copied); copied = nullptr; }
-        if (!words && hipHostMalloc((void**)&words, 64, hipHostMallocDefault) != hipSuccess) { words = nullptr; return false; }
+        if (!words && hipHostMalloc((void**)&words, WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { words = nullptr; return false; }
         if (hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess) { copied = nullptr; return false; }
         device = dev;
         return true;
@@ -213,7 +214,7 @@ int api_max_segments() { return max_segments(); }
 int api_segment_length() { return segment_length(); }
 int api_pass1_rounds(int* out, int cap) { return pass1_rounds(out, cap); }
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s) {
-    if (n > 16 || !t_host_read.ready()) return (int)hipErrorOutOfMemory;
+    if (n > HostRead::WORDS || !t_host_read.ready()) return (int)hipErrorOutOfMemory;
     hipError_t e = hipMemcpyAsync(t_host_read.words, dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipEventRecord(t_host_read.copied, s);
     if (e == hipSuccess && zero && zero_bytes) e = hipMemsetAsync(zero, 0, zero_bytes, s);
@@ -287,7 +288,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (!img_p) return fail(LIDARGS_ERR_ALLOC, "image allocator returned NULL%s");
     lg::GeomView geom; lg::geom_carve(geom_p, (size_t)P, &geom);
     lg::ImgView img; lg::img_carve(img_p, width, height, grid4.num_tiles(), &img);
-    LG_HIP(hipMemsetAsync(geom.totals, 0, 32 * sizeof(uint32_t), stream));
+    LG_HIP(hipMemsetAsync(geom.totals, 0, LG_TOTALS_WORDS * sizeof(uint32_t), stream));
 
     lg::PreprocessParams pp;
     pp.P = P; pp.W = width; pp.H = height; pp.TH = 4; pp.tiles_x = grid4.tiles_x; pp.tiles_y = grid4.tiles_y;
@@ -315,15 +316,18 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     //    4 / 8 / 16 -> tile height, R.  Only if another height wins are the offsets recomputed.
     uint32_t* scan_scratch = geom.scratch + lg::sort_scratch_words((size_t)P);
     const int th_guess = forced_tile_rows() ? forced_tile_rows() : 4;
-    if (th_guess == 4) lg::launch_gather_counts(ids_sorted, geom.tcount, geom.cnt_sorted, (size_t)P, stream);      // one 4-byte gather
-    else lg::launch_gather_counts_spans(ids_sorted, geom.rowspan, geom.xspan, th_guess, geom.cnt_sorted, (size_t)P, stream);
+    lg::launch_gather_counts(ids_sorted, geom.spans, th_guess, geom.cnt_sorted, geom.span_sorted, (size_t)P, stream);   // one 16-byte gather
     lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
     LG_STAGE_CHECK("instance scan");
-    uint32_t totals_h[16];                                             // [0] scan total, [8..13] the three 64-bit instance totals
+    uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
     // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
-    LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, 16, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
-    unsigned long long inst[3];
-    memcpy(inst, totals_h + 8, sizeof inst);
+    LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, LG_TOTALS_WORDS, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
+    unsigned long long inst[3] = {0, 0, 0};
+    for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
+        unsigned long long v[4];
+        memcpy(v, totals_h + LG_TOTALS_SLOT_WORD + 8 * slot, sizeof v);
+        inst[0] += v[0]; inst[1] += v[1]; inst[2] += v[2];
+    }
     const uint32_t scan_total = totals_h[0];
     const unsigned long long inst3[3] = {inst[0], inst[1], inst[2]};
     const int TH = choose_tile_rows(inst3);
@@ -332,7 +336,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (R64 > (unsigned long long)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
     const size_t R = (size_t)R64;
     if (TH != th_guess) {
-        lg::launch_gather_counts_spans(ids_sorted, geom.rowspan, geom.xspan, TH, geom.cnt_sorted, (size_t)P, stream);
+        lg::launch_gather_counts(ids_sorted, geom.spans, TH, geom.cnt_sorted, geom.span_sorted, (size_t)P, stream);
         lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
     }
     remember_tile_rows(geom_p, TH, true);
@@ -347,7 +351,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 3. emit instances in range order, bin them by tile (stable)
     const uint32_t* point_list = bin.val_a;
     if (R) {
-        lg::launch_emit_instances(ids_sorted, geom.cnt_sorted, geom.off_sorted, geom.rowspan, geom.xspan, (size_t)P, grid,
+        lg::launch_emit_instances(ids_sorted, geom.off_sorted, geom.span_sorted, (size_t)P, grid,
                                   bin.tile_a, bin.val_a, stream);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
@@ -393,7 +397,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_counters[5] = grid.num_tiles();
     g_counters[6] = -1; g_counters[7] = S;
     g_last_flags = ra.flags; g_last_flags_n = (size_t)grid.waves_per_tile * R;
-    g_last_totals_dev = geom.ref_tiles;   // R_ref / V are reduced lazily in lidargs_last_counters
+    g_last_totals_dev = (uint32_t*)geom.spans;   // R_ref / V are reduced lazily in lidargs_last_counters (word 3 of each span)
     g_last_stream = stream;
     return (int)R;
 }
@@ -663,10 +667,10 @@ int lidargs_last_counters(long long* out, int n) {
     if (g_counters[1] < 0 && g_last_totals_dev && g_counters[0] > 0) {
         // reduce ref_tiles on the host (diagnostics path, not on any timed path)
         const size_t P = (size_t)g_counters[0];
-        uint32_t* h = (uint32_t*)malloc(P * sizeof(uint32_t));
-        if (h && hipMemcpy(h, g_last_totals_dev, P * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+        uint32_t* h = (uint32_t*)malloc(4 * P * sizeof(uint32_t));
+        if (h && hipMemcpy(h, g_last_totals_dev, 4 * P * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
             long long v = 0, r = 0;
-            for (size_t i = 0; i < P; i++) { if (h[i]) v++; r += h[i]; }
+            for (size_t i = 0; i < P; i++) { if (h[4 * i + 3]) v++; r += h[4 * i + 3]; }
             g_counters[1] = v; g_counters[3] = r;
         }
         free(h);

@@ -322,52 +322,46 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gather_counts(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ tcount,
-                                                       uint32_t* __restrict__ cnt_sorted, size_t P) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < P) cnt_sorted[i] = tcount[ids_sorted[i]];
+// tiles of a pruned rect for tile height TH (a power of two): (column span) x (rows of tiles the row span touches); an empty
+// column span = 0
+__device__ __forceinline__ uint32_t span_tiles(uint32_t xs, uint32_t rs, int th_shift) {
+    const uint32_t cols = (xs >> 16) - (xs & 0xFFFFu);
+    return cols ? cols * ((((rs >> 16) - 1u) >> th_shift) - ((rs & 0xFFFFu) >> th_shift) + 1u) : 0u;
 }
 
-// tiles of a pruned rect for tile height TH: (column span) x (rows of tiles the row span touches); an empty column span = 0
-__global__ void __launch_bounds__(256) k_gather_counts_spans(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ rowspan,
-                                                             const uint32_t* __restrict__ xspan, int TH, uint32_t* __restrict__ cnt_sorted, size_t P) {
+// One 16-byte gather per Gaussian in range order -> its instance count and its spans, written in range order
+__global__ void __launch_bounds__(256) k_gather_counts(const uint32_t* __restrict__ ids_sorted, const uint4* __restrict__ spans, int th_shift,
+                                                       uint32_t* __restrict__ cnt_sorted, uint2* __restrict__ span_sorted, size_t P) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const uint32_t g = ids_sorted[i];
-    const uint32_t xs = xspan[g];
-    const uint32_t cols = (xs >> 16) - (xs & 0xFFFFu);
-    uint32_t c = 0;
-    if (cols) { const uint32_t rs = rowspan[g]; c = cols * (((rs >> 16) - 1u) / (uint32_t)TH - (rs & 0xFFFFu) / (uint32_t)TH + 1u); }
-    cnt_sorted[i] = c;
+    const uint4 sp = spans[ids_sorted[i]];
+    cnt_sorted[i] = span_tiles(sp.y, sp.x, th_shift);
+    span_sorted[i] = make_uint2(sp.y, sp.x);
 }
-void launch_gather_counts_spans(const uint32_t* ids_sorted, const uint32_t* rowspan, const uint32_t* xspan, int TH, uint32_t* cnt_sorted, size_t P,
-                                hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_counts_spans, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, rowspan, xspan, TH, cnt_sorted, P);
-}
-
-void launch_gather_counts(const uint32_t* ids_sorted, const uint32_t* tcount, uint32_t* cnt_sorted, size_t P, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, tcount, cnt_sorted, P);
+void launch_gather_counts(const uint32_t* ids_sorted, const uint4* spans, int TH, uint32_t* cnt_sorted, uint2* span_sorted, size_t P, hipStream_t s) {
+    int sh = 0;
+    while ((1 << sh) < TH) sh++;
+    hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, spans, sh, cnt_sorted, span_sorted, P);
 }
 
 // Load-balanced expansion: each wave owns 64 range-consecutive Gaussians and writes their
 // instances cooperatively, 64 consecutive output slots per step (coalesced 256-B stores),
 // instead of one thread looping over its own rect (the reference's duplicateWithKeys,
 // R3/cr/rasterizer_impl.cu:70-112, whose per-thread trip count varies 1..100s).
-__global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ cnt_sorted,
-                                                        const uint32_t* __restrict__ off_sorted, const uint32_t* __restrict__ rowspan,
-                                                        const uint32_t* __restrict__ xspan, size_t P, int TH, int tiles_x,
+__global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ off_sorted,
+                                                        const uint2* __restrict__ span_sorted, size_t P, int th_shift, int tiles_x,
                                                         uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val) {
     const int lane = threadIdx.x & 63;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t cnt = 0, off = 0, g = 0, nx = 1, x0 = 0, ty0 = 0;
     if (i < P) {
-        cnt = cnt_sorted[i];
+        const uint2 sp = span_sorted[i];                               // (xspan, rowspan)
+        cnt = span_tiles(sp.x, sp.y, th_shift);
         off = off_sorted[i];
         if (cnt) {
             g = ids_sorted[i];
-            const uint32_t xs = xspan[g], rs = rowspan[g];
-            x0 = xs & 0xFFFFu; nx = (xs >> 16) - x0;
-            ty0 = (rs & 0xFFFFu) / (uint32_t)TH;
+            x0 = sp.x & 0xFFFFu; nx = (sp.x >> 16) - x0;
+            ty0 = (sp.y & 0xFFFFu) >> th_shift;
         }
     }
     const bool valid = i < P;
@@ -397,11 +391,12 @@ __global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restri
     }
 }
 
-void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* cnt_sorted, const uint32_t* off_sorted,
-                           const uint32_t* rowspan, const uint32_t* xspan, size_t P, TileGrid grid,
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* off_sorted, const uint2* span_sorted, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s) {
-    hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, cnt_sorted, off_sorted,
-                       rowspan, xspan, P, grid.TH, grid.tiles_x, inst_tile, inst_val);
+    int sh = 0;
+    while ((1 << sh) < grid.TH) sh++;
+    hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, off_sorted, span_sorted, P, sh,
+                       grid.tiles_x, inst_tile, inst_val);
 }
 
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys; ranges pre-zeroed (:324)

@@ -10,10 +10,11 @@
 //                            rec[1] = (u1'.x, u1'.y, u1'.z, A)     u1' = u1/(u1.u1), conic A
 //                            rec[2] = (u2'.x, u2'.y, u2'.z, B)     u2' = u2/(u2.u2), conic B
 //                            rec[3] = (C, opacity, colour0, colour1)
-//     rowspan  u32[P]      ymin | ymax<<16 of the reference's pixel-row rect (R3/cr/auxiliary.h:80-92)
-//     xspan    u32[P]      xmin | xmax<<16 of the same rect, in 16-pixel tile columns
+//     rowspan  u32[P]      ymin | ymax<<16 of the (pruned) pixel-row rect (R3/cr/auxiliary.h:80-92): read per list entry by the blend
+//     spans    u32x4[P]    (rowspan, xspan = xmin | xmax<<16 in 16-pixel tile columns (0 = no instances), instance count at
+//                           4-row tiles, the reference's 16x1 tiles_touched): ONE 16-byte gather per Gaussian when the lists are built
+//     span_sorted u32x2[P] (xspan, rowspan) in range order: the instance emit reads no per-Gaussian array at random
 //     key_a    u32[P]      float bits of the range (sort key), 0xFFFFFFFF when culled
-//     ref_tiles u32[P]     the reference's 16x1 tiles_touched (statistics only: R_ref)
 //     sort ping/pong, sorted ids, per-sorted-Gaussian instance offsets, scan/sort scratch
 //   binning buffer   (sized by R = #instances)
 //     tile keys ping/pong u32[R], Gaussian ids ping/pong u32[R], sort scratch
@@ -71,14 +72,18 @@ inline size_t sort_scratch_words(size_t n) {
 }
 inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 
+// totals: word 0 = instance total of the scan; from word LG_TOTALS_SLOT_WORD on, LG_INST_SLOTS slots of four 64-bit sums (the
+// instance counts for tile heights 4 / 8 / 16 + pad), one 32-byte slot per group of preprocess blocks
+#define LG_INST_SLOTS 64
+#define LG_TOTALS_SLOT_WORD 8
+#define LG_TOTALS_WORDS (LG_TOTALS_SLOT_WORD + 8 * LG_INST_SLOTS)
 struct GeomView {
     float4* rec;
     uint32_t* rowspan;
-    uint32_t* xspan;
-    uint32_t* ref_tiles;
+    uint4* spans;                       // (rowspan, xspan, instances at 4-row tiles, reference tiles_touched)
+    uint2* span_sorted;                 // (xspan, rowspan) of the i-th Gaussian in range order
     uint32_t* key_a; uint32_t* key_b;   // range keys ping/pong
     uint32_t* id_a; uint32_t* id_b;     // Gaussian ids ping/pong (id_sorted ends in id_a)
-    uint32_t* tcount;                   // (16 x 4) tiles touched: the instance count for the default tile height
     uint32_t* cnt_sorted;               // tiles touched for the chosen tile height, in range order
     uint32_t* off_sorted;               // exclusive scan of cnt_sorted
     uint32_t* totals;                   // [0]=#instances, [1]=#visible, [2..3]=R_ref (u64)
@@ -92,14 +97,13 @@ inline size_t geom_carve(char* base, size_t P, GeomView* v) {
     GeomView g;
     g.rec = c.take<float4>(4 * P);
     g.rowspan = c.take<uint32_t>(P);
-    g.xspan = c.take<uint32_t>(P);
-    g.ref_tiles = c.take<uint32_t>(P);
-    g.tcount = c.take<uint32_t>(P);
+    g.spans = c.take<uint4>(P);
+    g.span_sorted = c.take<uint2>(P);
     g.key_a = c.take<uint32_t>(P); g.key_b = c.take<uint32_t>(P);
     g.id_a = c.take<uint32_t>(P); g.id_b = c.take<uint32_t>(P);
     g.cnt_sorted = c.take<uint32_t>(P);
     g.off_sorted = c.take<uint32_t>(P);
-    g.totals = c.take<uint32_t>(32);
+    g.totals = c.take<uint32_t>(LG_TOTALS_WORDS);
     g.gacc = c.take<float>(16 * P);
     g.scratch_words = sort_scratch_words(P) + scan_scratch_words(P);
     g.scratch = c.take<uint32_t>(g.scratch_words);
@@ -199,7 +203,7 @@ int api_ceil_log2(uint32_t n);
 int api_max_segments();
 int api_segment_length();
 int api_pass1_rounds(int* out, int cap);
-// Device -> host read of `n` (<= 16) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
+// Device -> host read of `n` (<= 1024) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
 // for the copy only.  Returns a hipError_t.
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s);
 void api_remember_forward(const void* geom, int tile_rows, bool grads_zeroed);
@@ -223,11 +227,8 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 // sorts (key,val) pairs on key bits [0,end_bit); result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s);
-void launch_gather_counts(const uint32_t* ids_sorted, const uint32_t* tcount, uint32_t* cnt_sorted, size_t P, hipStream_t s);
-void launch_gather_counts_spans(const uint32_t* ids_sorted, const uint32_t* rowspan, const uint32_t* xspan, int TH, uint32_t* cnt_sorted, size_t P,
-                                hipStream_t s);
-void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* cnt_sorted, const uint32_t* off_sorted,
-                           const uint32_t* rowspan, const uint32_t* xspan, size_t P, TileGrid grid,
+void launch_gather_counts(const uint32_t* ids_sorted, const uint4* spans, int TH, uint32_t* cnt_sorted, uint2* span_sorted, size_t P, hipStream_t s);
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* off_sorted, const uint2* span_sorted, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s);
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s);
 

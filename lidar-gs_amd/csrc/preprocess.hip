@@ -103,8 +103,8 @@ struct PreKernelArgs {
     const float* means3D; const float* scales; const float* rotations; const float* opacities;
     const float* colors; const float* cov3D_precomp; const float* beams;
     int* radii; int* radii_xy;
-    float4* rec; uint32_t* rowspan; uint32_t* xspan; uint32_t* dkey; uint32_t* ids; uint32_t* ref_tiles; uint32_t* tcount;
-    uint32_t* inst_part;                // [blocks][3]: per-block instance counts for tile heights 4, 8, 16
+    float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
+    unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: instance counts for tile heights 4, 8, 16 (zeroed by the caller)
 };
 
 template <bool FILTER>
@@ -285,40 +285,29 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;  // every row written: callers need not pre-zero
     }
     if (FILTER) return;
-    {   // instance totals for tile heights 4 / 8 / 16 (the host picks the height from them, api.hip choose_tile_rows): per-block
-        // partial sums, folded by k_fold_inst_totals -- 31 k waves adding to the same three words cost a millisecond
+    {   // instance totals for tile heights 4 / 8 / 16 (the host picks the height from them, api.hip choose_tile_rows): one block
+        // sum, added to one of LG_INST_SLOTS slots -- 31 k waves adding to the same three words cost a millisecond, 7.8 k blocks
+        // spread over 64 lines do not show; the host adds the slots up after its one read
         __shared__ uint32_t s_part[4][3];
         uint32_t s4 = t4, s8 = t8, s16 = t16;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s4 += __shfl_xor(s4, o); s8 += __shfl_xor(s8, o); s16 += __shfl_xor(s16, o); }
         if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = s4; s_part[threadIdx.x >> 6][1] = s8; s_part[threadIdx.x >> 6][2] = s16; }
         __syncthreads();
-        if (threadIdx.x < 3) a.inst_part[3 * (size_t)blockIdx.x + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+        if (threadIdx.x < 3) {
+            const uint32_t sum = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+            if (sum) atomicAdd(a.inst_slots + (size_t)(blockIdx.x % LG_INST_SLOTS) * 4 + threadIdx.x, (unsigned long long)sum);
+        }
     }
     if (!in_range) return;
     a.dkey[idx] = key;
     a.ids[idx] = (uint32_t)idx;
-    a.ref_tiles[idx] = reftiles;
-    a.tcount[idx] = t4;
-    a.xspan[idx] = tiles ? xsp : 0u;                                    // an empty column span = no instances, whatever the row span holds
+    a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, t4, reftiles);   // an empty column span = no instances, whatever the row span holds
     if (live) {
         a.rowspan[idx] = rspan;
         float4* r = a.rec + 4 * (size_t)idx;
         r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
     }
-}
-
-__global__ void __launch_bounds__(256) k_fold_inst_totals(const uint32_t* __restrict__ part, unsigned blocks, unsigned long long* __restrict__ totals) {
-    __shared__ unsigned long long s_sum[4][3];
-    unsigned long long v[3] = {0, 0, 0};
-    for (unsigned b = threadIdx.x; b < blocks; b += 256) { v[0] += part[3 * (size_t)b]; v[1] += part[3 * (size_t)b + 1]; v[2] += part[3 * (size_t)b + 2]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
-        if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6][k] = v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) totals[threadIdx.x] = s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x];
 }
 
 void launch_preprocess(const PreprocessParams& pp, const float* means3D, const float* scales, const float* rotations,
@@ -328,14 +317,11 @@ void launch_preprocess(const PreprocessParams& pp, const float* means3D, const f
     a.pp = pp;
     a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.colors = colors;
     a.cov3D_precomp = cov3D_precomp; a.beams = beams; a.radii = radii; a.radii_xy = radii_xy;
-    a.rec = g.rec; a.rowspan = g.rowspan; a.xspan = g.xspan; a.dkey = g.key_a; a.ids = g.id_a; a.inst_part = g.cnt_sorted;                 // free until the instance scan; P words >= 3 * blocks
-    a.ref_tiles = g.ref_tiles; a.tcount = g.tcount;
+    a.rec = g.rec; a.rowspan = g.rowspan; a.spans = g.spans; a.dkey = g.key_a; a.ids = g.id_a;
+    a.inst_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_SLOT_WORD);
     const dim3 grid((pp.P + 255) / 256), block(256);
     if (filter_only) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, a);
-    else {
-        hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, a);
-        hipLaunchKernelGGL(k_fold_inst_totals, dim3(1), dim3(256), 0, s, a.inst_part, (unsigned)grid.x, reinterpret_cast<unsigned long long*>(g.totals + 8));
-    }
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -86,7 +86,7 @@ struct SfPreArgs {
     const float* view;
     const float* means3D; const float* scales; const float* rotations; const float* opacities; const float* colors; const float* beams;
     int* radii; int* radii_xy;
-    float4* rec; uint32_t* rowspan; uint32_t* xspan; uint32_t* dkey; uint32_t* ids; uint32_t* tcount; uint32_t* ref_tiles;
+    float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
 };
 
 template <bool FILTER>
@@ -170,9 +170,10 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     a.radii[idx] = out_radius;
     a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;
     if (FILTER) return;
-    a.dkey[idx] = key; a.ids[idx] = (uint32_t)idx; a.tcount[idx] = tiles; a.ref_tiles[idx] = reftiles;
+    a.dkey[idx] = key; a.ids[idx] = (uint32_t)idx;
+    a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, tiles, reftiles);   // lidargs_common.h: one gather per Gaussian when the lists are built
     if (live) {
-        a.rowspan[idx] = rspan; a.xspan[idx] = xsp;
+        a.rowspan[idx] = rspan;
         float4* r = a.rec + 5 * (size_t)idx;
         r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4;
     }
