@@ -70,12 +70,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buffer, binning_buffer, img_buffer)
         ctx.mark_non_differentiable(radii)
+        # no zero tensors made for outputs the loss does not use (radii never has a gradient: that alone is one fill of P ints a
+        # frame); backward fills in the image planes that are missing
+        ctx.set_materialize_grads(False)
         return color, depth, occ, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_out_depth, grad_out_occ, _grad_radii):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buffer, binning_buffer, img_buffer = ctx.saved_tensors
+        plane = lambda g, c: g if g is not None else torch.zeros((c, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+        grad_out_color, grad_out_depth, grad_out_occ = plane(grad_out_color, 2), plane(grad_out_depth, 1), plane(grad_out_occ, 1)
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.beam_inclinations, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_occ,
                 sh, rs.sh_degree, rs.campos, geom_buffer, ctx.num_rendered, binning_buffer, img_buffer, rs.debug)

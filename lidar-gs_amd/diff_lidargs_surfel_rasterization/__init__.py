@@ -44,12 +44,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, pixels)
+        ctx.set_materialize_grads(False)      # no zero tensors for radii / pixels; backward fills in a missing image gradient
         return color, radii, others, pixels
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_others, grad_pix):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        plane = lambda g, c: g if g is not None else torch.zeros((c, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+        grad_out_color, grad_others = plane(grad_out_color, 2), plane(grad_others, 7)
         (grad_means2D, grad_colors, grad_opacities, grad_means3D, grad_transMat, grad_sh, grad_scales, grad_rotations,
          _depth) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,

@@ -223,3 +223,25 @@ def test_backward_twice_on_one_forward(hip_lib_built):
         # float atomics order the sums differently from launch to launch: compare at the parity tolerance
         parity("second backward", b.cpu().numpy(), a.cpu().numpy(), verbose=False)
         parity("other forward's backward", c.cpu().numpy(), a.cpu().numpy(), verbose=False)
+
+
+def test_unused_outputs_have_no_gradient(hip_lib_built):
+    """A loss that reads only `color`: autograd hands no gradient for depth / occ (none is materialised), which must equal
+    passing zeros for them."""
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import to_torch, make_settings
+    H, W = 16, 300
+    scene = sc.make_scene("shell", 3000, H, 41)
+    st = to_torch(scene)
+    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((3000, 4), device="cuda", requires_grad=True)
+    rast = GaussianRasterizer(make_settings(st, W, H))
+    gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, 41))
+    color, depth, occ, _ = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                                scales=leaves["scales"], rotations=leaves["rotations"])
+    inputs = list(leaves.values()) + [means2D]
+    only_color = torch.autograd.grad([color], inputs, [gc], retain_graph=True)
+    zeros = torch.autograd.grad([color, depth, occ], inputs, [gc, torch.zeros_like(gd), torch.zeros_like(go)])
+    for a, b in zip(only_color, zeros):
+        parity("color-only backward", a.cpu().numpy(), b.cpu().numpy(), verbose=False)
