@@ -314,10 +314,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 2. instance offsets in range order for the likeliest tile height (queued before the host wait, so that the device has work
     //    while the host decides), then the one host wait (R3/cr/rasterizer_impl.cu:292): the instance totals for tile heights
     //    4 / 8 / 16 -> tile height, R.  Only if another height wins are the offsets recomputed.
-    uint32_t* scan_scratch = geom.scratch + lg::sort_scratch_words((size_t)P);
     const int th_guess = forced_tile_rows() ? forced_tile_rows() : 4;
-    lg::launch_gather_counts(ids_sorted, geom.spans, th_guess, geom.cnt_sorted, geom.span_sorted, (size_t)P, stream);   // one 16-byte gather
-    lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
+    lg::launch_instance_offsets(ids_sorted, geom.spans, th_guess, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
     LG_STAGE_CHECK("instance scan");
     uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
     // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
@@ -336,8 +334,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (R64 > (unsigned long long)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
     const size_t R = (size_t)R64;
     if (TH != th_guess) {
-        lg::launch_gather_counts(ids_sorted, geom.spans, TH, geom.cnt_sorted, geom.span_sorted, (size_t)P, stream);
-        lg::launch_exclusive_scan(geom.cnt_sorted, geom.off_sorted, (size_t)P, geom.totals, scan_scratch, stream);
+        lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
     }
     remember_tile_rows(geom_p, TH, true);
     g_prof.mark("scan+readback", stream);
@@ -351,7 +348,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 3. emit instances in range order, bin them by tile (stable)
     const uint32_t* point_list = bin.val_a;
     if (R) {
-        lg::launch_emit_instances(ids_sorted, geom.off_sorted, geom.span_sorted, (size_t)P, grid,
+        lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, (size_t)P, grid,
                                   bin.tile_a, bin.val_a, stream);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);

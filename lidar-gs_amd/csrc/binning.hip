@@ -329,49 +329,70 @@ __device__ __forceinline__ uint32_t span_tiles(uint32_t xs, uint32_t rs, int th_
     return cols ? cols * ((((rs >> 16) - 1u) >> th_shift) - ((rs & 0xFFFFu) >> th_shift) + 1u) : 0u;
 }
 
-// One 16-byte gather per Gaussian in range order -> its instance count and its spans, written in range order
-__global__ void __launch_bounds__(256) k_gather_counts(const uint32_t* __restrict__ ids_sorted, const uint4* __restrict__ spans, int th_shift,
-                                                       uint32_t* __restrict__ cnt_sorted, uint2* __restrict__ span_sorted, size_t P) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const uint4 sp = spans[ids_sorted[i]];
-    cnt_sorted[i] = span_tiles(sp.y, sp.x, th_shift);
-    span_sorted[i] = make_uint2(sp.y, sp.x);
+// Instance offsets without a per-Gaussian scan array.  A block of SCAN_BLOCK range-consecutive Gaussians:
+//   k_gather_spans   one 16-byte gather per Gaussian -> its spans in range order + the block's instance count -> block_sum[block]
+//   k_scan_partials  exclusive prefix of the block sums, grand total (= R) -> what the host reads
+//   k_emit_instances re-derives the counts from the range-ordered spans and scans them inside the block
+__global__ void __launch_bounds__(256) k_gather_spans(const uint32_t* __restrict__ ids_sorted, const uint4* __restrict__ spans, int th_shift,
+                                                      uint2* __restrict__ span_sorted, uint32_t* __restrict__ block_sum, size_t P) {
+    __shared__ uint32_t ws[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint32_t id[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const size_t i = base + (size_t)r * 256; id[r] = i < P ? ids_sorted[i] : 0xFFFFFFFFu; }
+    uint4 sp[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) sp[r] = id[r] != 0xFFFFFFFFu ? spans[id[r]] : make_uint4(0u, 0u, 0u, 0u);     // four gathers in flight
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const size_t i = base + (size_t)r * 256;
+        if (i < P) span_sorted[i] = make_uint2(sp[r].y, sp[r].x);
+        sum += span_tiles(sp[r].y, sp[r].x, th_shift);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-void launch_gather_counts(const uint32_t* ids_sorted, const uint4* spans, int TH, uint32_t* cnt_sorted, uint2* span_sorted, size_t P, hipStream_t s) {
+// spans in range order + exclusive block offsets in `block_off` (scan_blocks(P) words) + the instance total in *total_out
+void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
+                             size_t P, hipStream_t s) {
     int sh = 0;
     while ((1 << sh) < TH) sh++;
-    hipLaunchKernelGGL(k_gather_counts, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, spans, sh, cnt_sorted, span_sorted, P);
+    const size_t nb = scan_blocks(P);
+    hipLaunchKernelGGL(k_gather_spans, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, block_off, nb, total_out);
 }
 
-// Load-balanced expansion: each wave owns 64 range-consecutive Gaussians and writes their
+// Load-balanced expansion: each wave owns 64 range-consecutive Gaussians at a time and writes their
 // instances cooperatively, 64 consecutive output slots per step (coalesced 256-B stores),
 // instead of one thread looping over its own rect (the reference's duplicateWithKeys,
 // R3/cr/rasterizer_impl.cu:70-112, whose per-thread trip count varies 1..100s).
-__global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ off_sorted,
-                                                        const uint2* __restrict__ span_sorted, size_t P, int th_shift, int tiles_x,
-                                                        uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val) {
-    const int lane = threadIdx.x & 63;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t cnt = 0, off = 0, g = 0, nx = 1, x0 = 0, ty0 = 0;
-    if (i < P) {
-        const uint2 sp = span_sorted[i];                               // (xspan, rowspan)
-        cnt = span_tiles(sp.x, sp.y, th_shift);
-        off = off_sorted[i];
-        if (cnt) {
-            g = ids_sorted[i];
-            x0 = sp.x & 0xFFFFu; nx = (sp.x >> 16) - x0;
-            ty0 = (sp.y & 0xFFFFu) >> th_shift;
-        }
-    }
+__global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ block_off,
+                                                               const uint2* __restrict__ span_sorted, size_t P, int th_shift, int tiles_x,
+                                                               uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val) {
+    __shared__ uint32_t s_tot[SCAN_BLOCK / 64];                        // instance count of each wave's 64 Gaussians
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const bool valid = i < P;
-    const uint32_t wave_base = __shfl(off, 0);                        // lane 0 invalid => whole wave invalid => total 0
-    uint32_t wave_end = valid ? off + cnt : 0u;                       // offsets are exclusive and monotone
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wave_end = max(wave_end, (uint32_t)__shfl_xor((int)wave_end, o));
-    const uint32_t wave_total = wave_end > wave_base ? wave_end - wave_base : 0u;
-    const uint32_t lo = valid ? off - wave_base : 0xFFFFFFFFu;        // local exclusive prefix (+inf past the end)
-    const uint32_t t_end = (wave_total + 63u) & ~63u;                 // every lane takes part in the shuffles
+    const uint2 sp = valid ? span_sorted[i] : make_uint2(0u, 0u);      // (xspan, rowspan); an empty column span = no instances
+    const uint32_t cnt = span_tiles(sp.x, sp.y, th_shift);
+    const uint32_t inc = wave_incl_scan(cnt, lane);
+    if (lane == 63) s_tot[w] = inc;
+    uint32_t g = 0, nx = 1, x0 = 0, ty0 = 0;
+    if (cnt) {
+        g = ids_sorted[i];
+        x0 = sp.x & 0xFFFFu; nx = (sp.x >> 16) - x0;
+        ty0 = (sp.y & 0xFFFFu) >> th_shift;
+    }
+    __syncthreads();
+    uint32_t wave_base = block_off[blockIdx.x];
+    for (int q = 0; q < w; q++) wave_base += s_tot[q];
+    const uint32_t wave_total = __shfl(inc, 63);
+    const uint32_t lo = valid ? inc - cnt : 0xFFFFFFFFu;               // local exclusive prefix (+inf past the end)
+    const uint32_t t_end = (wave_total + 63u) & ~63u;                  // every lane takes part in the shuffles
     for (uint32_t t = lane; t < t_end; t += 64) {
         // owner = largest lane L with lo_L <= t  (zero-count lanes share their successor's lo and lose)
         int a = 0, b = 63;
@@ -383,19 +404,19 @@ __global__ void __launch_bounds__(256) k_emit_instances(const uint32_t* __restri
         }
         const uint32_t o_lo = __shfl(lo, a), o_g = __shfl(g, a), o_nx = __shfl(nx, a), o_x0 = __shfl(x0, a), o_ty0 = __shfl(ty0, a);
         if (t < wave_total) {
-            const uint32_t j = t - o_lo;
-            const uint32_t ry = j / o_nx, rx = j - ry * o_nx;
+            const uint32_t jj = t - o_lo;
+            const uint32_t ry = jj / o_nx, rx = jj - ry * o_nx;
             inst_tile[(size_t)wave_base + t] = (o_ty0 + ry) * (uint32_t)tiles_x + o_x0 + rx;
             inst_val[(size_t)wave_base + t] = o_g;
         }
     }
 }
 
-void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* off_sorted, const uint2* span_sorted, size_t P, TileGrid grid,
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s) {
     int sh = 0;
     while ((1 << sh) < grid.TH) sh++;
-    hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ids_sorted, off_sorted, span_sorted, P, sh,
+    hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted, P, sh,
                        grid.tiles_x, inst_tile, inst_val);
 }
 

@@ -84,8 +84,7 @@ struct GeomView {
     uint2* span_sorted;                 // (xspan, rowspan) of the i-th Gaussian in range order
     uint32_t* key_a; uint32_t* key_b;   // range keys ping/pong
     uint32_t* id_a; uint32_t* id_b;     // Gaussian ids ping/pong (id_sorted ends in id_a)
-    uint32_t* cnt_sorted;               // tiles touched for the chosen tile height, in range order
-    uint32_t* off_sorted;               // exclusive scan of cnt_sorted
+    uint32_t* block_off;                // [scan_blocks(P)] exclusive instance offset of each block of SCAN_BLOCK range-consecutive Gaussians
     uint32_t* totals;                   // [0]=#instances, [1]=#visible, [2..3]=R_ref (u64)
     float* gacc;                        // [16P] packed per-Gaussian gradient accumulators (backward)
     uint32_t* scratch;                  // sort + scan scratch
@@ -101,8 +100,7 @@ inline size_t geom_carve(char* base, size_t P, GeomView* v) {
     g.span_sorted = c.take<uint2>(P);
     g.key_a = c.take<uint32_t>(P); g.key_b = c.take<uint32_t>(P);
     g.id_a = c.take<uint32_t>(P); g.id_b = c.take<uint32_t>(P);
-    g.cnt_sorted = c.take<uint32_t>(P);
-    g.off_sorted = c.take<uint32_t>(P);
+    g.block_off = c.take<uint32_t>(scan_blocks(P) + 64);
     g.totals = c.take<uint32_t>(LG_TOTALS_WORDS);
     g.gacc = c.take<float>(16 * P);
     g.scratch_words = sort_scratch_words(P) + scan_scratch_words(P);
@@ -227,8 +225,9 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 // sorts (key,val) pairs on key bits [0,end_bit); result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s);
-void launch_gather_counts(const uint32_t* ids_sorted, const uint4* spans, int TH, uint32_t* cnt_sorted, uint2* span_sorted, size_t P, hipStream_t s);
-void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* off_sorted, const uint2* span_sorted, size_t P, TileGrid grid,
+void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
+                             size_t P, hipStream_t s);
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s);
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s);
 
