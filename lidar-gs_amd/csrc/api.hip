@@ -299,9 +299,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     pp.tan_col_step = tanf(2 * pi_f / width);                          // R3/cr/forward.cu:362
     pp.view = viewmatrix;
 
-    lg::launch_setup_tables(beams, width, height, img, stream);
     lg::launch_preprocess(pp, means3D, scales, rotations, opacities, colors_precomp, cov3D_precomp, beams, radii, radii_xy,
-                          geom, false, stream);
+                          geom, &img, false, stream);                  // also fills the pixel-ray tables of the image buffer
     LG_STAGE_CHECK("preprocess");
     g_prof.mark("preprocess", stream);
 
@@ -520,7 +519,7 @@ int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user,
     pp.view = viewmatrix;
     lg::GeomView none; memset(&none, 0, sizeof none);
     lg::launch_preprocess(pp, means3D, scales, rotations, nullptr, nullptr, cov3D_precomp, beam_inclinations, radii, radii_xy, none,
-                          true, stream);
+                          nullptr, true, stream);
     LG_STAGE_CHECK("filter preprocess");
     return 0;
 }

@@ -211,7 +211,7 @@ bool api_take_zeroed_gradients(const void* geom);
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);
 void launch_preprocess(const PreprocessParams& pp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* colors, const float* cov3D_precomp, const float* beams,
-                       int* radii, int* radii_xy, GeomView g, bool filter_only, hipStream_t s);
+                       int* radii, int* radii_xy, GeomView g, const ImgView* tables, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
 
 void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s);

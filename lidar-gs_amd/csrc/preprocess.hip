@@ -73,9 +73,9 @@ __device__ __forceinline__ void tangent_basis(float3 dir, float3& u1, float3& u2
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_setup_tables(const float* __restrict__ beams, int W, int H,
-                               float2* __restrict__ coltab, float2* __restrict__ rowtab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// entry i of the pixel-ray tables: (cos, sin) of the azimuth of column i and of the elevation of pixel row i
+__device__ __forceinline__ void ray_table_entry(int i, const float* __restrict__ beams, int W, int H, float2* __restrict__ coltab,
+                                                float2* __restrict__ rowtab) {
     const float pi_f = 3.14159265358979323846f;
     if (i < W) {
         // R3/cr/forward.cu:590: evaluated in double, rounded to float, then float cos/sin
@@ -91,6 +91,9 @@ __global__ void k_setup_tables(const float* __restrict__ beams, int W, int H,
         rowtab[i] = make_float2((float)cos((double)alp), (float)sin((double)alp));
     }
 }
+__global__ void k_setup_tables(const float* __restrict__ beams, int W, int H, float2* __restrict__ coltab, float2* __restrict__ rowtab) {
+    ray_table_entry(blockIdx.x * blockDim.x + threadIdx.x, beams, W, H, coltab, rowtab);
+}
 
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s) {
     const int n = W > H ? W : H;
@@ -105,6 +108,7 @@ struct PreKernelArgs {
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
     unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: instance counts for tile heights 4, 8, 16 (zeroed by the caller)
+    float2* coltab; float2* rowtab;     // pixel-ray tables for the blend, filled by the first workgroups (nullptr: not wanted)
 };
 
 template <bool FILTER>
@@ -112,6 +116,10 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const PreprocessParams& pp = a.pp;
     const bool in_range = idx < pp.P;                                  // no early return: the whole wave takes part in the sums at the end
+    if (!FILTER && a.coltab) {                                         // W + H table entries ride on the first workgroups: one launch less
+        const int n = max(pp.W, pp.H);
+        for (int i = idx; i < n; i += gridDim.x * blockDim.x) ray_table_entry(i, a.beams, pp.W, pp.H, a.coltab, a.rowtab);
+    }
     // the beam table is binary-searched three times per Gaussian (6 dependent reads each): keep it in LDS when it fits
     constexpr int BEAMS_LDS = 1024;
     __shared__ float s_beams[BEAMS_LDS];
@@ -312,11 +320,12 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
 
 void launch_preprocess(const PreprocessParams& pp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* colors, const float* cov3D_precomp, const float* beams,
-                       int* radii, int* radii_xy, GeomView g, bool filter_only, hipStream_t s) {
+                       int* radii, int* radii_xy, GeomView g, const ImgView* tables, bool filter_only, hipStream_t s) {
     PreKernelArgs a;
     a.pp = pp;
     a.means3D = means3D; a.scales = scales; a.rotations = rotations; a.opacities = opacities; a.colors = colors;
     a.cov3D_precomp = cov3D_precomp; a.beams = beams; a.radii = radii; a.radii_xy = radii_xy;
+    a.coltab = tables ? tables->coltab : nullptr; a.rowtab = tables ? tables->rowtab : nullptr;
     a.rec = g.rec; a.rowspan = g.rowspan; a.spans = g.spans; a.dkey = g.key_a; a.ids = g.id_a;
     a.inst_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_SLOT_WORD);
     const dim3 grid((pp.P + 255) / 256), block(256);
