@@ -24,7 +24,7 @@ SOURCES = {
     "api.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render.hip": [],
+    "render.hip": ["-fno-slp-vectorize"],  # the packed-fp32 pairs are written out (v2f); the SLP vectorizer pairs the rest up at the price of moves
     "neural_gaussians.hip": [],
     "lidar_loss.hip": [],
     "chamfer.hip": ["-ffp-contract=off"],        # the squared distance must round as the reference writes it: the argmin index is compared bit for bit

@@ -7,9 +7,9 @@
 //     rec      float4[4P]  one 64-byte "splat record" per Gaussian, written once by preprocess and
 //                          gathered as one aligned 64-B segment per (tile, Gaussian) instance:
 //                            rec[0] = (s.x, s.y, s.z, range)       s = p_view/|p_view|
-//                            rec[1] = (u1'.x, u1'.y, u1'.z, A)     u1' = u1/(u1.u1), conic A
-//                            rec[2] = (u2'.x, u2'.y, u2'.z, B)     u2' = u2/(u2.u2), conic B
-//                            rec[3] = (C, opacity, colour0, colour1)
+//                            rec[1] = (u1'.x, u2'.x, u1'.y, u2'.y)     u_i' = u_i/(u_i.u_i); the two tangent directions are
+//                            rec[2] = (u1'.z, u2'.z, A, C)             interleaved by component and the conic's diagonal is a
+//                            rec[3] = (B, opacity, colour0, colour1)   pair: both projections run as packed-fp32 operations
 //     rowspan  u32[P]      ymin | ymax<<16 of the (pruned) pixel-row rect (R3/cr/auxiliary.h:80-92): read per list entry by the blend
 //     spans    u32x4[P]    (rowspan, xspan = xmin | xmax<<16 in 16-pixel tile columns (0 = no instances), instance count at
 //                           4-row tiles, the reference's 16x1 tiles_touched): ONE 16-byte gather per Gaussian when the lists are built

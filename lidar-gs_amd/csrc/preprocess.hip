@@ -283,9 +283,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
         const float i1 = uu1 > 0.f ? 1.f / uu1 : 0.f, i2 = uu2 > 0.f ? 1.f / uu2 : 0.f;
         r0 = make_float4(dir.x, dir.y, dir.z, dist);
-        r1 = make_float4(u1.x * i1, u1.y * i1, u1.z * i1, conA);
-        r2 = make_float4(u2.x * i2, u2.y * i2, u2.z * i2, conB);
-        r3 = make_float4(conC, a.opacities[idx], a.colors[2 * idx], a.colors[2 * idx + 1]);
+        r1 = make_float4(u1.x * i1, u2.x * i2, u1.y * i1, u2.y * i2);                  // (u1', u2') interleaved by component:
+        r2 = make_float4(u1.z * i1, u2.z * i2, conA, conC);                            // the blend evaluates both projections in
+        r3 = make_float4(conB, a.opacities[idx], a.colors[2 * idx], a.colors[2 * idx + 1]);   // packed-fp32 operations
     } while (false);
 
     if (in_range) {

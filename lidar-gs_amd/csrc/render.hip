@@ -40,6 +40,10 @@ namespace lg {
 
 #define LG_CHUNK 64
 
+// (u1-part, u2-part) pairs: the splat record interleaves the two tangent directions so that everything the two projections
+// share is one packed-fp32 operation (v_pk_fma_f32 / v_pk_mul_f32) on adjacent registers, without moves to pair them up.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct PixelSetup {
     int x, y, pix;
     bool inside;
@@ -153,9 +157,9 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
 
                     const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
                     const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-                    const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
-                    const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
-                    const float power = -0.5f * (r1.w * dx * dx + r3.x * dy * dy) - r2.w * dx * dy;   // :601
+                    const v2f d = ex * v2f{r1.x, r1.y} + ey * v2f{r1.z, r1.w} + ez * v2f{r2.x, r2.y};     // (d.x, d.y) = delta . (u1', u2')
+                    const v2f qd = v2f{r2.z, r2.w} * d * d;                                              // (A dx^2, C dy^2)
+                    const float power = -0.5f * (qd.x + qd.y) - r3.x * d.x * d.y;                         // :601
                     const float alpha = fminf(0.99f, r3.y * __expf(fminf(power, 0.f)));
                     const bool hit = !done && rows && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
                     const float test_T = T * (1.f - alpha);
@@ -429,9 +433,10 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
             const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based position inside the segment
             const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
             const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-            const float dx = ex * r1.x + ey * r1.y + ez * r1.z;
-            const float dy = ex * r2.x + ey * r2.y + ez * r2.z;
-            const float A = r1.w, B = r2.w, Cc = r3.x, op = r3.y;
+            const v2f ux = v2f{r1.x, r1.y}, uy = v2f{r1.z, r1.w}, uz = v2f{r2.x, r2.y};        // (u1', u2') by component
+            const v2f d = ex * ux + ey * uy + ez * uz;
+            const float dx = d.x, dy = d.y;
+            const float A = r2.z, B = r3.x, Cc = r2.w, op = r3.y;
             const float power = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
             const float G = __expf(fminf(power, 0.f));
             const float alpha_raw = fminf(0.99f, op * G);
@@ -459,11 +464,12 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 const float gx = dL_dG * (-gdx * A - gdy * B);         // dL/dmean2D.x  (:734,:753)
                 const float gy = dL_dG * (-gdy * Cc - gdx * B);        // dL/dmean2D.y
                 // per-pixel sphere-gradient norm statistic (:759-779): |gx u1' + gy u2'|
-                const float sx = gx * r1.x + gy * r2.x, sy = gx * r1.y + gy * r2.y, sz = gx * r1.z + gy * r2.z;
+                const float sx = gx * ux.x + gy * ux.y, sy = gx * uy.x + gy * uy.y, sz = gx * uz.x + gy * uz.y;
                 // dL/du1 = gx (delta/uu1 - 2 dx u1'),  1/uu1 = |u1'|^2      (:738-750)
-                const float iu1 = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
-                const float iu2 = r2.x * r2.x + r2.y * r2.y + r2.z * r2.z;
-                const float t1 = -2.f * dx, t2 = -2.f * dy;
+                const v2f iu = ux * ux + uy * uy + uz * uz;             // (1/uu1, 1/uu2)
+                const v2f tt = -2.f * d;
+                const v2f gxy = v2f{gx, gy};
+                const v2f bx = gxy * (ex * iu + tt * ux), by = gxy * (ey * iu + tt * uy), bz = gxy * (ez * iu + tt * uz);
                 float v[16];
                 v[0] = gx;
                 v[1] = gy;
@@ -475,12 +481,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 v[7] = w * g0;                                         // colours (:702)
                 v[8] = w * g1;
                 v[9] = w * gd;                                         // range (:711)
-                v[10] = gx * (ex * iu1 + t1 * r1.x);
-                v[11] = gx * (ey * iu1 + t1 * r1.y);
-                v[12] = gx * (ez * iu1 + t1 * r1.z);
-                v[13] = gy * (ex * iu2 + t2 * r2.x);
-                v[14] = gy * (ey * iu2 + t2 * r2.y);
-                v[15] = gy * (ez * iu2 + t2 * r2.z);
+                v[10] = bx.x; v[11] = by.x; v[12] = bz.x;              // dL/du1
+                v[13] = bx.y; v[14] = by.y; v[15] = bz.y;              // dL/du2
                 T = Tn;
                 acc0 = a0; acc1 = a1; accd = ad; acco = ao;
                 lc0 = r3.z; lc1 = r3.w; ld = r0.w;
