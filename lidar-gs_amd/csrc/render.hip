@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
         for (int k = 0; k < seg; k++) T *= tp[(size_t)k * (LG_SEG_PLANES * 64)];
     }
     float T_break = T;
-    float C0 = 0.f, C1 = 0.f, D = 0.f;
+    v2f C01 = v2f{0.f, 0.f};
+    float D = 0.f;
     uint32_t last = 0;
     // a lane that starts below the threshold can never blend again: every contributing entry trips T < 1e-4
     bool done = !px.inside || (!T_ONLY && T < 0.0001f);
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
                     const bool blend = hit && !trip;
                     if (!T_ONLY) {
                         const float w = blend ? alpha * T : 0.f;
-                        C0 += r3.z * w; C1 += r3.w * w; D += r0.w * w;
+                        C01 += v2f{r3.z, r3.w} * w; D += r0.w * w;
                     }
                     T = blend ? test_T : T;
                     T_break = hit ? test_T : T_break;
@@ -196,8 +197,8 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     if (T_ONLY) {
         segbase[LG_SEG_TPASS * 64 + lane] = T_break;
     } else {
-        segbase[LG_SEG_C0 * 64 + lane] = C0;
-        segbase[LG_SEG_C1 * 64 + lane] = C1;
+        segbase[LG_SEG_C0 * 64 + lane] = C01.x;
+        segbase[LG_SEG_C1 * 64 + lane] = C01.y;
         segbase[LG_SEG_D * 64 + lane] = D;
         segbase[LG_SEG_TEND * 64 + lane] = T;
         segbase[LG_SEG_TBREAK * 64 + lane] = T_break;
@@ -382,7 +383,9 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     float g0 = 0.f, g1 = 0.f, gd = 0.f, go = 0.f;
     if (px.inside) { g0 = a.dL_dpix[px.pix]; g1 = a.dL_dpix[N + px.pix]; gd = a.dL_ddepth[px.pix]; go = a.dL_docc[px.pix]; }
     const float bgdot = a.bg ? (a.bg[0] * g0 + a.bg[1] * g1) : 0.f;
-    float acc0 = 0.f, acc1 = 0.f, accd = 0.f, acco = 0.f;           // accum_rec[2], accum_red, accum_reo
+    // accum_rec[2] | accum_red, accum_reo: the four "colour behind" recurrences run as two packed pairs
+    v2f acc01 = v2f{0.f, 0.f}, accdo = v2f{0.f, 0.f};
+    const v2f g01 = v2f{g0, g1}, gdo = v2f{gd, go};
     {
         float b0 = 0.f, b1 = 0.f, bd = 0.f;
         const int Send = a.alive ? min(St, (int)a.alive[patch]) : St;  // nothing was walked behind the patch's limit
@@ -394,11 +397,12 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
         if (a.behind && px.inside) { b0 += a.behind[px.pix]; b1 += a.behind[N + px.pix]; bd += a.behind[2 * N + px.pix]; }
         if (T > 0.f) {
             const float inv = 1.f / T;
-            acc0 = b0 * inv; acc1 = b1 * inv; accd = bd * inv;
-            acco = 1.f - T_final * inv;
+            acc01 = v2f{b0 * inv, b1 * inv};
+            accdo = v2f{bd * inv, 1.f - T_final * inv};
         }
     }
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, ld = 0.f;
+    float last_alpha = 0.f;
+    v2f lc01 = v2f{0.f, 0.f}, ldo = v2f{0.f, 1.f};                    // last entry's (colour0, colour1) | (range, 1)
 
     const int c_last = (int)((n_max - 1) / LG_CHUNK);
     const uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
@@ -451,41 +455,44 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 const float inv = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; (1 - alpha) >= 0.01
                 const float Tn = T * inv;                              // :681
                 const float w = alpha * Tn;
-                const float a0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                const float a1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                const float ad = last_alpha * ld + (1.f - last_alpha) * accd;
-                const float ao = last_alpha + (1.f - last_alpha) * acco;
-                float dL_dalpha = (r3.z - a0) * g0 + (r3.w - a1) * g1 + (r0.w - ad) * gd + (1.f - ao) * go;
-                dL_dalpha *= Tn;
+                const float keep = 1.f - last_alpha;
+                const v2f a01 = last_alpha * lc01 + keep * acc01;      // :694-714
+                const v2f ado = last_alpha * ldo + keep * accdo;
+                const v2f c01 = v2f{r3.z, r3.w}, cdo = v2f{r0.w, 1.f};
+                const v2f t4 = (c01 - a01) * g01 + (cdo - ado) * gdo;
+                float dL_dalpha = (t4.x + t4.y) * Tn;
                 dL_dalpha -= T_final * inv * bgdot;                    // :727
                 dL_dalpha = contrib ? dL_dalpha : 0.f;                 // every sum below carries dL_dalpha or w as a factor
                 const float dL_dG = op * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float gx = dL_dG * (-gdx * A - gdy * B);         // dL/dmean2D.x  (:734,:753)
-                const float gy = dL_dG * (-gdy * Cc - gdx * B);        // dL/dmean2D.y
+                const v2f gd2 = G * d;                                 // (G dx, G dy)
+                const float gdx = gd2.x, gdy = gd2.y;
+                const v2f gxy = -dL_dG * (gd2 * v2f{A, Cc} + v2f{gdy, gdx} * B);   // dL/dmean2D  (:734,:753)
+                const float gx = gxy.x, gy = gxy.y;
                 // per-pixel sphere-gradient norm statistic (:759-779): |gx u1' + gy u2'|
                 const float sx = gx * ux.x + gy * ux.y, sy = gx * uy.x + gy * uy.y, sz = gx * uz.x + gy * uz.y;
                 // dL/du1 = gx (delta/uu1 - 2 dx u1'),  1/uu1 = |u1'|^2      (:738-750)
                 const v2f iu = ux * ux + uy * uy + uz * uz;             // (1/uu1, 1/uu2)
                 const v2f tt = -2.f * d;
-                const v2f gxy = v2f{gx, gy};
                 const v2f bx = gxy * (ex * iu + tt * ux), by = gxy * (ey * iu + tt * uy), bz = gxy * (ez * iu + tt * uz);
                 float v[16];
                 v[0] = gx;
                 v[1] = gy;
                 v[2] = sqrtf(sx * sx + sy * sy + sz * sz);
-                v[3] = -0.5f * gdx * dx * dL_dG;                       // conic A (:783)
-                v[4] = -0.5f * gdx * dy * dL_dG;                       // conic B
-                v[5] = -0.5f * gdy * dy * dL_dG;                       // conic C
+                const float mh = -0.5f * dL_dG;
+                const v2f cac = mh * gd2 * d;                          // conic A, C (:783)
+                const v2f wc = w * g01;                                // colours (:702)
+                v[3] = cac.x;
+                v[4] = mh * gdx * dy;                                  // conic B
+                v[5] = cac.y;
                 v[6] = G * dL_dalpha;                                  // opacity (:788)
-                v[7] = w * g0;                                         // colours (:702)
-                v[8] = w * g1;
+                v[7] = wc.x;
+                v[8] = wc.y;
                 v[9] = w * gd;                                         // range (:711)
                 v[10] = bx.x; v[11] = by.x; v[12] = bz.x;              // dL/du1
                 v[13] = bx.y; v[14] = by.y; v[15] = bz.y;              // dL/du2
                 T = Tn;
-                acc0 = a0; acc1 = a1; accd = ad; acco = ao;
-                lc0 = r3.z; lc1 = r3.w; ld = r0.w;
+                acc01 = a01; accdo = ado;
+                lc01 = c01; ldo = cdo;
                 last_alpha = alpha;
                 const float mine = reduce_scatter16(v, lane);
                 if (lane < 16) {
