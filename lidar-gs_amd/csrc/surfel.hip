@@ -11,8 +11,9 @@
 // reference rect, tile width 16 = BLOCK_X) and the ray tables.
 //
 // Per-surfel record, 80 bytes, written once by k_sf_preprocess and gathered per (tile, surfel) instance:
-//   r0 = (Tu'.xyz, opacity)     Tu' = Tu / (Tu.Tu), Tu = view-space first axis (incl. scale)
-//   r1 = (Tv'.xyz, colour0)     so that s = (dp.Tu', dp.Tv') needs no division per pair (R2/cr/forward.cu:463-468)
+//   r0 = (Tu'.x, Tv'.x, Tu'.y, Tv'.y)      Tu' = Tu / (Tu.Tu), Tu = view-space first axis (incl. scale), Tv likewise: interleaved
+//   r1 = (Tu'.z, Tv'.z, opacity, colour0)  by component, so that s = (dp.Tu', dp.Tv') needs no division per pair
+//                                          (R2/cr/forward.cu:463-468) and both halves run as one packed-fp32 operation
 //   r2 = (Tw.xyz,  colour1)     Tw = view-space centre
 //   r3 = (n.xyz,   lambda)      n = normal flipped towards the sensor, lambda = Tw.n (distance of the plane)
 //   r4 = (p_c, p_r, |Tw|, Tw.n) projected centre in pixels (2-D filter, :469), range, and the raw dot Tw.n (backward)
@@ -27,6 +28,7 @@
 namespace lg {
 
 #define SF_CHUNK 64
+typedef float sf2 __attribute__((ext_vector_type(2)));    // a (Tu-part, Tv-part) pair: one packed-fp32 operation
 #define SF_NEAR_N 0.2f
 #define SF_FAR_N 80.0f
 
@@ -158,8 +160,9 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         key = __float_as_uint(dist);
         const float uu = sdot(Tu, Tu), vv = sdot(Tv, Tv);
         const float iu = uu > 0.f ? 1.f / uu : 0.f, iv = vv > 0.f ? 1.f / vv : 0.f;
-        r0 = make_float4(Tu.x * iu, Tu.y * iu, Tu.z * iu, a.opacities[idx]);
-        r1 = make_float4(Tv.x * iv, Tv.y * iv, Tv.z * iv, a.colors[2 * idx]);
+        // (Tu', Tv') interleaved by component: the blend evaluates s = (dp.Tu', dp.Tv') and its gradients as packed-fp32 pairs
+        r0 = make_float4(Tu.x * iu, Tv.x * iv, Tu.y * iu, Tv.y * iv);
+        r1 = make_float4(Tu.z * iu, Tv.z * iv, a.opacities[idx], a.colors[2 * idx]);
         r2 = make_float4(pv.x, pv.y, pv.z, a.colors[2 * idx + 1]);
         // lambda = |Tw| * cos(phi1) with cos(phi1) = (Tw.n)/|Tw|, rounded in the reference's order (:449-452): the hit
         // point lam2 * p - Tw cancels ~3 digits, so a 1-ulp change of lambda is a 1e-4 change of the Gaussian weight
@@ -227,8 +230,8 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
     const float safe = o.cos2 != 0.f ? o.cos2 : 1.f;
     o.lam2 = r3.w / safe;                                              // ray / plane hit distance (:449-457)
     o.dp = sf3(o.lam2 * px.p.x - r2.x, o.lam2 * px.p.y - r2.y, o.lam2 * px.p.z - r2.z);
-    o.sx = o.dp.x * r0.x + o.dp.y * r0.y + o.dp.z * r0.z;
-    o.sy = o.dp.x * r1.x + o.dp.y * r1.y + o.dp.z * r1.z;
+    const sf2 sxy = o.dp.x * sf2{r0.x, r0.y} + o.dp.y * sf2{r0.z, r0.w} + o.dp.z * sf2{r1.x, r1.y};
+    o.sx = sxy.x; o.sy = sxy.y;
     const float rho3d = o.sx * o.sx + o.sy * o.sy;
     o.dxp = r4.x - (float)px.x; o.dyp = r4.y - (float)px.y;
     const float rho2d = 2.0f * (40.f * o.dxp * o.dxp + 100.f * o.dyp * o.dyp);   // FilterInvSquare * (...), :469
@@ -238,7 +241,7 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
     o.depth = o.in3d ? o.lam2 : r4.z;
     const float power = -0.5f * rho;
     o.G = __expf(fminf(power, 0.f));
-    o.alpha = fminf(0.99f, r0.w * o.G);
+    o.alpha = fminf(0.99f, r1.z * o.G);
     o.ok = (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N) && !(power > 0.f) && !(o.alpha < 1.0f / 255.0f);
     return o;
 }
@@ -592,18 +595,20 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             dL_dalpha *= Tn;
             dL_dalpha -= T_final * inv * bgdot;
             dL_dalpha = contrib ? dL_dalpha : 0.f;
-            const float dL_dG = r0.w * dL_dalpha;
+            const float dL_dG = r1.z * dL_dalpha;
             dL_dz += w * g_depth;                                       // :420
             // 3-D branch: gradient through s = (dp.Tu', dp.Tv'), dp = lam2 p - Tw, lam2 = (Tw.n)/(p.n)   (:427-563); its three
             // roots are zeroed for a 2-D-branch pair, the 2-D branch's two for a 3-D one
             const bool in3d = q.in3d;
             const float ga = in3d ? -dL_dG * G * q.sx : 0.f, gb = in3d ? -dL_dG * G * q.sy : 0.f;   // dL/ds
-            const float iu = r0.x * r0.x + r0.y * r0.y + r0.z * r0.z;     // 1/(Tu.Tu)
-            const float iv = r1.x * r1.x + r1.y * r1.y + r1.z * r1.z;
+            const sf2 tx = sf2{r0.x, r0.y}, ty = sf2{r0.z, r0.w}, tz = sf2{r1.x, r1.y};   // (Tu', Tv') by component
+            const sf2 iuv = tx * tx + ty * ty + tz * tz;                  // (1/(Tu.Tu), 1/(Tv.Tv))
+            const sf2 gab = sf2{ga, gb}, s2 = 2.f * sf2{q.sx, q.sy};
             // dL/dTu = ga (dp - 2 sx Tu)/(Tu.Tu) = ga (dp * iu - 2 sx Tu')
-            const float3 gTu = sf3(ga * (q.dp.x * iu - 2.f * q.sx * r0.x), ga * (q.dp.y * iu - 2.f * q.sx * r0.y), ga * (q.dp.z * iu - 2.f * q.sx * r0.z));
-            const float3 gTv = sf3(gb * (q.dp.x * iv - 2.f * q.sy * r1.x), gb * (q.dp.y * iv - 2.f * q.sy * r1.y), gb * (q.dp.z * iv - 2.f * q.sy * r1.z));
-            const float3 gdp = sf3(ga * r0.x + gb * r1.x, ga * r0.y + gb * r1.y, ga * r0.z + gb * r1.z);
+            const sf2 gTx = gab * (q.dp.x * iuv - s2 * tx), gTy = gab * (q.dp.y * iuv - s2 * ty), gTz = gab * (q.dp.z * iuv - s2 * tz);
+            const float3 gTu = sf3(gTx.x, gTy.x, gTz.x), gTv = sf3(gTx.y, gTy.y, gTz.y);
+            const sf2 px2 = gab * tx, py2 = gab * ty, pz2 = gab * tz;
+            const float3 gdp = sf3(px2.x + px2.y, py2.x + py2.y, pz2.x + pz2.y);
             const float g_lam = in3d ? sdot(gdp, px.p) + dL_dz : 0.f;
             const float icos = __builtin_amdgcn_rcpf(q.cos2 != 0.f ? q.cos2 : 1.f);
             const float3 gTw = sf3(-gdp.x + g_lam * r3.x * icos, -gdp.y + g_lam * r3.y * icos, -gdp.z + g_lam * r3.z * icos);
