@@ -297,12 +297,7 @@ void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Butterfly reduce-scatter of 16 per-lane values over the 64 lanes of a wave.  On return lane L
-// (L < 16; every 16-lane row holds the same) owns the wave-wide sum of value slot
-//   id(L) = 8*(L&1) + 4*((L>>1)&1) + 2*((L>>2)&1) + ((L>>3)&1)
-// in v[0].
-// lane ^ 1 and lane ^ 2 partners come from DPP quad permutes (VALU, no LDS crossbar round trip); ^4, ^8, ^16 from
-// ds_swizzle bit-mode (no address VGPR); ^32 from ds_bpermute.
+// Cross-lane exchanges for the reduce-scatter below.
 __device__ __forceinline__ float xchg_xor1(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
 }
@@ -314,38 +309,42 @@ __device__ __forceinline__ float xchg_swz(float x) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (XORMASK << 10) | 0x1F));
 }
 
+// gfx950 lane swaps: {a', b'} with a' = (a's lower half | b's lower half), b' = (a's upper half | b's upper half) for halves of
+// 32 lanes (v_permlane32_swap) or, row pair by row pair, of 16 (v_permlane16_swap).  a' + b' is then one reduce-scatter step
+// with no select: the lower half of the lanes owns the sum of a, the upper half the sum of b.
+__device__ __forceinline__ float fold_halves32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_halves16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Reduce-scatter of 16 per-lane values over the 64 lanes of a wave.  On return lane L owns, in v[0], the wave-wide sum of value slot
+//   id(L) = 8*bit5(L) + 4*bit4(L) + 2*bit0(L) + bit1(L)          (lanes that differ only in bits 2, 3 hold the same)
+// The two wide steps come first, when there are most values to fold: a lane swap + an add each, instead of two selects + a
+// cross-lane add.  lane ^ 1 and lane ^ 2 partners then come from DPP quad permutes, ^4 and ^8 (plain sums by then) from ds_swizzle.
 __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = fold_halves32(v[k], v[k + 8]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = fold_halves16(v[k], v[k + 4]);
     {
         const bool hi = lane & 1;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float keep = hi ? v[k + 8] : v[k], send = hi ? v[k] : v[k + 8];
+        for (int k = 0; k < 2; k++) {
+            const float keep = hi ? v[k + 2] : v[k], send = hi ? v[k] : v[k + 2];
             v[k] = keep + xchg_xor1(send);
         }
     }
     {
         const bool hi = lane & 2;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float keep = hi ? v[k + 4] : v[k], send = hi ? v[k] : v[k + 4];
-            v[k] = keep + xchg_xor2(send);
-        }
-    }
-    {
-        const bool hi = lane & 4;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const float keep = hi ? v[k + 2] : v[k], send = hi ? v[k] : v[k + 2];
-            v[k] = keep + xchg_swz<4>(send);
-        }
-    }
-    {
-        const bool hi = lane & 8;
         const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
-        v[0] = keep + xchg_swz<8>(send);
+        v[0] = keep + xchg_xor2(send);
     }
-    v[0] += xchg_swz<16>(v[0]);
-    v[0] += __shfl_xor(v[0], 32);
+    v[0] += xchg_swz<4>(v[0]);
+    v[0] += xchg_swz<8>(v[0]);
     return v[0];
 }
 
@@ -495,8 +494,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 lc01 = c01; ldo = cdo;
                 last_alpha = alpha;
                 const float mine = reduce_scatter16(v, lane);
-                if (lane < 16) {
-                    const int slot = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                if ((lane & 12) == 0) {                                 // one owner per slot
+                    const int slot = 8 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 2 * (lane & 1) + ((lane >> 1) & 1);
                     atomicAdd(a.gacc + 16 * (size_t)s_gid[j] + slot, mine);
                 }
             }
