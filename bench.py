@@ -32,6 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")
 import numpy as np
 import torch
 
+STAGE_EVERY = 8           # frames between two frames whose stages are bracketed by HIP events
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -502,7 +503,9 @@ def main():
         step()
     barrier()
     _flush_c_stdio()                    # every rank: whatever the collectives' bring-up printed goes out now, not at exit
-    _C.profile_enable(True)             # reset: from here on only hipEventRecord per stage, no host waits
+    # stage events live inside the timed region, on every STAGE_EVERY-th frame: recording all twelve of them on every frame costs
+    # 55 us of device time per frame (measured: 0.94 ms with, 0.88 ms without), which would be the harness, not the path
+    _C.profile_enable(STAGE_EVERY)
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -567,6 +570,7 @@ def main():
                          "frame_algorithmic_bytes": fwd_b + bwd_b,
                          "frame_achieved_GBs": (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9},
             "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+            "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",
             "frame_ms_spread": spread,
             "hipmalloc_calls_in_timed_region": int(allocs1 - allocs0),
         }

@@ -296,7 +296,7 @@ int lidargs_surfel_visible_filter(
  * records one event per stage boundary (no host wait); lidargs_profile_read() synchronises the
  * LAST call's events and returns elapsed milliseconds per stage. */
 #define LIDARGS_MAX_STAGES 24
-void lidargs_profile_enable(int on);
+void lidargs_profile_enable(int on);                         /* 0 off, 1 every call, N > 1 every N-th forward and every N-th backward */
 int lidargs_profile_read(float* ms_out, int max_stages);      /* returns #stages written     */
 const char* lidargs_profile_stage_name(int stage);            /* NULL past the last stage    */
 /* Aggregate of all calls recorded since lidargs_profile_enable(1) (up to 512): per distinct stage

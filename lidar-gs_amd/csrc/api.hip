@@ -20,6 +20,7 @@
 #include <mutex>
 
 namespace {
+using lg::SegPlan;
 
 thread_local char g_err[512] = "";
 long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -128,61 +129,51 @@ struct HostRead {
 };
 thread_local HostRead t_host_read;
 
-int max_segments() {
-    static int v = [] {
-        const char* e = getenv("LIDARGS_MAX_SEGMENTS");
-        int m = e ? atoi(e) : 33;
-        if (m < 1) m = 1;
-        if (m > 63) m = 63;
-        return m | 1;       // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
-    }();
-    return v;
-}
-
-int segment_length() {
-    static int v = [] {
-        const char* e = getenv("LIDARGS_SEG_LEN");
-        int m = e ? atoi(e) : LG_SEG_LEN_DEFAULT;
-        if (m < 64) m = 64;
-        return m;
-    }();
-    return v;
-}
-
-// Depth of the pass-1 rounds, in segments: e.g. LIDARGS_ROUNDS="3,9" walks segments [0,3), then [3,9) of the patches still
-// open, then the rest of those still open after that.
-int pass1_rounds(int* out, int cap) {
-    static int cached[8], n_cached = -1;
-    if (n_cached < 0) {
+// How a frame's tile lists are cut up: target entries per segment, segment slots per list, and the depth (in segments) of the
+// gated pass-1 rounds, e.g. rounds {3, 9} walks segments [0,3), then [3,9) of the patches still open, then the rest of those
+// still open after that.  A pure function of (R, waves per tile, variant) and the environment, so the backward and the shell's
+// phase 2 find the split the forward used.
+//   Few nominal segments (R * waves_per_tile / 128 < 150 k: the 2 M-Gaussian 64x2650 frames, range shells of them) leave the
+//   blend latency-bound at ~2 waves per SIMD (SQ_WAVE_CYCLES), so the lists are cut finer: 64-entry segments, 45 slots, a first
+//   round of 5 segments (cfg3 0.99 -> 0.93 ms).  Frames with plenty of segments (8 M Gaussians at 128x4096) lose 10 % that way
+//   and keep 128 / 33 / 3.  The surfel blend does twice the arithmetic per entry and sits in between: 96 / 45 / 4.
+//   LIDARGS_SEG_LEN, LIDARGS_MAX_SEGMENTS, LIDARGS_ROUNDS ("3,9") override.
+SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
+    static const int env_len = [] { const char* e = getenv("LIDARGS_SEG_LEN"); return e ? std::max(64, atoi(e)) : 0; }();
+    static const int env_max = [] { const char* e = getenv("LIDARGS_MAX_SEGMENTS"); return e ? std::min(63, std::max(1, atoi(e))) | 1 : 0; }();
+    static int env_rounds[8];
+    static const int env_nrounds = [] {
         const char* e = getenv("LIDARGS_ROUNDS");
-        if (!e) e = "3";        // one gated round measured best (0.36 -> 0.18 ms on the 2 M street scene); more rounds add launch tails
+        if (!e) return -1;
         int n = 0, prev = 0;
         while (*e && n < 8) {
             const int v = atoi(e);
-            if (v > prev && v < 255) { cached[n++] = v; prev = v; }
+            if (v > prev && v < 255) { env_rounds[n++] = v; prev = v; }
             while (*e && *e != ',') e++;
             if (*e == ',') e++;
         }
-        n_cached = n;
-    }
-    int n = 0;
-    for (int i = 0; i < n_cached && n < cap; i++) out[n++] = cached[i];
-    return n;
+        return n;
+    }();
+    SegPlan p;
+    const bool fine = (unsigned long long)R * (unsigned)waves_per_tile / 128ull < 150000ull;
+    p.seg_len = fine ? (surfel ? 96 : 64) : LG_SEG_LEN_DEFAULT;
+    p.max_segments = fine ? 45 : 33;        // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
+    p.n_rounds = 1; p.rounds[0] = fine ? (surfel ? 4 : 5) : 3;    // one gated round: more rounds add launch tails
+    if (env_len) p.seg_len = env_len;
+    if (env_max) p.max_segments = env_max;
+    if (env_nrounds >= 0) { p.n_rounds = env_nrounds; for (int k = 0; k < env_nrounds; k++) p.rounds[k] = env_rounds[k]; }
+    return p;
 }
-bool pass1_gated(int S) {
-    int r[8];
-    const int n = pass1_rounds(r, 8);
-    return n > 0 && r[0] < S;
-}
+bool pass1_gated(const SegPlan& p, int S) { return p.n_rounds > 0 && p.rounds[0] < S; }
 
 // Pass 1 in rounds of growing depth: the first segments of every list, then -- only for the patches some pixel of which is
 // still unsaturated -- the next ones, and so on.  In a street scene most patches saturate within a few hundred entries,
 // and pass 1 (which restarts from T = 1 in every segment) would otherwise walk every entry behind that point for nothing.
 // Leaves `ra` covering all segments with the gate armed, which is what pass 2 and the combine expect.
-void run_pass1_rounds(lg::RenderFwdArgs& ra, uint8_t* alive, hipStream_t stream) {
+void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive, hipStream_t stream) {
     const int S = ra.S;
-    int r[8];
-    const int n = pass1_rounds(r, 8);
+    const int* r = plan.rounds;
+    const int n = plan.n_rounds;
     ra.alive = nullptr; ra.front = 0;
     int lo = 0;
     for (int i = 0; i < n && r[i] < S; i++) {
@@ -210,9 +201,7 @@ int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 int api_check_launch(hipStream_t s, int debug, const char* what) { return check_launch(s, debug, what); }
 int api_tile_rows() { return tile_rows(); }
 int api_ceil_log2(uint32_t n) { return ceil_log2(n); }
-int api_max_segments() { return max_segments(); }
-int api_segment_length() { return segment_length(); }
-int api_pass1_rounds(int* out, int cap) { return pass1_rounds(out, cap); }
+SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel) { return plan_segments(R, waves_per_tile, surfel); }
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s) {
     if (n > HostRead::WORDS || !t_host_read.ready()) return (int)hipErrorOutOfMemory;
     hipError_t e = hipMemcpyAsync(t_host_read.words, dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
@@ -235,12 +224,15 @@ struct Profiler {
     static constexpr int MAX_CALLS = 256;
     struct Call { int n = 0; const char* names[LIDARGS_MAX_STAGES]; hipEvent_t ev[LIDARGS_MAX_STAGES + 1]; bool created = false; };
     bool enabled = false;
+    int every = 1;           // record every `every`-th call of a kind: an event costs ~4.5 us of device time, a dozen per call 6 % of a frame
+    int seen[2] = {0, 0};    // calls of each kind (0 forward-like, 1 backward) since enable
     int ncalls = 0;          // calls recorded since enable
     Call* calls = nullptr;
     Call* cur = nullptr;
-    void begin(hipStream_t s) {
+    void begin(hipStream_t s, int kind) {
         cur = nullptr;
         if (!enabled) return;
+        if (seen[kind]++ % every != 0) return;
         if (!calls) calls = new Call[MAX_CALLS];
         cur = &calls[ncalls % MAX_CALLS];
         ncalls++;
@@ -280,7 +272,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (P == 0) return 0;   // R3/rasterize_points.cu:87: outputs stay as the caller initialised them
 
     const lg::TileGrid grid4 = lg::make_grid(width, height, 4);        // the image buffer is laid out for the finest tiling
-    g_prof.begin(stream);
+    g_prof.begin(stream, 0);
 
     char* geom_p = geometry_alloc(geometry_user, lg::geom_carve(nullptr, (size_t)P, nullptr));
     if (!geom_p) return fail(LIDARGS_ERR_ALLOC, "geometry allocator returned NULL%s");
@@ -339,7 +331,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_prof.mark("scan+readback", stream);
 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const int S = lg::choose_segments(R, max_segments());
+    const lg::SegPlan plan = plan_segments(R, grid.waves_per_tile, 0);
+    const int S = lg::choose_segments(R, plan.max_segments);
     char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, patches, grid.waves_per_tile, S, nullptr));
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
     lg::BinView bin; lg::bin_carve(bin_p, R, patches, grid.waves_per_tile, S, &bin);
@@ -369,13 +362,13 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
-    ra.seg = bin.seg; ra.S = S; ra.seg_len = segment_length();
+    ra.seg = bin.seg; ra.S = S; ra.seg_len = plan.seg_len;
     ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = R;
     ra.transmittance_only = transmittance_pass;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
     if (ra.run_pass1) {
-        run_pass1_rounds(ra, bin.alive, stream);
+        run_pass1_rounds(ra, plan, bin.alive, stream);
         LG_STAGE_CHECK("render pass 1");
         g_prof.mark("render_pass1", stream);
     }
@@ -420,10 +413,11 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     if (!TH) return fail(LIDARGS_ERR_STATE, "backward: these buffers do not come from a forward of this library instance%s");
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const int S = lg::choose_segments((size_t)R, max_segments());
+    const lg::SegPlan plan = plan_segments((size_t)R, grid.waves_per_tile, 0);
+    const int S = lg::choose_segments((size_t)R, plan.max_segments);
     lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
-    g_prof.begin(stream);
+    g_prof.begin(stream, 1);
 
     if (!take_zeroed_gradients(geom_buffer)) LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
     g_prof.mark("bwd_zero", stream);
@@ -431,8 +425,8 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     lg::RenderBwdArgs rb;
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
-    rb.seg = bin.seg; rb.S = S; rb.seg_len = segment_length();
-    rb.alive = pass1_gated(S) ? bin.alive : nullptr;
+    rb.seg = bin.seg; rb.S = S; rb.seg_len = plan.seg_len;
+    rb.alive = pass1_gated(plan, S) ? bin.alive : nullptr;
     rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = (size_t)R;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
@@ -560,7 +554,8 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     if (!TH) return fail(LIDARGS_ERR_STATE, "render_shell: these buffers do not come from a forward of this library instance%s");
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const int S = lg::choose_segments((size_t)R, max_segments());
+    const lg::SegPlan plan = plan_segments((size_t)R, grid.waves_per_tile, 0);
+    const int S = lg::choose_segments((size_t)R, plan.max_segments);
     lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     lg::RenderFwdArgs ra;
@@ -568,14 +563,14 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
-    ra.seg = bin.seg; ra.S = S; ra.seg_len = segment_length();
+    ra.seg = bin.seg; ra.S = S; ra.seg_len = plan.seg_len;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0;
-    ra.alive = pass1_gated(S) ? bin.alive : nullptr;              // written, like the flags, by the shell's phase 1
+    ra.alive = pass1_gated(plan, S) ? bin.alive : nullptr;        // written, like the flags, by the shell's phase 1
     ra.flags = bin.flags; ra.R = (size_t)R;      // written by the shell's phase 1 (lidargs_forward_shell)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
-    if (ra.run_pass1) run_pass1_rounds(ra, bin.alive, stream);
+    if (ra.run_pass1) run_pass1_rounds(ra, plan, bin.alive, stream);
     if (!transmittance_pass) lg::launch_render_pass2(ra, stream);
     lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render shell");
@@ -608,6 +603,8 @@ void lidargs_profile_enable(int on) {
             c.n = 0;
         }
         g_prof.ncalls = 0;
+        g_prof.seen[0] = g_prof.seen[1] = 0;
+        g_prof.every = on > 1 ? on : 1;
     }
     g_prof.enabled = on != 0;
 }

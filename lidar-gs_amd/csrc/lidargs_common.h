@@ -198,9 +198,8 @@ int api_fail(int code, const char* msg);
 int api_check_launch(hipStream_t s, int debug, const char* what);
 int api_tile_rows();
 int api_ceil_log2(uint32_t n);
-int api_max_segments();
-int api_segment_length();
-int api_pass1_rounds(int* out, int cap);
+struct SegPlan { int seg_len, max_segments, n_rounds, rounds[8]; };   // api.hip plan_segments
+SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel);
 // Device -> host read of `n` (<= 1024) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
 // for the copy only.  Returns a hipError_t.
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s);

@@ -256,7 +256,9 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 # ---- introspection (bench.py / tests) ----------------------------------------------------------------------------
 def profile_enable(on=True):
-    _lib.lidargs_profile_enable(C.c_int(1 if on else 0))
+    """False/0: off; True/1: stage events on every call; N > 1: on every N-th forward and every N-th backward (an event costs
+    ~4.5 us of device time, a dozen per call 6 % of a 1 ms frame)."""
+    _lib.lidargs_profile_enable(C.c_int(int(on)))
 
 
 def profile_read():
