@@ -45,9 +45,15 @@ def algorithmic_bytes(P, V, R_ref, N, T):
     return fwd, bwd, blend_fwd, blend_bwd
 
 
-def clock_ramp(step, seconds=0.5):
+def clock_ramp(step, seconds=0.5, fixed_steps=None):
     """A freshly started process on an idle GPU runs its first few hundred frames 5-8 % slower than steady state (measured:
-    0.96 vs 0.90 ms/frame): `seconds` of untimed steps before the W warm-up steps the contract asks for."""
+    0.96 vs 0.90 ms/frame): `seconds` of untimed steps before the W warm-up steps the contract asks for.  With more than one
+    rank the step holds collectives, so every rank must run the SAME number of steps: pass `fixed_steps`."""
+    if fixed_steps is not None:
+        for _ in range(fixed_steps):
+            step()
+        torch.cuda.synchronize()
+        return
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         step()
@@ -510,7 +516,7 @@ def main():
             shares = lidargs_dist.rebalance_shares(shares, [float(t) for t in times], fixed=0.25)
             rast.edges = cut(shares)
         _C.profile_enable(True)
-    clock_ramp(step)
+    clock_ramp(step, fixed_steps=300 if (world > 1 or force_shells) else None)
     for _ in range(args.warmup):
         step()
     barrier()
