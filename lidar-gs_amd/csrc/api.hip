@@ -712,6 +712,37 @@ int lidargs_shell_select(int P, const float* means3D, const float* colors, const
     return (int)total_h;
 }
 
+int lidargs_shell_pack_grad_rows(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors, const float* dL_dopacity,
+                                 const float* dL_dscales, const float* dL_drotations, const int* idx, float* rows, void* stream) {
+    if (M < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_pack_grad_rows: M < 0%s");
+    if (M == 0) return 0;
+    if (!dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dscales || !dL_drotations || !idx || !rows)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_pack_grad_rows: NULL pointer%s");
+    lg::launch_shell_pack_rows(M, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, idx, rows, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "shell pack rows");
+}
+int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense, void* stream) {
+    if (n < 0 || P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_unpack_grad_rows: bad sizes%s");
+    if (P == 0) return 0;
+    if (!dense || (n > 0 && !rows)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_unpack_grad_rows: NULL pointer%s");
+    LG_HIP(hipMemsetAsync(dense, 0, sizeof(float) * 17 * (size_t)P, (hipStream_t)stream));
+    if (n) lg::launch_shell_unpack_rows(n, rows, P, dense, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "shell unpack rows");
+}
+int lidargs_shell_chunk_counts(int M, const int* idx, int chunk_rows, int world, float* counts, void* stream) {
+    if (M < 0 || chunk_rows <= 0 || world <= 0 || !counts || (M > 0 && !idx)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_chunk_counts: bad arguments%s");
+    lg::launch_shell_chunk_counts(M, idx, chunk_rows, world, counts, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "shell chunk counts");
+}
+int lidargs_shell_scatter_radii(int M, const int* idx, const int* radii_shell, int P, int* radii, void* stream) {
+    if (M < 0 || P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_scatter_radii: bad sizes%s");
+    if (P == 0) return 0;
+    if (!radii || (M > 0 && (!idx || !radii_shell))) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_scatter_radii: NULL pointer%s");
+    LG_HIP(hipMemsetAsync(radii, 0, sizeof(int) * (size_t)P, (hipStream_t)stream));
+    if (M) lg::launch_shell_scatter_i32(M, idx, radii_shell, P, radii, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "shell scatter radii");
+}
+
 int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, void* stream_) {
     if (G < 1 || rank < 0 || rank >= G || N < 0 || !all_T || !T_in) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_transmittance: bad argument%s");
     if (N) lg::launch_shell_transmittance(G, rank, N, all_T, T_in, (hipStream_t)stream_);

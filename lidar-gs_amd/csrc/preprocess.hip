@@ -547,4 +547,63 @@ void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, con
                        idx_out, o_means, o_colors, o_opac, o_scales, o_rot);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gradient rows of a range shell (lidargs_dist step 6): the six returned gradients of the shell's M Gaussians + their global
+// index as one [M, 18] row block (what the all-to-all ships), and back: rows scattered by index into a dense [P, 17] block.
+// One launch each instead of a concatenate, casts, an index_copy and their temporaries.
+__global__ void __launch_bounds__(256) k_shell_pack_rows(int M, const float* __restrict__ g_m3, const float* __restrict__ g_m2,
+                                                         const float* __restrict__ g_col, const float* __restrict__ g_op,
+                                                         const float* __restrict__ g_sc, const float* __restrict__ g_rot,
+                                                         const int* __restrict__ idx, float* __restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float* r = rows + 18 * (size_t)i;
+    r[0] = g_m3[3 * (size_t)i]; r[1] = g_m3[3 * (size_t)i + 1]; r[2] = g_m3[3 * (size_t)i + 2];
+    const float4 m2 = reinterpret_cast<const float4*>(g_m2)[i];
+    r[3] = m2.x; r[4] = m2.y; r[5] = m2.z; r[6] = m2.w;
+    const float2 c = reinterpret_cast<const float2*>(g_col)[i];
+    r[7] = c.x; r[8] = c.y;
+    r[9] = g_op[i];
+    r[10] = g_sc[3 * (size_t)i]; r[11] = g_sc[3 * (size_t)i + 1]; r[12] = g_sc[3 * (size_t)i + 2];
+    const float4 q = reinterpret_cast<const float4*>(g_rot)[i];
+    r[13] = q.x; r[14] = q.y; r[15] = q.z; r[16] = q.w;
+    r[17] = __int_as_float(idx[i]);                                    // the index travels as a bit pattern
+}
+__global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* __restrict__ rows, int P, float* __restrict__ dense) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rows + 18 * (size_t)i;
+    const int g = __float_as_int(r[17]);
+    if (g < 0 || g >= P) return;
+    float* d = dense + 17 * (size_t)g;
+#pragma unroll
+    for (int k = 0; k < 17; k++) d[k] = r[k];
+}
+// counts[d] = #(idx in [d * chunk, (d + 1) * chunk)), idx ascending: the split sizes of the gradient all-to-all
+__global__ void __launch_bounds__(64) k_shell_chunk_counts(int M, const int* __restrict__ idx, int chunk, int world, float* __restrict__ counts) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= world) return;
+    auto lower = [&](long long v) { int lo = 0, hi = M; while (lo < hi) { const int md = (lo + hi) >> 1; if ((long long)idx[md] < v) lo = md + 1; else hi = md; } return lo; };
+    counts[d] = (float)(lower((long long)(d + 1) * chunk) - lower((long long)d * chunk));
+}
+__global__ void __launch_bounds__(256) k_shell_scatter_i32(int M, const int* __restrict__ idx, const int* __restrict__ src, int P, int* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int g = idx[i];
+    if (g >= 0 && g < P) dst[g] = src[i];
+}
+void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const float* g_col, const float* g_op, const float* g_sc,
+                            const float* g_rot, const int* idx, float* rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_pack_rows, dim3((M + 255) / 256), dim3(256), 0, s, M, g_m3, g_m2, g_col, g_op, g_sc, g_rot, idx, rows);
+}
+void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense);
+}
+void launch_shell_chunk_counts(int M, const int* idx, int chunk, int world, float* counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_chunk_counts, dim3((world + 63) / 64), dim3(64), 0, s, M, idx, chunk, world, counts);
+}
+void launch_shell_scatter_i32(int M, const int* idx, const int* src, int P, int* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_scatter_i32, dim3((M + 255) / 256), dim3(256), 0, s, M, idx, src, P, dst);
+}
+
 }  // namespace lg

@@ -176,7 +176,8 @@ class HipShellBackend:
         from diff_lidargs_rasterization import _C
         self._C = _C
         self.lib = _C._lib
-        for name in ("lidargs_shell_select", "lidargs_shell_transmittance", "lidargs_shell_compose"):
+        for name in ("lidargs_shell_select", "lidargs_shell_transmittance", "lidargs_shell_compose", "lidargs_shell_pack_grad_rows",
+                     "lidargs_shell_unpack_grad_rows", "lidargs_shell_chunk_counts", "lidargs_shell_scatter_radii"):
             getattr(self.lib, name).restype = C.c_int
         self.lib.lidargs_shell_select_scratch_bytes.restype = C.c_size_t
         self._sel = {}              # persistent selection buffers per (device, P): no per-frame allocation
@@ -311,6 +312,42 @@ class HipShellBackend:
         return dict(means3D=g_m3, means2D=g_m2, colors=g_col, opacities=g_op, scales=g_sc, rotations=g_rot)
 
 
+    # ---- step 6 helpers: one launch each instead of concatenates, casts and index copies -------------------------------
+    def _call(self, name, dev, *args):
+        with torch.cuda.device(dev):
+            rc = getattr(self.lib, name)(*args, self._C._stream(dev))
+        if rc < 0:
+            self._C._raise(rc, name)
+
+    def scatter_radii(self, idx, radii_shell, P):
+        """radii i32[P]: the shell's radii at their global rows, zero elsewhere."""
+        dev, p = idx.device, self._C._ptr
+        out = torch.empty(P, dtype=torch.int32, device=dev)
+        self._call("lidargs_shell_scatter_radii", dev, C.c_int(int(idx.shape[0])), p(idx), p(radii_shell), C.c_int(P), p(out))
+        return out
+
+    def chunk_counts(self, idx, chunk_rows, world, out):
+        """out f32[world] (a view into the buffer the T_pass all-gather ships): rows of this shell bound for each index chunk."""
+        self._call("lidargs_shell_chunk_counts", idx.device, C.c_int(int(idx.shape[0])), self._C._ptr(idx), C.c_int(chunk_rows), C.c_int(world),
+                   self._C._ptr(out))
+
+    def pack_rows(self, g, idx):
+        """[M, 18]: the six gradients of the shell's rows + the bit pattern of their global index."""
+        dev, p, M = idx.device, self._C._ptr, int(idx.shape[0])
+        rows = torch.empty((M, GRAD_COLS + 1), dtype=torch.float32, device=dev)
+        self._call("lidargs_shell_pack_grad_rows", dev, C.c_int(M), p(g["means3D"]), p(g["means2D"]), p(g["colors"]), p(g["opacities"]),
+                   p(g["scales"]), p(g["rotations"]), p(idx), p(rows))
+        return rows
+
+    def unpack_rows(self, rows, P):
+        """dense [P, 17]: zero, then every row written at the index it carries."""
+        dev, p = rows.device, self._C._ptr
+        rows = rows.contiguous()
+        dense = torch.empty((P, GRAD_COLS), dtype=torch.float32, device=dev)
+        self._call("lidargs_shell_unpack_grad_rows", dev, C.c_int(int(rows.shape[0])), p(rows), C.c_int(P), p(dense))
+        return dense
+
+
 def _chunk_rows(P, world):
     return (P + world - 1) // world
 
@@ -345,20 +382,17 @@ def shell_forward(module, means3D, colors, opacities, scales, rotations):
         # of their own, and are read back at the end of the forward, off the backward's critical path.
         rows = _chunk_rows(P, comm.world)
         assert rows < (1 << 24)
-        bounds = torch.arange(0, comm.world + 1, device=dev, dtype=idx.dtype) * rows
-        cuts = torch.searchsorted(idx, bounds)
-        tail = (cuts[1:] - cuts[:-1]).to(torch.float32)
+        tail = torch.empty(comm.world, dtype=torch.float32, device=dev)
+        be.chunk_counts(idx, rows, comm.world, tail)
     st, T_pass = be.forward(sel, lo, hi)                                          # 1
-    radii = torch.zeros(P, dtype=torch.int32, device=dev)
-    idx64 = idx.long()
-    radii[idx64] = st["radii"]
+    radii = be.scatter_radii(idx, st["radii"], P)
     wait_radii = comm.all_reduce_async(radii) if comm.world > 1 else (lambda: None)   # overlaps the rendering
     allT = comm.all_gather(T_pass if tail is None else torch.cat([T_pass, tail]))  # 2   [G, N (+G)]
     counts = allT[:, N:] if exchange else None
     T_in = be.transmittance(allT[:, :N] if exchange else allT, comm.rank)
     planes = comm.all_gather(be.render(st, T_in))                                 # 3, 4   [G, 5, N]
     color, depth, occ, T_final, behind = be.compose(planes, comm.rank, inp["bg"], H, W)
-    saved = dict(st=st, behind=behind, T_final=T_final, idx=idx, idx64=idx64, P=P)
+    saved = dict(st=st, behind=behind, T_final=T_final, idx=idx, P=P)
     if exchange:
         c = counts.to(torch.int64).cpu()                                          # [src, dst]
         saved.update(send=c[comm.rank].tolist(), recv=c[:, comm.rank].tolist())
@@ -376,18 +410,13 @@ def shell_backward(module, saved, g_color, g_depth, g_occ):
     # d(color)/d(T_final) for the background is inside the blend: (-T_final/(1-alpha)) * bg.g  (R3/cr/backward.cu:727)
     g = be.backward(st, saved["behind"], saved["T_final"], (g_color.reshape(2, H * W), g_depth.reshape(H * W), g_occ.reshape(H * W)))
     sync = module.grad_sync if comm.world > 1 else "none"
+    packed = be.pack_rows(g, idx)                                                 # [M, 18]: gradients + the row's global index
     if sync == "reduce_scatter":
         # 6: the shell's rows go straight to their index-chunk owners; the row index travels as an 18th column (bit pattern)
-        rows = _chunk_rows(P, comm.world)
-        packed = torch.cat([g[k] for k, _ in GRAD_WIDTHS] + [idx.view(torch.float32).view(-1, 1)], dim=1)      # [M, 18]
         got = comm.all_to_all_rows(packed, saved["send"], saved["recv"])
-        local = got[:, GRAD_COLS].contiguous().view(torch.int32).long() - comm.rank * rows
-        dense = torch.zeros((P, GRAD_COLS), dtype=torch.float32, device=dev)
-        dense[comm.rank * rows:(comm.rank + 1) * rows].index_copy_(0, local, got[:, :GRAD_COLS])
+        dense = be.unpack_rows(got, P)
     else:
-        packed = torch.cat([g[k] for k, _ in GRAD_WIDTHS], dim=1)                 # [M, 17]
-        dense = torch.zeros((P, GRAD_COLS), dtype=torch.float32, device=dev)
-        dense.index_copy_(0, saved["idx64"], packed)
+        dense = be.unpack_rows(packed, P)
         if sync == "all_reduce":
             dense = comm.all_reduce(dense)
         elif sync == "reduce_scatter_dense":

@@ -28,6 +28,27 @@ class OracleShellBackend:
             sel[k] = inp[k][idx.long()]
         return idx, sel
 
+    # step 6 helpers: same protocol as HipShellBackend, in framework ops
+    def scatter_radii(self, idx, radii_shell, P):
+        out = torch.zeros(P, dtype=torch.int32)
+        out[idx.long()] = radii_shell
+        return out
+
+    def chunk_counts(self, idx, chunk_rows, world, out):
+        bounds = torch.arange(0, world + 1, dtype=idx.dtype) * chunk_rows
+        cuts = torch.searchsorted(idx, bounds)
+        out.copy_((cuts[1:] - cuts[:-1]).to(torch.float32))
+
+    def pack_rows(self, g, idx):
+        cols = [g[k] for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations")]
+        return torch.cat(cols + [idx.view(torch.float32).view(-1, 1)], dim=1)
+
+    def unpack_rows(self, rows, P):
+        dense = torch.zeros((P, 17), dtype=torch.float32)
+        if rows.shape[0]:
+            dense.index_copy_(0, rows[:, 17].contiguous().view(torch.int32).long(), rows[:, :17])
+        return dense
+
     def transmittance(self, allT, rank):
         return torch.prod(allT[:rank], dim=0) if rank > 0 else torch.ones_like(allT[0])
 
