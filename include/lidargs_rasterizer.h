@@ -251,14 +251,15 @@ int lidargs_shell_compose(int G, int rank, int N, const float* planes, const flo
 /* Gradient exchange of the range shells (lidargs_dist step 6), one launch each:
  * lidargs_shell_pack_grad_rows    rows f32[M*18] = per selected Gaussian (dL_dmeans3D 3, dL_dmeans2D 4, dL_dcolors 2, dL_dopacity 1,
  *                                 dL_dscales 3, dL_drotations 4, bit pattern of its global index idx[i]): what the all-to-all ships.
- * lidargs_shell_unpack_grad_rows  dense f32[P*17] = 0, then row i of rows f32[n*18] written to dense row (index in column 17).
+ * lidargs_shell_unpack_grad_rows  dense f32[P*17] = 0, then row i of rows f32[n*18] written at the index in its column 17: as row
+ *                                 [17] of dense (blocked = 0) or into six contiguous blocks [P,3][P,4][P,2][P,1][P,3][P,4] (blocked = 1).
  * lidargs_shell_chunk_counts      counts f32[world]: how many of the ascending idx i32[M] fall into each index chunk of chunk_rows
  *                                 rows (the split sizes of the all-to-all; exact as floats below 2^24).
  * lidargs_shell_scatter_radii     radii i32[P] = 0, then radii[idx[i]] = radii_shell[i]. */
 int lidargs_shell_pack_grad_rows(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors,
                                  const float* dL_dopacity, const float* dL_dscales, const float* dL_drotations, const int* idx,
                                  float* rows, void* stream);
-int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense, void* stream);
+int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense, int blocked, void* stream);
 int lidargs_shell_chunk_counts(int M, const int* idx, int chunk_rows, int world, float* counts, void* stream);
 int lidargs_shell_scatter_radii(int M, const int* idx, const int* radii_shell, int P, int* radii, void* stream);
 

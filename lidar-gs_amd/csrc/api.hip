@@ -721,12 +721,12 @@ int lidargs_shell_pack_grad_rows(int M, const float* dL_dmeans3D, const float* d
     lg::launch_shell_pack_rows(M, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, idx, rows, (hipStream_t)stream);
     return check_launch((hipStream_t)stream, 0, "shell pack rows");
 }
-int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense, void* stream) {
+int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense, int blocked, void* stream) {
     if (n < 0 || P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_unpack_grad_rows: bad sizes%s");
     if (P == 0) return 0;
     if (!dense || (n > 0 && !rows)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_unpack_grad_rows: NULL pointer%s");
     LG_HIP(hipMemsetAsync(dense, 0, sizeof(float) * 17 * (size_t)P, (hipStream_t)stream));
-    if (n) lg::launch_shell_unpack_rows(n, rows, P, dense, (hipStream_t)stream);
+    if (n) lg::launch_shell_unpack_rows(n, rows, P, dense, blocked, (hipStream_t)stream);
     return check_launch((hipStream_t)stream, 0, "shell unpack rows");
 }
 int lidargs_shell_chunk_counts(int M, const int* idx, int chunk_rows, int world, float* counts, void* stream) {

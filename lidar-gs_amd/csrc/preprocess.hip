@@ -569,15 +569,26 @@ __global__ void __launch_bounds__(256) k_shell_pack_rows(int M, const float* __r
     r[13] = q.x; r[14] = q.y; r[15] = q.z; r[16] = q.w;
     r[17] = __int_as_float(idx[i]);                                    // the index travels as a bit pattern
 }
-__global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* __restrict__ rows, int P, float* __restrict__ dense) {
+// blocked != 0: dense is six contiguous blocks [P,3][P,4][P,2][P,1][P,3][P,4] (what autograd takes without a strided copy each)
+__global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* __restrict__ rows, int P, float* __restrict__ dense, int blocked) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rows + 18 * (size_t)i;
     const int g = __float_as_int(r[17]);
     if (g < 0 || g >= P) return;
-    float* d = dense + 17 * (size_t)g;
+    if (!blocked) {
+        float* d = dense + 17 * (size_t)g;
 #pragma unroll
-    for (int k = 0; k < 17; k++) d[k] = r[k];
+        for (int k = 0; k < 17; k++) d[k] = r[k];
+        return;
+    }
+    const size_t Ps = (size_t)P, gs = (size_t)g;
+    float* d = dense + 3 * gs;            d[0] = r[0]; d[1] = r[1]; d[2] = r[2];
+    d = dense + 3 * Ps + 4 * gs;          d[0] = r[3]; d[1] = r[4]; d[2] = r[5]; d[3] = r[6];
+    d = dense + 7 * Ps + 2 * gs;          d[0] = r[7]; d[1] = r[8];
+    dense[9 * Ps + gs] = r[9];
+    d = dense + 10 * Ps + 3 * gs;         d[0] = r[10]; d[1] = r[11]; d[2] = r[12];
+    d = dense + 13 * Ps + 4 * gs;         d[0] = r[13]; d[1] = r[14]; d[2] = r[15]; d[3] = r[16];
 }
 // counts[d] = #(idx in [d * chunk, (d + 1) * chunk)), idx ascending: the split sizes of the gradient all-to-all
 __global__ void __launch_bounds__(64) k_shell_chunk_counts(int M, const int* __restrict__ idx, int chunk, int world, float* __restrict__ counts) {
@@ -596,8 +607,8 @@ void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const f
                             const float* g_rot, const int* idx, float* rows, hipStream_t s) {
     hipLaunchKernelGGL(k_shell_pack_rows, dim3((M + 255) / 256), dim3(256), 0, s, M, g_m3, g_m2, g_col, g_op, g_sc, g_rot, idx, rows);
 }
-void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, hipStream_t s) {
-    hipLaunchKernelGGL(k_shell_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense);
+void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense, blocked);
 }
 void launch_shell_chunk_counts(int M, const int* idx, int chunk, int world, float* counts, hipStream_t s) {
     hipLaunchKernelGGL(k_shell_chunk_counts, dim3((world + 63) / 64), dim3(64), 0, s, M, idx, chunk, world, counts);

@@ -339,12 +339,13 @@ class HipShellBackend:
                    p(g["scales"]), p(g["rotations"]), p(idx), p(rows))
         return rows
 
-    def unpack_rows(self, rows, P):
-        """dense [P, 17]: zero, then every row written at the index it carries."""
+    def unpack_rows(self, rows, P, blocked=False):
+        """Zero, then every row written at the index it carries: dense [P, 17], or (blocked) one flat [17 P] tensor holding the
+        six gradients as contiguous blocks [P,3][P,4][P,2][P,1][P,3][P,4], which autograd takes without a strided copy each."""
         dev, p = rows.device, self._C._ptr
         rows = rows.contiguous()
-        dense = torch.empty((P, GRAD_COLS), dtype=torch.float32, device=dev)
-        self._call("lidargs_shell_unpack_grad_rows", dev, C.c_int(int(rows.shape[0])), p(rows), C.c_int(P), p(dense))
+        dense = torch.empty(P * GRAD_COLS if blocked else (P, GRAD_COLS), dtype=torch.float32, device=dev)
+        self._call("lidargs_shell_unpack_grad_rows", dev, C.c_int(int(rows.shape[0])), p(rows), C.c_int(P), p(dense), C.c_int(1 if blocked else 0))
         return dense
 
 
@@ -411,12 +412,13 @@ def shell_backward(module, saved, g_color, g_depth, g_occ):
     g = be.backward(st, saved["behind"], saved["T_final"], (g_color.reshape(2, H * W), g_depth.reshape(H * W), g_occ.reshape(H * W)))
     sync = module.grad_sync if comm.world > 1 else "none"
     packed = be.pack_rows(g, idx)                                                 # [M, 18]: gradients + the row's global index
+    blocked = sync != "reduce_scatter_dense"
     if sync == "reduce_scatter":
         # 6: the shell's rows go straight to their index-chunk owners; the row index travels as an 18th column (bit pattern)
         got = comm.all_to_all_rows(packed, saved["send"], saved["recv"])
-        dense = be.unpack_rows(got, P)
+        dense = be.unpack_rows(got, P, blocked=True)
     else:
-        dense = be.unpack_rows(packed, P)
+        dense = be.unpack_rows(packed, P, blocked=blocked)
         if sync == "all_reduce":
             dense = comm.all_reduce(dense)
         elif sync == "reduce_scatter_dense":
@@ -430,7 +432,11 @@ def shell_backward(module, saved, g_color, g_depth, g_occ):
             dense = dense[:P]
     o, out = 0, {}
     for k, w in GRAD_WIDTHS:
-        out[k] = dense[:, o:o + w]; o += w
+        if blocked:
+            out[k] = dense[o * P:(o + w) * P].view(P, w)
+        else:
+            out[k] = dense[:, o:o + w]
+        o += w
     return out
 
 

@@ -43,11 +43,16 @@ class OracleShellBackend:
         cols = [g[k] for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations")]
         return torch.cat(cols + [idx.view(torch.float32).view(-1, 1)], dim=1)
 
-    def unpack_rows(self, rows, P):
+    def unpack_rows(self, rows, P, blocked=False):
         dense = torch.zeros((P, 17), dtype=torch.float32)
         if rows.shape[0]:
             dense.index_copy_(0, rows[:, 17].contiguous().view(torch.int32).long(), rows[:, :17])
-        return dense
+        if not blocked:
+            return dense
+        o, parts = 0, []
+        for w in (3, 4, 2, 1, 3, 4):                      # six contiguous blocks [P, w]
+            parts.append(dense[:, o:o + w].contiguous().view(-1)); o += w
+        return torch.cat(parts)
 
     def transmittance(self, allT, rank):
         return torch.prod(allT[:rank], dim=0) if rank > 0 else torch.ones_like(allT[0])
