@@ -168,3 +168,34 @@ def test_rccl_collectives_world_of_one(hip_lib_built):
         parity("dL_drotations", g["rotations"].cpu().numpy(), ref["dL_drotations"])
     finally:
         dist.destroy_process_group()
+
+
+def test_shell_exchange_helpers_match_framework_ops(hip_lib_built):
+    """lidargs_shell_{pack,unpack}_grad_rows, _chunk_counts, _scatter_radii against the framework ops they replace (bit for bit:
+    they only move data), including empty inputs and both dense layouts."""
+    import lidargs_dist
+    be = lidargs_dist.HipShellBackend()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    P, world = 10007, 3
+    for M in (0, 1, 4321):
+        idx = torch.sort(torch.randperm(P, generator=g)[:M]).values.to(torch.int32).cuda()
+        grads = {k: torch.randn((M, w), generator=g).cuda() for k, w in lidargs_dist.GRAD_WIDTHS}
+        rows = be.pack_rows(grads, idx)
+        ref_rows = torch.cat([grads[k] for k, _ in lidargs_dist.GRAD_WIDTHS] + [idx.view(torch.float32).view(-1, 1)], dim=1)
+        assert torch.equal(rows.view(torch.int32), ref_rows.view(torch.int32))
+        ref_dense = torch.zeros((P, lidargs_dist.GRAD_COLS), device="cuda")
+        ref_dense[idx.long()] = ref_rows[:, :lidargs_dist.GRAD_COLS]
+        assert torch.equal(be.unpack_rows(rows, P), ref_dense)
+        flat, o = be.unpack_rows(rows, P, blocked=True), 0
+        for k, w in lidargs_dist.GRAD_WIDTHS:
+            assert torch.equal(flat[o * P:(o + w) * P].view(P, w), ref_dense[:, o:o + w]), k
+            o += w
+        chunk = lidargs_dist._chunk_rows(P, world)
+        counts = torch.full((world,), -1.0, device="cuda")
+        be.chunk_counts(idx, chunk, world, counts)
+        ref_counts = torch.bincount(idx.long() // chunk, minlength=world).float()
+        assert torch.equal(counts, ref_counts)
+        radii_shell = torch.randint(1, 50, (M,), generator=g).to(torch.int32).cuda()
+        ref_radii = torch.zeros(P, dtype=torch.int32, device="cuda")
+        ref_radii[idx.long()] = radii_shell
+        assert torch.equal(be.scatter_radii(idx, radii_shell, P), ref_radii)
