@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__
 
 // One wave per (digit, chunk of `chunk` blocks): exclusive prefix of the block histograms inside the chunk, in place, and the
 // chunk's sum -> part[digit][chunk].  With a single chunk (chunk >= nblocks) the sum is the digit total itself.
+template <int MAXG>
 __global__ void __launch_bounds__(256) k_radix_digit_prefix(uint32_t* __restrict__ hist, unsigned nblocks, int bins, unsigned chunk,
                                                             unsigned chunks, uint32_t* __restrict__ part) {
     const int lane = threadIdx.x & 63;
@@ -144,13 +145,21 @@ __global__ void __launch_bounds__(256) k_radix_digit_prefix(uint32_t* __restrict
     if (d >= (unsigned)bins) return;
     uint32_t* row = hist + (size_t)d * nblocks;
     const unsigned lo = c * chunk, hi = min(nblocks, lo + chunk);
+    // A chunk is at most 2 * SORT_PREFIX_CHUNK blocks = 32 groups of 64 (MAXG: 8, 16 or 32, picked at launch): every load is issued before the first scan and the
+    // groups' scans are independent chains (walking the groups one after the other, load -> six dependent cross-lane steps
+    // -> store, made this ~9 us launch the slowest part of a sort pass on small inputs); only the carries are sequential.
+    uint32_t v[MAXG], inc[MAXG];
+    const unsigned groups = (hi - lo + 63u) / 64u;                     // wave-uniform
+#pragma unroll
+    for (int g = 0; g < MAXG; g++) { const unsigned b = lo + (unsigned)g * 64 + lane; v[g] = b < hi ? row[b] : 0u; }
+#pragma unroll
+    for (int g = 0; g < MAXG; g++) inc[g] = (unsigned)g < groups ? wave_incl_scan(v[g], lane) : 0u;
     uint32_t carry = 0;
-    for (unsigned b0 = lo; b0 < hi; b0 += 64) {
-        const unsigned b = b0 + lane;
-        const uint32_t v = b < hi ? row[b] : 0u;
-        const uint32_t inc = wave_incl_scan(v, lane);
-        if (b < hi) row[b] = carry + inc - v;
-        carry += __shfl(inc, 63);
+#pragma unroll
+    for (int g = 0; g < MAXG; g++) {
+        const unsigned b = lo + (unsigned)g * 64 + lane;
+        if (b < hi) row[b] = carry + inc[g] - v[g];
+        carry += __shfl(inc[g], 63);
     }
     if (lane == 0) part[(size_t)d * chunks + c] = carry;
 }
@@ -287,7 +296,11 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
     hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
     // single level: the chunk sums ARE the digit totals, written straight to `tot`
-    hipLaunchKernelGGL(k_radix_digit_prefix, dim3((BINS * chunks + 3) / 4), dim3(256), 0, s, hist, nb, BINS, chunk, chunks, two_level ? part : tot);
+    const dim3 pgrid((BINS * chunks + 3) / 4);
+    uint32_t* const pout = two_level ? part : tot;
+    if (chunk <= 8 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<16>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    else hipLaunchKernelGGL(k_radix_digit_prefix<32>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
     hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, shift, hist, tot, nb,
                        two_level ? part : (const uint32_t*)nullptr, chunk, chunks);
