@@ -305,7 +305,9 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 2. instance offsets in range order for the likeliest tile height (queued before the host wait, so that the device has work
     //    while the host decides), then the one host wait (R3/cr/rasterizer_impl.cu:292): the instance totals for tile heights
     //    4 / 8 / 16 -> tile height, R.  Only if another height wins are the offsets recomputed.
-    const int th_guess = forced_tile_rows() ? forced_tile_rows() : 4;
+    // the likeliest tile height: the one the last frame on this thread chose (a training loop renders similar frames in a row)
+    thread_local int t_last_th = 4;
+    const int th_guess = forced_tile_rows() ? forced_tile_rows() : t_last_th;
     lg::launch_instance_offsets(ids_sorted, geom.spans, th_guess, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
     LG_STAGE_CHECK("instance scan");
     uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
@@ -328,6 +330,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
     }
     remember_tile_rows(geom_p, TH, true);
+    t_last_th = TH;
     g_prof.mark("scan+readback", stream);
 
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
