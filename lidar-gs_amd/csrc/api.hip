@@ -287,7 +287,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     pp.scale_modifier = scale_modifier;
     pp.near_f = near_f; pp.far_f = far_f; pp.shell_lo = shell_lo; pp.shell_hi = shell_hi;
     const float pi_f = 3.14159265358979323846f;
-    pp.col_step = 2 * pi_f / width;                                    // R3/cr/forward.cu:334
+    pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;                                    // R3/cr/forward.cu:334
     pp.tan_col_step = tanf(2 * pi_f / width);                          // R3/cr/forward.cu:362
     pp.view = viewmatrix;
 
@@ -511,7 +511,7 @@ int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user,
     pp.near_f = (float)lidar_near; pp.far_f = (float)lidar_far;
     pp.shell_lo = -std::numeric_limits<float>::infinity(); pp.shell_hi = std::numeric_limits<float>::infinity();
     const float pi_f = 3.14159265358979323846f;
-    pp.col_step = 2 * pi_f / width;
+    pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;
     pp.tan_col_step = tanf(2 * pi_f / width);
     pp.view = viewmatrix;
     lg::GeomView none; memset(&none, 0, sizeof none);

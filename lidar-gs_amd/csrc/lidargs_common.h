@@ -189,6 +189,7 @@ struct PreprocessParams {
     float near_f, far_f;        // reference int near/far converted to float (R3/cr/forward.cu:304)
     float shell_lo, shell_hi;   // extra float range shell: keep lo <= range < hi (multi-GPU); +-inf otherwise
     float col_step;             // 2*pi/W        (float, as the reference evaluates it)
+    float inv_col_step;         // a bound from above on 1 / col_step (footprint pruning only)
     float tan_col_step;         // tanf(2*pi/W)  (host libm)
     const float* view;          // DEVICE pointer to the 16 floats (wave-uniform -> scalar loads)
 };
