@@ -73,6 +73,23 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
                         float* dL_dscaling_in, float* act_x, float* act_h, float* delta1, float* delta2,
                         char* scratch, size_t scratch_bytes, void* stream);
 
+/* Backward on the matrix pipe (v_mfma_f32_32x32x2_f32, exact f32): recompute, back-propagation and the weight gradients of the four
+ * MLPs as 32-row tile products; nothing per-anchor is written for a GEMM to read.  Same inputs and dense outputs as
+ * lidargs_ng_backward; instead of act_x / act_h / delta1 / delta2 the kernel's persistent waves write partial sums:
+ * partials f32[waves][floats_per_wave] (sizes from lidargs_ng_backward_partials), and the SUM OVER WAVES is
+ *   tiles  f32[5 + T2][32][32], T2 = 3 + ceil(7k/32):
+ *     tile m (m = 0 opacity, 1 covariance, 2 colour, 3 ray-drop)  [t][q]  dW1_m[t][q], q = 0..31
+ *     tile 4   [t][8 m + j]   dW1_m[t][32 + j], j = 0..3, and db1_m[t] at j = 4 (input 36 is the constant 1)
+ *     tile 5   [o][t] dW2 of the opacity MLP (rows o < k);  tiles 6 .. 5 + ceil(7k/32): covariance, row o of tile o / 32;
+ *     then colour, then ray-drop
+ *   db2    f32[128] after the tiles: output-layer bias gradients laid out [k | 7k | k | k]. */
+int lidargs_ng_backward_partials(int n_offsets, int* waves, int* floats_per_wave);
+int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* anchor_feat, const float* anchor,
+                             const float* offset, const float* scaling, const float* cam_center,
+                             const float* dL_dxyz, const float* dL_dcolor, const float* dL_dopacity, const float* dL_dscaling,
+                             const float* dL_drot, const float* dL_dneural_opacity, float* dL_danchor_feat, float* dL_danchor, float* dL_doffset,
+                             float* dL_dscaling_in, float* partials, char* scratch, size_t scratch_bytes, void* stream);
+
 /* Densification statistics -- GaussianModel.training_statis (scene/gaussian_model.py:599-622), in place, one launch chain, no host
  * read.  anchor_visible_mask u8[N]; offset_selection_mask u8[n*k] and neural_opacity f32[n*k] in visible-anchor order (what
  * generate_neural_gaussians returned); update_filter u8[M] (radii > 0) and viewspace_grad f32[M*4] (means2D.grad) in the order of

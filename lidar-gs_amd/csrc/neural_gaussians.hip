@@ -325,6 +325,332 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward(int N, int n_vis, NgMo
     for (int q = 0; q < 6; q++) d_scaling[6 * (size_t)i + q] = ds[q];
 }
 
+// ---- backward on the matrix pipe ---------------------------------------------------------------------------------------------------
+// k_ng_backward above evaluates the MLPs one anchor per lane, one FMA per scalar-loaded weight, and hands the weight gradients to two
+// library GEMMs through 1.4 KB of per-anchor rows (3 GB of write traffic per launch; VALU 22 % busy, 43 % of the wave cycles in
+// s_waitcnt).  Here a wave owns 64 anchors as two 32-row tiles and everything matrix-shaped runs on v_mfma_f32_32x32x2_f32 (exact f32):
+//   H = relu(X W1^T + b1), Y = H W2^T + b2            recompute     (A from LDS [unit][anchor], B = weights, L1-resident)
+//   per-anchor activation derivatives                 lane = anchor (the only VALU stage; y and delta2 pass through LDS)
+//   D1 = (D2 W2) * relu'(H), dX += D1 W1              back-propagation
+//   G1_m += D1^T [X 1], G2_m += D2^T H                weight gradients: the reduction index is the anchor, two per instruction;
+//                                                     13-15 accumulator tiles stay in registers for the life of the wave
+// Waves are persistent (one per SIMD), walk the anchor tiles with a grid stride and write their accumulators once, as partial sums
+// the caller adds up.  Nothing per-anchor is written except the dense input gradients.
+typedef float ng_f16v __attribute__((ext_vector_type(16)));
+#define NG_LS 65                                   // LDS stride of the [unit][anchor] arrays: transposed reads hit distinct banks
+#define NG_COV_TILES(K) ((7 * (K) + 31) / 32)
+#define NG_G2_TILES(K) (3 + NG_COV_TILES(K))       // opacity, covariance (1-3), colour, ray-drop
+#define NG_PARTIAL_FLOATS(K) ((5 + NG_G2_TILES(K)) * 1024 + 128)
+
+__device__ __forceinline__ int ng_crow(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }   // row of accumulator element e
+__device__ __forceinline__ float ng_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// c0 / c1 [32 anchors of tile 0 / 1][32 columns from col0] += sum_{k < kdim} A[anchor][k] B[k][col];  A = s_a[k][anchor] (LDS),
+// B[k][col] = Bm[k * sk + col * sc] (global, L1-resident; 0 for col >= ncols).  Both row tiles share the B operand, and the operands
+// of NG_U steps are fetched before the first product: with one wave per SIMD nothing else hides their latency.
+#define NG_U 4
+__device__ __forceinline__ void ng_gemm_pair(const float* __restrict__ s_a, const float* __restrict__ Bm, int sk, int sc, int col0, int ncols,
+                                             int kdim, ng_f16v& c0, ng_f16v& c1, int lane) {
+    const int u = lane & 31, half = lane >> 5;
+    const int col = col0 + u;
+    const bool colok = col < ncols;
+    const float* bp = Bm + col * sc;
+    const float* ap = s_a + u;
+#pragma unroll 1
+    for (int k0 = 0; k0 < kdim; k0 += 2 * NG_U) {
+        float a0[NG_U], a1[NG_U], b[NG_U];
+#pragma unroll
+        for (int j = 0; j < NG_U; j++) {
+            const int k = k0 + 2 * j + half;
+            const bool ok = k < kdim;
+            const int kc = ok ? k : 0;                                 // a row that exists; its b is 0
+            a0[j] = ap[kc * NG_LS]; a1[j] = ap[kc * NG_LS + 32];
+            b[j] = (colok && ok) ? bp[k * sk] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NG_U; j++) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], c1, 0, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ ng_f16v ng_splat(float v) {
+    ng_f16v c;
+#pragma unroll
+    for (int e = 0; e < 16; e++) c[e] = v;
+    return c;
+}
+// G1 / G2 of one MLP over the 64 anchors of the tile: g1a = G1 columns 0..31; g1n = the narrow columns 32..39 of ALL four MLPs in
+// one tile (MLP MM owns its columns 8 MM .. 8 MM + 7); g2[] = G2 row tiles
+template <int DOUT>
+__device__ __forceinline__ void ng_accumulate(const float* __restrict__ s_x, const float* __restrict__ s_h, const float* __restrict__ s_d1,
+                                              const float* __restrict__ s_d2, int MM, int lane, ng_f16v& g1a, ng_f16v& g1n, ng_f16v* __restrict__ g2) {
+    constexpr int MT = (DOUT + 31) / 32;
+    const int u = lane & 31, half = lane >> 5;
+    const bool mine = (u >> 3) == MM;
+#pragma unroll 1
+    for (int a0 = 0; a0 < NG_BLOCK; a0 += 2 * NG_U) {
+        float A1[NG_U], B0[NG_U], B1[NG_U], Bh[NG_U], A2[MT][NG_U];
+#pragma unroll
+        for (int j = 0; j < NG_U; j++) {
+            const int an = a0 + 2 * j + half;
+            A1[j] = s_d1[u * NG_LS + an];
+            B0[j] = s_x[u * NG_LS + an];
+            B1[j] = mine ? s_x[(32 + (u & 7)) * NG_LS + an] : 0.f;
+            Bh[j] = s_h[u * NG_LS + an];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) A2[mt][j] = mt * 32 + u < DOUT ? s_d2[(mt * 32 + u) * NG_LS + an] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NG_U; j++) {
+            g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B0[j], g1a, 0, 0, 0);
+            g1n = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], B1[j], g1n, 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) g2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[mt][j], Bh[j], g2[mt], 0, 0, 0);
+        }
+    }
+}
+// recompute of one MLP for the tile: s_h = relu(X W1^T + b1), s_y = H W2^T + b2  (s_y shares its rows with delta2)
+template <int DOUT>
+__device__ __forceinline__ void ng_mfma_recompute(const NgModel& m, int MM, const float* s_x, float* s_h, float* s_y, int lane) {
+    const int u = lane & 31;
+    const int din = m.din[MM];
+    const float b1 = m.b1[MM][u];
+    {
+        ng_f16v c0 = ng_splat(b1), c1 = c0;
+        ng_gemm_pair(s_x, m.W1[MM], 1, din, 0, NG_HID, din, c0, c1, lane);                              // B[k = q][t] = W1[t][q]
+#pragma unroll
+        for (int e = 0; e < 16; e++) { s_h[u * NG_LS + ng_crow(e, lane)] = fmaxf(c0[e], 0.f); s_h[u * NG_LS + 32 + ng_crow(e, lane)] = fmaxf(c1[e], 0.f); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NT = (DOUT + 31) / 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int o = nt * 32 + u;
+        const float b2 = o < DOUT ? m.b2[MM][o] : 0.f;
+        ng_f16v c0 = ng_splat(b2), c1 = c0;
+        ng_gemm_pair(s_h, m.W2T[MM], DOUT, 1, nt * 32, DOUT, NG_HID, c0, c1, lane);                     // B[k = t][o] = W2T[t][o]
+        if (o < DOUT) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) { s_y[o * NG_LS + ng_crow(e, lane)] = c0[e]; s_y[o * NG_LS + 32 + ng_crow(e, lane)] = c1[e]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// back-propagation of one MLP for the tile (delta2 is in s_d2): s_d1 = (D2 W2) * relu'(h);  dx tiles += D1 W1;  then the weight gradients
+template <int DOUT>
+__device__ __forceinline__ void ng_mfma_backprop(const NgModel& m, int MM, const float* s_x, const float* s_h, float* s_d1, const float* s_d2, int lane,
+                                                 ng_f16v (&dxa)[2][2], ng_f16v& g1a, ng_f16v& g1n, ng_f16v* g2) {
+    const int u = lane & 31;
+    const int din = m.din[MM];
+    __builtin_amdgcn_wave_barrier();
+    {
+        ng_f16v c0 = ng_splat(0.f), c1 = c0;
+        ng_gemm_pair(s_d2, m.W2[MM], NG_HID, 1, 0, NG_HID, DOUT, c0, c1, lane);                         // B[k = o][t] = W2[o][t]
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int i0 = u * NG_LS + ng_crow(e, lane), i1 = i0 + 32;
+            s_d1[i0] = s_h[i0] > 0.f ? c0[e] : 0.f;
+            s_d1[i1] = s_h[i1] > 0.f ? c1[e] : 0.f;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) ng_gemm_pair(s_d1, m.W1[MM], din, 1, nt * 32, din, NG_HID, dxa[0][nt], dxa[1][nt], lane);   // B[k = t][q] = W1[t][q]
+    ng_accumulate<DOUT>(s_x, s_h, s_d1, s_d2, MM, lane, g1a, g1n, g2);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the per-anchor stage of one of the three k-output MLPs (lane = anchor): y -> delta2, both through s_d2.  WHICH 0 = opacity (tanh),
+// 1 = colour, 2 = ray-drop (sigmoid)
+template <int K, int WHICH>
+__device__ __forceinline__ void ng_small_deltas(bool active, int i, size_t c, int lane, const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
+                                                const float* __restrict__ g_opacity, const float* __restrict__ g_color, const float* __restrict__ g_no,
+                                                float* s_d2, float* s_db2) {
+    constexpr int col0 = WHICH == 0 ? 0 : (WHICH == 1 ? 8 * K : 9 * K);          // layout [k | 7k | k | k] = opacity, cov, color, raydrop
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        float d = 0.f;
+        if (active) {
+            const float y = s_d2[j * NG_LS + lane];
+            const bool sel = sel_flags[(size_t)i * K + j] != 0u;
+            const size_t r = sel ? slot[(size_t)i * K + j] : 0;
+            float g = 0.f;
+            if (sel) g = WHICH == 0 ? g_opacity[r] : (WHICH == 1 ? g_color[2 * r] : g_color[2 * r + 1]);
+            if (WHICH == 0 && g_no) g += g_no[c * K + j];
+            if (WHICH == 0) { const float o = tanhf(y); d = g * (1.f - o * o); }
+            else { const float sg = ng_sigmoid(y); d = g * sg * (1.f - sg); }
+        }
+        s_d2[j * NG_LS + lane] = d;
+        const float sum = ng_wave_sum(d);
+        if (lane == 0) s_db2[col0 + j] += sum;
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(NG_BLOCK) k_ng_backward_mfma(int N, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
+                                                               const float* __restrict__ offset, const float* __restrict__ scaling,
+                                                               const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
+                                                               const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
+                                                               const float* __restrict__ g_xyz, const float* __restrict__ g_color, const float* __restrict__ g_opacity,
+                                                               const float* __restrict__ g_scaling, const float* __restrict__ g_rot, const float* __restrict__ g_no,
+                                                               float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_offset,
+                                                               float* __restrict__ d_scaling, float* __restrict__ partial) {
+    constexpr int NC = NG_COV_TILES(K), T2 = NG_G2_TILES(K);
+    constexpr int D2ROWS = 7 * K + 2;                                  // rows of y / delta2 (+ slack for an odd reduction length)
+    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS], s_d1[NG_HID * NG_LS], s_d2[D2ROWS * NG_LS], s_db2[128];
+    __shared__ uint32_t s_act[NG_BLOCK];
+    const int lane = threadIdx.x, u = lane & 31;
+    for (int q = lane; q < NG_XS * NG_LS; q += NG_BLOCK) s_x[q] = 0.f;         // nothing a product can meet is ever uninitialised
+    for (int q = lane; q < NG_HID * NG_LS; q += NG_BLOCK) { s_h[q] = 0.f; s_d1[q] = 0.f; }
+    for (int q = lane; q < D2ROWS * NG_LS; q += NG_BLOCK) s_d2[q] = 0.f;
+    s_db2[lane] = 0.f; s_db2[64 + lane] = 0.f;
+    ng_f16v g1[5], g2[T2];                                            // g1[0..3]: columns 0..31 of the four MLPs; g1[4]: their columns 32..39
+#pragma unroll
+    for (int t = 0; t < 5; t++) g1[t] = ng_splat(0.f);
+#pragma unroll
+    for (int t = 0; t < T2; t++) g2[t] = ng_splat(0.f);
+    const int ntiles = (N + NG_BLOCK - 1) / NG_BLOCK;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i = tile * NG_BLOCK + lane;
+        bool active = false;
+        size_t c = 0;
+        if (i < N) {
+            bool zero_dense = true;
+            if (vis_flags[i]) {
+                c = vis_idx[i];
+                bool any = g_no != nullptr;                            // with a gradient on neural_opacity every visible anchor has work
+#pragma unroll
+                for (int j = 0; j < K; j++) any = any || sel_flags[(size_t)i * K + j] != 0u;
+                active = any; zero_dense = !any;
+            }
+            if (zero_dense) {                                          // every row of the dense outputs is written
+                float* df = d_feat + (size_t)i * NG_FEAT;
+                float* dofs = d_offset + 3 * (size_t)i * K;
+                for (int q = 0; q < NG_FEAT; q++) df[q] = 0.f;
+                for (int q = 0; q < 3 * K; q++) dofs[q] = 0.f;
+                for (int q = 0; q < 3; q++) d_anchor[3 * (size_t)i + q] = 0.f;
+                for (int q = 0; q < 6; q++) d_scaling[6 * (size_t)i + q] = 0.f;
+            }
+        }
+        if (__ballot(active) == 0ull) continue;                        // nothing to fold in this tile
+        __builtin_amdgcn_wave_barrier();
+        s_act[lane] = active ? 1u : 0u;
+        float vx = 0.f, vy = 0.f, vz = 0.f, dist = 1.f;
+        {
+            float x[NG_IN];
+#pragma unroll
+            for (int q = 0; q < NG_IN; q++) x[q] = 0.f;
+            if (active) ng_input(feat, anchor, cam, i, x);
+#pragma unroll
+            for (int q = 0; q < NG_IN; q++) s_x[q * NG_LS + lane] = x[q];
+            s_x[36 * NG_LS + lane] = active ? 1.f : 0.f;               // the constant input: bias gradients fall out of the same product
+            if (active) { vx = x[32]; vy = x[33]; vz = x[34]; dist = x[35]; }
+        }
+        float ds[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, da[3] = {0.f, 0.f, 0.f};
+        ng_f16v dxa[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) dxa[a][b] = ng_splat(0.f);
+        __builtin_amdgcn_wave_barrier();
+
+        // --- covariance MLP: scaling = s[3:6] * sigmoid(sr[0:3]), rot = normalize(sr[3:7]); and the direct paths of xyz / scaling
+        ng_mfma_recompute<7 * K>(m, NG_COV, s_x, s_h, s_d2, lane);
+        {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
+            if (active) { const float* sc = scaling + 6 * (size_t)i; s0 = sc[0]; s1 = sc[1]; s2 = sc[2]; s3 = sc[3]; s4 = sc[4]; s5 = sc[5]; }
+            float* dofs = d_offset + 3 * (size_t)(active ? i : 0) * K;
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                float d[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (active) {
+                    float sr[7];
+#pragma unroll
+                    for (int q = 0; q < 7; q++) sr[q] = s_d2[(7 * j + q) * NG_LS + lane];
+                    const bool sel = sel_flags[(size_t)i * K + j] != 0u;
+                    const size_t r = sel ? slot[(size_t)i * K + j] : 0;
+                    float gx = 0.f, gy = 0.f, gz = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f, gr3 = 0.f;
+                    if (sel) {
+                        gx = g_xyz[3 * r]; gy = g_xyz[3 * r + 1]; gz = g_xyz[3 * r + 2];
+                        gs0 = g_scaling[3 * r]; gs1 = g_scaling[3 * r + 1]; gs2 = g_scaling[3 * r + 2];
+                        gr0 = g_rot[4 * r]; gr1 = g_rot[4 * r + 1]; gr2 = g_rot[4 * r + 2]; gr3 = g_rot[4 * r + 3];
+                    }
+                    const float* of = offset + 3 * ((size_t)i * K + j);
+                    const float o0 = of[0], o1 = of[1], o2 = of[2];
+                    dofs[3 * j] = gx * s0; dofs[3 * j + 1] = gy * s1; dofs[3 * j + 2] = gz * s2;
+                    ds[0] += gx * o0; ds[1] += gy * o1; ds[2] += gz * o2;
+                    da[0] += gx; da[1] += gy; da[2] += gz;
+                    const float g0 = ng_sigmoid(sr[0]), g1s = ng_sigmoid(sr[1]), g2s = ng_sigmoid(sr[2]);
+                    ds[3] += gs0 * g0; ds[4] += gs1 * g1s; ds[5] += gs2 * g2s;
+                    d[0] = gs0 * s3 * g0 * (1.f - g0); d[1] = gs1 * s4 * g1s * (1.f - g1s); d[2] = gs2 * s5 * g2s * (1.f - g2s);
+                    const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
+                    const float qn = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+                    const float r0 = q0 / qn, r1 = q1 / qn, r2 = q2 / qn, r3 = q3 / qn;
+                    const float dotp = gr0 * r0 + gr1 * r1 + gr2 * r2 + gr3 * r3;
+                    d[3] = (gr0 - r0 * dotp) / qn; d[4] = (gr1 - r1 * dotp) / qn; d[5] = (gr2 - r2 * dotp) / qn; d[6] = (gr3 - r3 * dotp) / qn;
+                }
+#pragma unroll
+                for (int q = 0; q < 7; q++) {
+                    s_d2[(7 * j + q) * NG_LS + lane] = d[q];
+                    const float sum = ng_wave_sum(d[q]);
+                    if (lane == 0) s_db2[K + 7 * j + q] += sum;
+                }
+            }
+        }
+        ng_mfma_backprop<7 * K>(m, NG_COV, s_x, s_h, s_d1, s_d2, lane, dxa, g1[NG_COV], g1[4], &g2[1]);
+        // --- opacity (tanh), colour and ray-drop (sigmoid) MLPs
+        ng_mfma_recompute<K>(m, NG_OPA, s_x, s_h, s_d2, lane);
+        ng_small_deltas<K, 0>(active, i, c, lane, sel_flags, slot, g_opacity, g_color, g_no, s_d2, s_db2);
+        ng_mfma_backprop<K>(m, NG_OPA, s_x, s_h, s_d1, s_d2, lane, dxa, g1[NG_OPA], g1[4], &g2[0]);
+        ng_mfma_recompute<K>(m, NG_COL, s_x, s_h, s_d2, lane);
+        ng_small_deltas<K, 1>(active, i, c, lane, sel_flags, slot, g_opacity, g_color, g_no, s_d2, s_db2);
+        ng_mfma_backprop<K>(m, NG_COL, s_x, s_h, s_d1, s_d2, lane, dxa, g1[NG_COL], g1[4], &g2[1 + NC]);
+        ng_mfma_recompute<K>(m, NG_RD, s_x, s_h, s_d2, lane);
+        ng_small_deltas<K, 2>(active, i, c, lane, sel_flags, slot, g_opacity, g_color, g_no, s_d2, s_db2);
+        ng_mfma_backprop<K>(m, NG_RD, s_x, s_h, s_d1, s_d2, lane, dxa, g1[NG_RD], g1[4], &g2[2 + NC]);
+
+        // --- input gradients: the feature part leaves in accumulator layout (a lane holds one column of 16 anchors: 128-byte
+        //     row segments); the view / distance part goes through LDS back to its anchor's lane
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int a = mt * 32 + ng_crow(e, lane);
+                if (s_act[a]) d_feat[(size_t)(tile * NG_BLOCK + a) * NG_FEAT + u] = dxa[mt][0][e];
+                if (u < 4) s_d1[u * NG_LS + a] = dxa[mt][1][e];
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            const float dx32 = s_d1[0 * NG_LS + lane], dx33 = s_d1[1 * NG_LS + lane], dx34 = s_d1[2 * NG_LS + lane], dx35 = s_d1[3 * NG_LS + lane];
+            const float dv = dx32 * vx + dx33 * vy + dx34 * vz;
+            da[0] += dx32 / dist - vx * (dv / dist) + dx35 * vx;
+            da[1] += dx33 / dist - vy * (dv / dist) + dx35 * vy;
+            da[2] += dx34 / dist - vz * (dv / dist) + dx35 * vz;
+#pragma unroll
+            for (int q = 0; q < 3; q++) d_anchor[3 * (size_t)i + q] = da[q];
+#pragma unroll
+            for (int q = 0; q < 6; q++) d_scaling[6 * (size_t)i + q] = ds[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // --- this wave's partial sums: tiles [t or o][q or t] as 32 x 32 blocks, then the output-layer bias sums
+    float* out = partial + (size_t)blockIdx.x * NG_PARTIAL_FLOATS(K);
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) out[t * 1024 + ng_crow(e, lane) * 32 + u] = g1[t][e];
+#pragma unroll
+    for (int t = 0; t < T2; t++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) out[(5 + t) * 1024 + ng_crow(e, lane) * 32 + u] = g2[t][e];
+    __builtin_amdgcn_wave_barrier();
+    out[(5 + T2) * 1024 + lane] = s_db2[lane]; out[(5 + T2) * 1024 + 64 + lane] = s_db2[64 + lane];
+}
+
 // ---- densification statistics (scene/gaussian_model.py:599-622) ------------------------------------------------------------
 // flags of the selected pairs in GLOBAL (anchor, offset) order, from the compact mask the decode returned
 __global__ void __launch_bounds__(256) k_ng_stats_flags(int N, int K, const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
@@ -453,6 +779,41 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
     NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, n_visible, m, cam, anchor_feat, anchor, offset,
                                         scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
                                         dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, act_x, act_h, delta1, delta2));
+    NG_HIP(hipGetLastError());
+    return 0;
+}
+
+static int ng_persistent_waves() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return 4 * cus;                                                    // one wave per SIMD
+}
+int lidargs_ng_backward_partials(int n_offsets, int* waves, int* floats_per_wave) {
+    const int k = n_offsets;
+    if (!(k == 4 || k == 5 || k == 6 || k == 8 || k == 10) || !waves || !floats_per_wave) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_partials: bad argument");
+    *waves = ng_persistent_waves();
+    *floats_per_wave = (5 + 3 + (7 * k + 31) / 32) * 1024 + 128;
+    return 0;
+}
+int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* anchor_feat, const float* anchor,
+                             const float* offset, const float* scaling, const float* cam_center,
+                             const float* dL_dxyz, const float* dL_dcolor, const float* dL_dopacity, const float* dL_dscaling,
+                             const float* dL_drot, const float* dL_dneural_opacity, float* dL_danchor_feat, float* dL_danchor, float* dL_doffset,
+                             float* dL_dscaling_in, float* partials, char* scratch, size_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    lg::NgModel m;
+    if (int rc = ng_model(model, &m)) return rc;
+    if (N <= 0) return 0;
+    if (!anchor_feat || !anchor || !offset || !scaling || !cam_center || !dL_danchor_feat || !dL_danchor || !dL_doffset || !dL_dscaling_in || !partials || !scratch)
+        return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_mfma: NULL pointer");
+    for (int q = 0; q < 4; q++) if (!m.W2T[q]) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_mfma: model.W2T (transposed second-layer weights) is required");
+    if (scratch_bytes < lidargs_ng_scratch_bytes(N, m.k)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_mfma: scratch too small");
+    lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)m.k, &s);
+    const float3 cam = make_float3(cam_center[0], cam_center[1], cam_center[2]);
+    const int waves = ng_persistent_waves();
+    NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward_mfma<K>, dim3(waves), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset,
+                                        scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
+                                        dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials));
     NG_HIP(hipGetLastError());
     return 0;
 }

@@ -9,6 +9,7 @@ Model configurations outside the native kernel's scope (feature bank, appearance
 hidden width != 32, n_offsets not in {4,5,6,8,10}) raise NotImplementedError: there is no silent framework fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -23,7 +24,8 @@ class _Model(C.Structure):
                 ("W1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("W2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("W2T", C.c_void_p * 4)]
 
 
-for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_ng_training_stats"):
+for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_ng_backward_mfma",
+           "lidargs_ng_backward_partials", "lidargs_ng_training_stats"):
     getattr(_lib, _n).restype = C.c_int
 _lib.lidargs_ng_scratch_bytes.restype = C.c_size_t
 
@@ -101,29 +103,56 @@ class _Decode(torch.autograd.Function):
         d_anchor = dense[o:o + N * 3].view(N, 3); o += N * 3
         d_offset = dense[o:o + N * 3 * k].view(N, k, 3); o += N * 3 * k
         d_scaling = dense[o:o + N * 6].view(N, 6)
-        act_x = torch.empty((n, 40), dtype=torch.float32, device=dev)
-        act_h = torch.empty((n, 132), dtype=torch.float32, device=dev)
-        delta1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
-        delta2 = torch.empty((n, 10 * k), dtype=torch.float32, device=dev)
         p = _base._ptr
-        if N:
-            with torch.cuda.device(dev):
-                _check(_lib.lidargs_ng_backward(C.c_int(N), C.c_int(n), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
-                                                p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
-                                                p(d_offset), p(d_scaling), p(act_x), p(act_h), p(delta1), p(delta2), p(scratch),
-                                                C.c_size_t(scratch.numel()), _base._stream(dev)), "lidargs_ng_backward")
-        # Weight and bias gradients: two [a x n] [n x b] reductions (library GEMMs, not a kernel of ours).  With n ~ 1e5..1e6 and
-        # a, b <= 132 a plain mm picks a one-tile kernel that walks all of n serially (0.5 ms each), so n is split into chunks:
-        # a batched GEMM of partial products plus a small sum.
-        def tn(a, b):
-            rows = a.shape[0]
-            if rows == 0:
-                return torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float32, device=dev)
-            S = max(1, min(512, rows // 512))
-            cut = (rows // S) * S
-            out = torch.bmm(a[:cut].view(S, cut // S, a.shape[1]).transpose(1, 2), b[:cut].view(S, cut // S, b.shape[1])).sum(0)
-            return out + a[cut:].t() @ b[cut:] if cut < rows else out
-        G1, G2 = tn(delta1, act_x), tn(delta2, act_h)                  # [128, 40], [10k, 132]
+        if os.environ.get("LIDARGS_NG_ACT_BUFFERS", "0") == "1":
+            # the older formulation: the kernel writes what two library GEMMs reduce (1.4 KB per visible anchor)
+            act_x = torch.empty((n, 40), dtype=torch.float32, device=dev)
+            act_h = torch.empty((n, 132), dtype=torch.float32, device=dev)
+            delta1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
+            delta2 = torch.empty((n, 10 * k), dtype=torch.float32, device=dev)
+            if N:
+                with torch.cuda.device(dev):
+                    _check(_lib.lidargs_ng_backward(C.c_int(N), C.c_int(n), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
+                                                    p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
+                                                    p(d_offset), p(d_scaling), p(act_x), p(act_h), p(delta1), p(delta2), p(scratch),
+                                                    C.c_size_t(scratch.numel()), _base._stream(dev)), "lidargs_ng_backward")
+            # With n ~ 1e5..1e6 and a, b <= 132 a plain mm picks a one-tile kernel that walks all of n serially (0.5 ms each), so n is
+            # split into chunks: a batched GEMM of partial products plus a small sum.
+            def tn(a, b):
+                rows = a.shape[0]
+                if rows == 0:
+                    return torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float32, device=dev)
+                S = max(1, min(512, rows // 512))
+                cut = (rows // S) * S
+                out = torch.bmm(a[:cut].view(S, cut // S, a.shape[1]).transpose(1, 2), b[:cut].view(S, cut // S, b.shape[1])).sum(0)
+                return out + a[cut:].t() @ b[cut:] if cut < rows else out
+            G1, G2 = tn(delta1, act_x), tn(delta2, act_h)              # [128, 40], [10k, 132]
+        else:
+            # everything matrix-shaped on the matrix pipe, weight gradients included: the persistent waves' partial sums come back,
+            # one row per wave
+            waves, per_wave = C.c_int(0), C.c_int(0)
+            _check(_lib.lidargs_ng_backward_partials(C.c_int(k), C.byref(waves), C.byref(per_wave)), "lidargs_ng_backward_partials")
+            partials = torch.empty((waves.value, per_wave.value), dtype=torch.float32, device=dev)
+            if N:
+                with torch.cuda.device(dev):
+                    _check(_lib.lidargs_ng_backward_mfma(C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
+                                                         p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
+                                                         p(d_offset), p(d_scaling), p(partials), p(scratch), C.c_size_t(scratch.numel()),
+                                                         _base._stream(dev)), "lidargs_ng_backward_mfma")
+                total = partials.sum(0)
+            else:
+                total = torch.zeros(per_wave.value, dtype=torch.float32, device=dev)
+            nc = (7 * k + 31) // 32
+            T = total[:(8 + nc) * 1024].view(8 + nc, 32, 32)
+            db2 = total[(8 + nc) * 1024:(8 + nc) * 1024 + 10 * k]
+            # the same [128, 40] / [10k, 132] tables the GEMM formulation produces, assembled from the tiles
+            G1 = torch.cat([torch.cat([T[i], T[4][:, 8 * i:8 * i + 8]], dim=1) for i in range(4)], dim=0)
+            G2 = torch.zeros((10 * k, 132), dtype=torch.float32, device=dev)
+            G2[0:k, 0:32] = T[5][:k]
+            G2[k:8 * k, 32:64] = T[6:6 + nc].reshape(nc * 32, 32)[:7 * k]
+            G2[8 * k:9 * k, 64:96] = T[6 + nc][:k]
+            G2[9 * k:10 * k, 96:128] = T[7 + nc][:k]
+            G2[:, 128] = db2
         cols = ((0, k), (k, 8 * k), (8 * k, 9 * k), (9 * k, 10 * k))
         dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
         g_params = []
