@@ -352,29 +352,33 @@ __device__ __forceinline__ float ng_wave_sum(float v) {
 // B[k][col] = Bm[k * sk + col * sc] (global, L1-resident; 0 for col >= ncols).  Both row tiles share the B operand, and the operands
 // of NG_U steps are fetched before the first product: with one wave per SIMD nothing else hides their latency.
 #define NG_U 4
+// The LDS arrays are padded to a multiple of 2 NG_U rows (zero-initialised, always finite), so the A reads need no guard; only B is
+// cut off at kdim (TAIL).  Pointers advance by one batch per trip and every operand sits at a fixed offset from them: no address
+// arithmetic between the products (it was half of the kernel's VALU instructions).
+template <bool TAIL>
 __device__ __forceinline__ void ng_gemm_pair(const float* __restrict__ s_a, const float* __restrict__ Bm, int sk, int sc, int col0, int ncols,
                                              int kdim, ng_f16v& c0, ng_f16v& c1, int lane) {
     const int u = lane & 31, half = lane >> 5;
     const int col = col0 + u;
     const bool colok = col < ncols;
-    const float* bp = Bm + col * sc;
-    const float* ap = s_a + u;
+    const float* bp = Bm + (colok ? col * sc : 0) + half * sk;
+    const float* ap = s_a + u + half * NG_LS;
+    const int sk2 = 2 * sk;
 #pragma unroll 1
     for (int k0 = 0; k0 < kdim; k0 += 2 * NG_U) {
         float a0[NG_U], a1[NG_U], b[NG_U];
 #pragma unroll
         for (int j = 0; j < NG_U; j++) {
-            const int k = k0 + 2 * j + half;
-            const bool ok = k < kdim;
-            const int kc = ok ? k : 0;                                 // a row that exists; its b is 0
-            a0[j] = ap[kc * NG_LS]; a1[j] = ap[kc * NG_LS + 32];
-            b[j] = (colok && ok) ? bp[k * sk] : 0.f;
+            a0[j] = ap[2 * j * NG_LS]; a1[j] = ap[2 * j * NG_LS + 32];
+            const bool ok = colok && (!TAIL || k0 + 2 * j + half < kdim);
+            b[j] = ok ? bp[j * sk2] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < NG_U; j++) {
             c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], c1, 0, 0, 0);
         }
+        ap += 2 * NG_U * NG_LS; bp += NG_U * sk2;
     }
 }
 __device__ __forceinline__ ng_f16v ng_splat(float v) {
@@ -391,18 +395,22 @@ __device__ __forceinline__ void ng_accumulate(const float* __restrict__ s_x, con
     constexpr int MT = (DOUT + 31) / 32;
     const int u = lane & 31, half = lane >> 5;
     const bool mine = (u >> 3) == MM;
+    const float* pd1 = s_d1 + u * NG_LS + half;
+    const float* px = s_x + u * NG_LS + half;
+    const float* pxn = s_x + (32 + (u & 7)) * NG_LS + half;
+    const float* ph = s_h + u * NG_LS + half;
+    const float* pd2 = s_d2 + u * NG_LS + half;
 #pragma unroll 1
     for (int a0 = 0; a0 < NG_BLOCK; a0 += 2 * NG_U) {
         float A1[NG_U], B0[NG_U], B1[NG_U], Bh[NG_U], A2[MT][NG_U];
 #pragma unroll
         for (int j = 0; j < NG_U; j++) {
-            const int an = a0 + 2 * j + half;
-            A1[j] = s_d1[u * NG_LS + an];
-            B0[j] = s_x[u * NG_LS + an];
-            B1[j] = mine ? s_x[(32 + (u & 7)) * NG_LS + an] : 0.f;
-            Bh[j] = s_h[u * NG_LS + an];
+            A1[j] = pd1[2 * j];
+            B0[j] = px[2 * j];
+            B1[j] = mine ? pxn[2 * j] : 0.f;
+            Bh[j] = ph[2 * j];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) A2[mt][j] = mt * 32 + u < DOUT ? s_d2[(mt * 32 + u) * NG_LS + an] : 0.f;
+            for (int mt = 0; mt < MT; mt++) A2[mt][j] = mt * 32 + u < DOUT ? pd2[mt * 32 * NG_LS + 2 * j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < NG_U; j++) {
@@ -411,6 +419,7 @@ __device__ __forceinline__ void ng_accumulate(const float* __restrict__ s_x, con
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) g2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[mt][j], Bh[j], g2[mt], 0, 0, 0);
         }
+        pd1 += 2 * NG_U; px += 2 * NG_U; pxn += 2 * NG_U; ph += 2 * NG_U; pd2 += 2 * NG_U;
     }
 }
 // recompute of one MLP for the tile: s_h = relu(X W1^T + b1), s_y = H W2^T + b2  (s_y shares its rows with delta2)
@@ -421,7 +430,7 @@ __device__ __forceinline__ void ng_mfma_recompute(const NgModel& m, int MM, cons
     const float b1 = m.b1[MM][u];
     {
         ng_f16v c0 = ng_splat(b1), c1 = c0;
-        ng_gemm_pair(s_x, m.W1[MM], 1, din, 0, NG_HID, din, c0, c1, lane);                              // B[k = q][t] = W1[t][q]
+        ng_gemm_pair<true>(s_x, m.W1[MM], 1, din, 0, NG_HID, din, c0, c1, lane);                              // B[k = q][t] = W1[t][q]
 #pragma unroll
         for (int e = 0; e < 16; e++) { s_h[u * NG_LS + ng_crow(e, lane)] = fmaxf(c0[e], 0.f); s_h[u * NG_LS + 32 + ng_crow(e, lane)] = fmaxf(c1[e], 0.f); }
     }
@@ -432,7 +441,7 @@ __device__ __forceinline__ void ng_mfma_recompute(const NgModel& m, int MM, cons
         const int o = nt * 32 + u;
         const float b2 = o < DOUT ? m.b2[MM][o] : 0.f;
         ng_f16v c0 = ng_splat(b2), c1 = c0;
-        ng_gemm_pair(s_h, m.W2T[MM], DOUT, 1, nt * 32, DOUT, NG_HID, c0, c1, lane);                     // B[k = t][o] = W2T[t][o]
+        ng_gemm_pair<false>(s_h, m.W2T[MM], DOUT, 1, nt * 32, DOUT, NG_HID, c0, c1, lane);                     // B[k = t][o] = W2T[t][o]
         if (o < DOUT) {
 #pragma unroll
             for (int e = 0; e < 16; e++) { s_y[o * NG_LS + ng_crow(e, lane)] = c0[e]; s_y[o * NG_LS + 32 + ng_crow(e, lane)] = c1[e]; }
@@ -449,7 +458,7 @@ __device__ __forceinline__ void ng_mfma_backprop(const NgModel& m, int MM, const
     __builtin_amdgcn_wave_barrier();
     {
         ng_f16v c0 = ng_splat(0.f), c1 = c0;
-        ng_gemm_pair(s_d2, m.W2[MM], NG_HID, 1, 0, NG_HID, DOUT, c0, c1, lane);                         // B[k = o][t] = W2[o][t]
+        ng_gemm_pair<(DOUT % (2 * NG_U)) != 0>(s_d2, m.W2[MM], NG_HID, 1, 0, NG_HID, DOUT, c0, c1, lane);                         // B[k = o][t] = W2[o][t]
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int i0 = u * NG_LS + ng_crow(e, lane), i1 = i0 + 32;
@@ -459,7 +468,7 @@ __device__ __forceinline__ void ng_mfma_backprop(const NgModel& m, int MM, const
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) ng_gemm_pair(s_d1, m.W1[MM], din, 1, nt * 32, din, NG_HID, dxa[0][nt], dxa[1][nt], lane);   // B[k = t][q] = W1[t][q]
+    for (int nt = 0; nt < 2; nt++) ng_gemm_pair<false>(s_d1, m.W1[MM], din, 1, nt * 32, din, NG_HID, dxa[0][nt], dxa[1][nt], lane);   // B[k = t][q] = W1[t][q]
     ng_accumulate<DOUT>(s_x, s_h, s_d1, s_d2, MM, lane, g1a, g1n, g2);
     __builtin_amdgcn_wave_barrier();
 }
@@ -500,7 +509,7 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward_mfma(int N, NgModel m,
                                                                float* __restrict__ d_feat, float* __restrict__ d_anchor, float* __restrict__ d_offset,
                                                                float* __restrict__ d_scaling, float* __restrict__ partial) {
     constexpr int NC = NG_COV_TILES(K), T2 = NG_G2_TILES(K);
-    constexpr int D2ROWS = 7 * K + 2;                                  // rows of y / delta2 (+ slack for an odd reduction length)
+    constexpr int D2ROWS = (7 * K + 2 * NG_U - 1) / (2 * NG_U) * (2 * NG_U);   // rows of y / delta2, padded to whole operand batches
     __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS], s_d1[NG_HID * NG_LS], s_d2[D2ROWS * NG_LS], s_db2[128];
     __shared__ uint32_t s_act[NG_BLOCK];
     const int lane = threadIdx.x, u = lane & 31;
