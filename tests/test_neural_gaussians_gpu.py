@@ -99,3 +99,16 @@ def test_decode_edge_cases(hip_lib_built):
     pc = build_pc(p); pc.use_feat_bank = True
     with pytest.raises(NotImplementedError):
         generate_neural_gaussians(types.SimpleNamespace(camera_center=torch.zeros(3).cuda(), uid=0), pc)
+
+
+def test_decode_gemm_fed_backward_still_matches(hip_lib_built, monkeypatch):
+    """The older backward (lidargs_ng_backward: per-anchor rows + two library GEMMs, LIDARGS_NG_ACT_BUFFERS=1) stays in the ABI:
+    same gradients as the matrix-pipe one and the golden case."""
+    monkeypatch.setenv("LIDARGS_NG_ACT_BUFFERS", "1")
+    p, cam, vis, exp = load_case("a")
+    ups = [exp["up_" + k] for k in ("xyz", "color", "opacity", "scaling", "rot")]
+    r = run_hip(p, cam, vis, ups)
+    for k in ("anchor_feat", "anchor", "offset", "scaling"):
+        parity("d" + k, r["g_" + k], exp["g_" + k])
+    for k in PARAM_KEYS:
+        parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4)
