@@ -660,6 +660,72 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward_mfma(int N, NgModel m,
     out[(5 + T2) * 1024 + lane] = s_db2[lane]; out[(5 + T2) * 1024 + 64 + lane] = s_db2[64 + lane];
 }
 
+// ---- decode on the matrix pipe -----------------------------------------------------------------------------------------------------
+// k_ng_decode with the three MLPs as tile products (ng_mfma_recompute, the backward's own recompute: the same f32 fma chains in
+// the same order, so the backward re-derives exactly the activations the forward used).  A wave = 64 anchors; its outputs are
+// read back per anchor from LDS for the post-processing, which is unchanged.
+template <int K>
+__global__ void __launch_bounds__(NG_BLOCK) k_ng_decode_mfma(int N, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
+                                                             const float* __restrict__ offset, const float* __restrict__ scaling,
+                                                             const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
+                                                             const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
+                                                             const float* __restrict__ neural_opacity, float* __restrict__ o_xyz, float* __restrict__ o_color,
+                                                             float* __restrict__ o_opacity, float* __restrict__ o_scaling, float* __restrict__ o_rot) {
+    constexpr int YROWS = (7 * K + 2 * NG_U - 1) / (2 * NG_U) * (2 * NG_U);
+    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS], s_y[YROWS * NG_LS];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * NG_BLOCK + lane;
+    bool active = false;
+    if (i < N && vis_flags[i]) {
+#pragma unroll
+        for (int j = 0; j < K; j++) active = active || sel_flags[(size_t)i * K + j] != 0u;
+    }
+    if (__ballot(active) == 0ull) return;
+    {
+        float x[NG_IN];
+#pragma unroll
+        for (int q = 0; q < NG_IN; q++) x[q] = 0.f;
+        if (active) ng_input(feat, anchor, cam, i, x);
+#pragma unroll
+        for (int q = 0; q < NG_IN; q++) s_x[q * NG_LS + lane] = x[q];
+#pragma unroll
+        for (int q = NG_IN; q < NG_XS; q++) s_x[q * NG_LS + lane] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float col[K], rd[K];
+    ng_mfma_recompute<K>(m, NG_COL, s_x, s_h, s_y, lane);
+#pragma unroll
+    for (int j = 0; j < K; j++) col[j] = s_y[j * NG_LS + lane];
+    __builtin_amdgcn_wave_barrier();
+    ng_mfma_recompute<K>(m, NG_RD, s_x, s_h, s_y, lane);
+#pragma unroll
+    for (int j = 0; j < K; j++) rd[j] = s_y[j * NG_LS + lane];
+    __builtin_amdgcn_wave_barrier();
+    ng_mfma_recompute<7 * K>(m, NG_COV, s_x, s_h, s_y, lane);
+    if (!active) return;
+    const float* sc = scaling + 6 * (size_t)i;
+    const float s0 = sc[0], s1 = sc[1], s2 = sc[2], s3 = sc[3], s4 = sc[4], s5 = sc[5];
+    const float ax = anchor[3 * (size_t)i], ay = anchor[3 * (size_t)i + 1], az = anchor[3 * (size_t)i + 2];
+    const size_t c = vis_idx[i];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (!sel_flags[(size_t)i * K + j]) continue;
+        const size_t r = slot[(size_t)i * K + j];
+        const float* of = offset + 3 * ((size_t)i * K + j);
+        o_xyz[3 * r] = ax + of[0] * s0; o_xyz[3 * r + 1] = ay + of[1] * s1; o_xyz[3 * r + 2] = az + of[2] * s2;      // :111-112
+        o_color[2 * r] = ng_sigmoid(col[j]); o_color[2 * r + 1] = ng_sigmoid(rd[j]);                                // :85-87
+        o_opacity[r] = neural_opacity[c * K + j];                                                                    // :71
+        float sr[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) sr[q] = s_y[(7 * j + q) * NG_LS + lane];
+        o_scaling[3 * r] = s3 * ng_sigmoid(sr[0]); o_scaling[3 * r + 1] = s4 * ng_sigmoid(sr[1]);                    // :107
+        o_scaling[3 * r + 2] = s5 * ng_sigmoid(sr[2]);
+        const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
+        const float qn = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);                               // F.normalize, :108
+        o_rot[4 * r] = q0 / qn; o_rot[4 * r + 1] = q1 / qn; o_rot[4 * r + 2] = q2 / qn; o_rot[4 * r + 3] = q3 / qn;
+    }
+}
+
 // ---- densification statistics (scene/gaussian_model.py:599-622) ------------------------------------------------------------
 // flags of the selected pairs in GLOBAL (anchor, offset) order, from the compact mask the decode returned
 __global__ void __launch_bounds__(256) k_ng_stats_flags(int N, int K, const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
@@ -762,8 +828,15 @@ int lidargs_ng_forward_decode(int N, const lidargs_ng_model* model, const float*
     if (scratch_bytes < lidargs_ng_scratch_bytes(N, m.k)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_forward_decode: scratch too small");
     lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)m.k, &s);
     const float3 cam = make_float3(cam_center[0], cam_center[1], cam_center[2]);
+    static const bool per_lane = [] { const char* e = getenv("LIDARGS_NG_PER_LANE_DECODE"); return e && atoi(e) != 0; }();
+    if (per_lane || !m.W2T[0] || !m.W2T[1] || !m.W2T[2] || !m.W2T[3]) {     // the matrix-pipe decode reads the transposed second-layer weights
     NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_decode<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset, scaling,
                                         s.vis_flags, s.vis_idx, s.sel_flags, s.slot, neural_opacity, out_xyz, out_color, out_opacity, out_scaling, out_rot));
+    } else {
+    NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_decode_mfma<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset, scaling,
+                                        s.vis_flags, s.vis_idx, s.sel_flags, s.slot, neural_opacity, out_xyz, out_color, out_opacity, out_scaling, out_rot));
+    }
+
     NG_HIP(hipGetLastError());
     return 0;
 }

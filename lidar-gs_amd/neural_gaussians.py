@@ -57,7 +57,9 @@ class _Decode(torch.autograd.Function):
         anchor_feat, anchor, offset, scaling = f32(anchor_feat), f32(anchor), f32(offset), f32(scaling)
         params = tuple(f32(p) for p in params)
         N, k = int(anchor.shape[0]), int(offset.shape[1])
-        model = _model_struct(k, flags, params)
+        # transposed second-layer weights: the B operand of Y = H W2^T on the matrix pipe (forward and backward)
+        w2t = tuple(params[4 * i + 2].t().contiguous() for i in range(4))
+        model = _model_struct(k, flags, params, w2t)
         nb = int(_lib.lidargs_ng_scratch_bytes(C.c_int(N), C.c_int(k)))
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         neural_opacity = torch.empty(max(N, 1) * k, dtype=torch.float32, device=dev)
@@ -77,7 +79,7 @@ class _Decode(torch.autograd.Function):
                 _check(_lib.lidargs_ng_forward_decode(C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
                                                       p(neural_opacity), p(xyz), p(color), p(opacity), p(scal), p(rot), p(scratch), C.c_size_t(nb),
                                                       _base._stream(dev)), "lidargs_ng_forward_decode")
-        ctx.save_for_backward(anchor_feat, anchor, offset, scaling, scratch, *params)
+        ctx.save_for_backward(anchor_feat, anchor, offset, scaling, scratch, *params, *w2t)
         ctx.meta = (N, k, n, M, tuple(float(c) for c in cam), tuple(bool(f) for f in flags))
         neural_opacity = neural_opacity[:n * k].view(n * k, 1)
         mask_b = mask[:n * k].view(torch.bool)
@@ -87,10 +89,9 @@ class _Decode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_xyz, g_color, g_opacity, g_scaling, g_rot, g_no, _g_mask):
         anchor_feat, anchor, offset, scaling, scratch = ctx.saved_tensors[:5]
-        params = ctx.saved_tensors[5:]
+        params, w2t = ctx.saved_tensors[5:21], ctx.saved_tensors[21:25]
         N, k, n, M, cam, flags = ctx.meta
         dev = anchor.device
-        w2t = [params[4 * i + 2].t().contiguous() for i in range(4)]        # the backward walks W2 by columns
         model = _model_struct(k, flags, params, w2t)
         camv = (C.c_float * 3)(*cam)
         f = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous()
