@@ -112,3 +112,16 @@ def test_decode_gemm_fed_backward_still_matches(hip_lib_built, monkeypatch):
         parity("d" + k, r["g_" + k], exp["g_" + k])
     for k in PARAM_KEYS:
         parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4)
+
+
+def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_built, monkeypatch):
+    """A caller of the C ABI that passes no W2T gets the one-anchor-per-lane decode (k_ng_decode): same outputs as the golden case
+    (forward only: the backward needs W2T)."""
+    import neural_gaussians as prod
+    real = prod._model_struct
+    monkeypatch.setattr(prod, "_model_struct", lambda k, flags, params, w2t=None: real(k, flags, params, None))
+    p, cam, vis, exp = load_case("a")
+    r = run_hip(p, cam, vis, None)
+    assert int((r["mask"] != exp["out_mask"]).sum()) == 0
+    for k in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
+        parity(k, r[k], exp["out_" + k])
