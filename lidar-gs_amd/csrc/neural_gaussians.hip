@@ -343,10 +343,18 @@ typedef float ng_f16v __attribute__((ext_vector_type(16)));
 #define NG_PARTIAL_FLOATS(K) ((5 + NG_G2_TILES(K)) * 1024 + 128)
 
 __device__ __forceinline__ int ng_crow(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }   // row of accumulator element e
+// wave-wide sum on the VALU alone: four DPP steps leave every 16-lane row holding its total, four lane reads add the rows (the
+// six-step bpermute butterfly went through the LDS crossbar, ~400 dependent cycles a sum, 60 sums per tile: 8 % of the kernel)
+template <int CTRL>
+__device__ __forceinline__ float ng_dpp(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
 __device__ __forceinline__ float ng_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += ng_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += ng_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += ng_dpp<0x141>(v);           // row_half_mirror
+    v += ng_dpp<0x140>(v);           // row_mirror
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
 }
 // c0 / c1 [32 anchors of tile 0 / 1][32 columns from col0] += sum_{k < kdim} A[anchor][k] B[k][col];  A = s_a[k][anchor] (LDS),
 // B[k][col] = Bm[k * sk + col * sc] (global, L1-resident; 0 for col >= ncols).  Both row tiles share the B operand, and the operands

@@ -146,14 +146,14 @@ class _Decode(torch.autograd.Function):
             nc = (7 * k + 31) // 32
             T = total[:(8 + nc) * 1024].view(8 + nc, 32, 32)
             db2 = total[(8 + nc) * 1024:(8 + nc) * 1024 + 10 * k]
-            # the same [128, 40] / [10k, 132] tables the GEMM formulation produces, assembled from the tiles
-            G1 = torch.cat([torch.cat([T[i], T[4][:, 8 * i:8 * i + 8]], dim=1) for i in range(4)], dim=0)
-            G2 = torch.zeros((10 * k, 132), dtype=torch.float32, device=dev)
-            G2[0:k, 0:32] = T[5][:k]
-            G2[k:8 * k, 32:64] = T[6:6 + nc].reshape(nc * 32, 32)[:7 * k]
-            G2[8 * k:9 * k, 64:96] = T[6 + nc][:k]
-            G2[9 * k:10 * k, 96:128] = T[7 + nc][:k]
-            G2[:, 128] = db2
+            dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
+            dW2 = (T[5][:k], T[6:6 + nc].reshape(nc * 32, 32)[:7 * k], T[6 + nc][:k], T[7 + nc][:k])      # views of the tiles
+            cols = ((0, k), (k, 8 * k), (8 * k, 9 * k), (9 * k, 10 * k))
+            g_params = []
+            for i in range(4):
+                dW1 = torch.cat([T[i], T[4][:, 8 * i:8 * i + dins[i] - 32]], dim=1)                        # columns 0..31 | 32..din-1
+                g_params += [dW1, T[4][:, 8 * i + 4], dW2[i], db2[cols[i][0]:cols[i][1]]]
+            return (d_feat, d_anchor, d_offset, d_scaling, *g_params, None, None, None)
         cols = ((0, k), (k, 8 * k), (8 * k, 9 * k), (9 * k, 10 * k))
         dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
         g_params = []
