@@ -28,7 +28,7 @@ SOURCES = {
     "neural_gaussians.hip": [],
     "lidar_loss.hip": [],
     "chamfer.hip": ["-ffp-contract=off"],        # the squared distance must round as the reference writes it: the argmin index is compared bit for bit
-    "surfel.hip": ["-ffp-contract=off"],   # ray/plane hit point cancels ~3 digits: round as the reference writes it
+    "surfel.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],   # ray/plane hit point cancels ~3 digits: round as the reference writes it
 }
 
 
