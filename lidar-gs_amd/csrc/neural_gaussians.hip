@@ -360,6 +360,31 @@ __device__ __forceinline__ float ng_wave_sum(float v) {
 // B[k][col] = Bm[k * sk + col * sc] (global, L1-resident; 0 for col >= ncols).  Both row tiles share the B operand, and the operands
 // of NG_U steps are fetched before the first product: with one wave per SIMD nothing else hides their latency.
 #define NG_U 4
+// Inputs of a 64-anchor tile into s_x[unit][anchor].  The 32 features of 64 consecutive anchors are 8 KB of contiguous memory:
+// eight 1-KB wave loads instead of every lane walking its own 128-byte row (64 lines per load instruction: 0.11 ms of the
+// backward at 666 k anchors); view direction and distance are per lane.  Anchors without work read as zeros.  Returns the lane's
+// (view, dist).
+__device__ __forceinline__ float4 ng_stage_inputs(const float* __restrict__ feat, const float* __restrict__ anchor, float3 cam, int tile, int N,
+                                                  bool active, const uint32_t* __restrict__ s_act, float* __restrict__ s_x, int lane) {
+    const float4* f4 = reinterpret_cast<const float4*>(feat) + (size_t)tile * (NG_BLOCK * NG_FEAT / 4);
+#pragma unroll
+    for (int it = 0; it < NG_FEAT / 4; it++) {
+        const int idx = it * NG_BLOCK + lane;
+        const int a = idx >> 3, qb = (idx & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile * NG_BLOCK + a < N && s_act[a]) v = f4[idx];
+        s_x[(qb + 0) * NG_LS + a] = v.x; s_x[(qb + 1) * NG_LS + a] = v.y; s_x[(qb + 2) * NG_LS + a] = v.z; s_x[(qb + 3) * NG_LS + a] = v.w;
+    }
+    float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        const size_t i = (size_t)tile * NG_BLOCK + lane;
+        const float ox = anchor[3 * i] - cam.x, oy = anchor[3 * i + 1] - cam.y, oz = anchor[3 * i + 2] - cam.z;
+        const float dist = sqrtf(ox * ox + oy * oy + oz * oz);
+        vd = make_float4(ox / dist, oy / dist, oz / dist, dist);
+    }
+    s_x[32 * NG_LS + lane] = vd.x; s_x[33 * NG_LS + lane] = vd.y; s_x[34 * NG_LS + lane] = vd.z; s_x[35 * NG_LS + lane] = vd.w;
+    return vd;
+}
 // The LDS arrays are padded to a multiple of 2 NG_U rows (zero-initialised, always finite), so the A reads need no guard; only B is
 // cut off at kdim (TAIL).  Pointers advance by one batch per trip and every operand sits at a fixed offset from them: no address
 // arithmetic between the products (it was half of the kernel's VALU instructions).
@@ -558,14 +583,10 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward_mfma(int N, NgModel m,
         s_act[lane] = active ? 1u : 0u;
         float vx = 0.f, vy = 0.f, vz = 0.f, dist = 1.f;
         {
-            float x[NG_IN];
-#pragma unroll
-            for (int q = 0; q < NG_IN; q++) x[q] = 0.f;
-            if (active) ng_input(feat, anchor, cam, i, x);
-#pragma unroll
-            for (int q = 0; q < NG_IN; q++) s_x[q * NG_LS + lane] = x[q];
+            __builtin_amdgcn_wave_barrier();
+            const float4 vd = ng_stage_inputs(feat, anchor, cam, tile, N, active, s_act, s_x, lane);
             s_x[36 * NG_LS + lane] = active ? 1.f : 0.f;               // the constant input: bias gradients fall out of the same product
-            if (active) { vx = x[32]; vy = x[33]; vz = x[34]; dist = x[35]; }
+            if (active) { vx = vd.x; vy = vd.y; vz = vd.z; dist = vd.w; }
         }
         float ds[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, da[3] = {0.f, 0.f, 0.f};
         ng_f16v dxa[2][2];
@@ -689,7 +710,7 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_decode_mfma(int N, NgModel m, f
         for (int j = 0; j < K; j++) active = active || sel_flags[(size_t)i * K + j] != 0u;
     }
     if (__ballot(active) == 0ull) return;
-    {
+    {   // per-lane rows here: with five waves per CU to hide them behind, the cooperative tile load of the backward measured slower
         float x[NG_IN];
 #pragma unroll
         for (int q = 0; q < NG_IN; q++) x[q] = 0.f;
