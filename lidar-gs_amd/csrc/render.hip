@@ -324,7 +324,7 @@ __device__ __forceinline__ float fold_halves16(float a, float b) {
 // Reduce-scatter of 16 per-lane values over the 64 lanes of a wave.  On return lane L owns, in v[0], the wave-wide sum of value slot
 //   id(L) = 8*bit5(L) + 4*bit4(L) + 2*bit0(L) + bit1(L)          (lanes that differ only in bits 2, 3 hold the same)
 // The two wide steps come first, when there are most values to fold: a lane swap + an add each, instead of two selects + a
-// cross-lane add.  lane ^ 1 and lane ^ 2 partners then come from DPP quad permutes, ^4 and ^8 (plain sums by then) from ds_swizzle.
+// cross-lane add.  lane ^ 1 and lane ^ 2 partners then come from DPP quad permutes, the sums over the row's quads from DPP row rotations.
 __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = fold_halves32(v[k], v[k + 8]);
@@ -343,8 +343,10 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
         const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
         v[0] = keep + xchg_xor2(send);
     }
-    v[0] += xchg_swz<4>(v[0]);
-    v[0] += xchg_swz<8>(v[0]);
+    // the four quads of a 16-lane row hold partial sums of the same slots: two row rotations (DPP, no LDS crossbar round trip on the
+    // entry's dependency chain) leave every lane with the row total
+    v[0] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x124, 0xF, 0xF, true));   // row_ror:4
+    v[0] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x128, 0xF, 0xF, true));   // row_ror:8
     return v[0];
 }
 
