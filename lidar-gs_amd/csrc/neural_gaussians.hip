@@ -755,6 +755,45 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_decode_mfma(int N, NgModel m, f
     }
 }
 
+// k_ng_opacity with its MLP as tile products (the same fma chains in the same order: the mask it decides is the per-lane kernel's)
+template <int K>
+__global__ void __launch_bounds__(NG_BLOCK) k_ng_opacity_mfma(int N, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
+                                                              const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
+                                                              float* __restrict__ neural_opacity, uint8_t* __restrict__ mask, uint32_t* __restrict__ sel_flags) {
+    constexpr int YROWS = (K + 2 * NG_U - 1) / (2 * NG_U) * (2 * NG_U);
+    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS], s_y[YROWS * NG_LS];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * NG_BLOCK + lane;
+    const bool vis = i < N && vis_flags[i] != 0u;
+    if (i < N && !vis) {
+#pragma unroll
+        for (int j = 0; j < K; j++) sel_flags[(size_t)i * K + j] = 0u;
+    }
+    if (__ballot(vis) == 0ull) return;
+    {
+        float x[NG_IN];
+#pragma unroll
+        for (int q = 0; q < NG_IN; q++) x[q] = 0.f;
+        if (vis) ng_input(feat, anchor, cam, i, x);
+#pragma unroll
+        for (int q = 0; q < NG_IN; q++) s_x[q * NG_LS + lane] = x[q];
+#pragma unroll
+        for (int q = NG_IN; q < NG_XS; q++) s_x[q * NG_LS + lane] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    ng_mfma_recompute<K>(m, NG_OPA, s_x, s_h, s_y, lane);
+    if (!vis) return;
+    const size_t c = vis_idx[i];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const float o = tanhf(s_y[j * NG_LS + lane]);                 // nn.Tanh closes the opacity MLP (gaussian_model.py:118)
+        neural_opacity[c * K + j] = o;
+        const bool keep = o > 0.0f;                                    // :67
+        mask[c * K + j] = keep ? 1 : 0;
+        sel_flags[(size_t)i * K + j] = keep ? 1u : 0u;
+    }
+}
+
 // ---- densification statistics (scene/gaussian_model.py:599-622) ------------------------------------------------------------
 // flags of the selected pairs in GLOBAL (anchor, offset) order, from the compact mask the decode returned
 __global__ void __launch_bounds__(256) k_ng_stats_flags(int N, int K, const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
@@ -834,8 +873,14 @@ int lidargs_ng_forward_select(int N, const lidargs_ng_model* model, const uint8_
     const float3 cam = make_float3(cam_center[0], cam_center[1], cam_center[2]);
     hipLaunchKernelGGL(lg::k_ng_visflags, dim3((N + 255) / 256), dim3(256), 0, stream, N, visible_mask, s.vis_flags);
     lg::launch_exclusive_scan(s.vis_flags, s.vis_idx, (size_t)N, s.totals, s.scan, stream);
-    NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_opacity<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, s.vis_flags,
-                                        s.vis_idx, neural_opacity, mask, s.sel_flags));
+    static const bool per_lane = [] { const char* e = getenv("LIDARGS_NG_PER_LANE_DECODE"); return e && atoi(e) != 0; }();
+    if (per_lane || !m.W2T[0]) {
+        NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_opacity<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, s.vis_flags,
+                                            s.vis_idx, neural_opacity, mask, s.sel_flags));
+    } else {
+        NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_opacity_mfma<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, s.vis_flags,
+                                            s.vis_idx, neural_opacity, mask, s.sel_flags));
+    }
     lg::launch_exclusive_scan(s.sel_flags, s.slot, (size_t)N * m.k, s.totals + 1, s.scan, stream);
     uint32_t tot[2] = {0, 0};
     NG_HIP(hipMemcpyAsync(tot, s.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
