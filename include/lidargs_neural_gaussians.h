@@ -25,8 +25,9 @@ extern "C" {
 #endif
 
 /* The four MLPs, in the order opacity, cov, color, raydrop.  Weights in nn.Linear layout: W1 [32][din], b1 [32],
- * W2 [dout][32], b2 [dout] with din = 35 + add_*_dist and dout = k, 7k, k, k.  W2T [32][dout] is W2 transposed: read by
- * lidargs_ng_backward only (rows of it are what the back-propagation through the second layer walks); may be NULL elsewhere. */
+ * W2 [dout][32], b2 [dout] with din = 35 + add_*_dist and dout = k, 7k, k, k.  W2T [32][dout] is W2 transposed: required by
+ * the backward entry points; the forward ones use it when given (their MLPs then run as tile products on the matrix pipe, with
+ * bit-identical results) and fall back to one anchor per lane when it is NULL. */
 typedef struct lidargs_ng_model {
     int n_offsets;
     int add_opacity_dist, add_cov_dist, add_color_dist;
