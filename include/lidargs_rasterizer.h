@@ -21,11 +21,17 @@
  *     prefiltered, tan_fov*) are accepted and ignored here too.
  *
  * The three scratch buffers are opaque: their layout, the meaning of the int returned by
- * lidargs_forward ("num_rendered" = number of (Gaussian, 16xTH-tile) instances this
- * implementation binned, NOT the reference's 16x1 count) and the per-pixel contributor
- * counts are private to this library and only consumed by lidargs_backward, exactly as
- * geomBuffer/binningBuffer/imgBuffer are private to the reference's backward
- * (R3/cr/rasterizer_impl.cu:469-471).
+ * lidargs_forward ("num_rendered") and the per-pixel contributor counts are private to this
+ * library and only consumed by lidargs_backward, exactly as geomBuffer/binningBuffer/imgBuffer
+ * are private to the reference's backward (R3/cr/rasterizer_impl.cu:469-471).
+ *   num_rendered = Rp | code: Rp = the number of (Gaussian, 16xTH-tile) instances this
+ *   implementation binned (NOT the reference's 16x1 count), rounded up to a multiple of 4;
+ *   code (low two bits) = log2(TH / 4), the tile height the forward chose for the frame.
+ * Like the reference's backward (`fromChunk` on (P, R, W*H)), lidargs_backward rebuilds its whole
+ * view of the buffers from (P, R, width, height) and the buffers' CONTENTS: nothing is keyed by a
+ * buffer's address and the library keeps no per-forward host state, so the saved buffers may be
+ * cloned, moved, offloaded and brought back before the backward runs, and a backward may run
+ * more than once on them (the "gradient lines still zero" mark is a word inside the geometry buffer).
  */
 #ifndef LIDARGS_RASTERIZER_H
 #define LIDARGS_RASTERIZER_H
@@ -234,7 +240,10 @@ int lidargs_backward_shell(
  * lidargs_shell_select compacts the Gaussians whose view-space range lies in [shell_lo, shell_hi) -- the same float test
  * lidargs_forward_shell applies -- into dense arrays, in ascending index order, so that a rank's frame runs on ~P/N rows.
  * idx_out i32[P] and the five out_* arrays have room for P rows; scratch holds lidargs_shell_select_scratch_bytes(P) bytes.
- * Returns the number of selected Gaussians (synchronises the stream) or a negative error code.
+ * Returns the number of selected Gaussians (one host read) or a negative error code.
+ * lidargs_shell_select_count / _gather are its two halves: count (flags + scan + the host read, result left in `scratch`) returns
+ * M, after which the caller allocates exactly M rows PER FRAME and gather fills them -- a forward's selection is saved for its
+ * backward and must not be overwritten by the next forward's (several views per step, gradient accumulation, an eval render).
  * lidargs_shell_transmittance: T_in[i] = prod_{g<rank} all_T[g*N+i].
  * lidargs_shell_compose folds the gathered per-shell planes (planes f32[G*5*N], per shell C0, C1, D, T_end, T_hand):
  * image = sum of partials (+ T_final * background), T_final = T_end of the first shell whose T_hand < 1e-4 (the last
@@ -244,6 +253,12 @@ int lidargs_shell_select(int P, const float* means3D, const float* colors, const
                          const float* rotations, const float* viewmatrix, float shell_lo, float shell_hi,
                          int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
                          float* out_rotations, char* scratch, size_t scratch_bytes, void* stream);
+int lidargs_shell_select_count(int P, const float* means3D, const float* viewmatrix, float shell_lo, float shell_hi,
+                               char* scratch, size_t scratch_bytes, void* stream);
+int lidargs_shell_select_gather(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                                const float* rotations, int* idx_out, float* out_means3D, float* out_colors,
+                                float* out_opacities, float* out_scales, float* out_rotations, char* scratch,
+                                size_t scratch_bytes, void* stream);
 int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, void* stream);
 int lidargs_shell_compose(int G, int rank, int N, const float* planes, const float* background, float* out_color,
                           float* out_depth, float* out_occ, float* T_final, float* behind, void* stream);

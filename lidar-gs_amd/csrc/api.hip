@@ -23,10 +23,10 @@ namespace {
 using lg::SegPlan;
 
 thread_local char g_err[512] = "";
-long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-const uint8_t* g_last_flags = nullptr; size_t g_last_flags_n = 0;
-uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals
-hipStream_t g_last_stream = nullptr;
+// diagnostics of the last forward ON THIS THREAD (lidargs_last_counters); never read by the compute path
+thread_local long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local const uint8_t* g_last_flags = nullptr; thread_local size_t g_last_flags_R = 0, g_last_flags_stride = 0; thread_local int g_last_flags_planes = 0;
+thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's spans
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -77,39 +77,15 @@ int choose_tile_rows(const unsigned long long (&inst)[3]) {
     return 4;
 }
 
-// The tile height a forward chose, for the calls that follow it on the same buffers (backward, shell phase 2): a host-side ring
-// keyed by the geometry buffer's address (the buffer cannot be asked without a device read).  4096 forwards may lie between a
-// forward and its backward before an entry is overwritten; a miss is an error, never a guess.
-struct ThEntry { const void* geom; int th; bool grads_zeroed; };
-constexpr unsigned TH_RING = 4096;
-std::mutex g_th_mutex;
-ThEntry g_th_ring[TH_RING];
-unsigned g_th_next = 0;
-void remember_tile_rows(const void* geom, int th, bool grads_zeroed) {
-    std::lock_guard<std::mutex> lk(g_th_mutex);
-    const unsigned last = (g_th_next + TH_RING - 1) % TH_RING;
-    if (g_th_ring[last].geom == geom) { g_th_ring[last].th = th; g_th_ring[last].grads_zeroed = grads_zeroed; return; }   // the training loop re-uses one allocation
-    g_th_ring[g_th_next] = ThEntry{geom, th, grads_zeroed};
-    g_th_next = (g_th_next + 1) % TH_RING;
-}
-int recall_tile_rows(const void* geom) {
-    std::lock_guard<std::mutex> lk(g_th_mutex);
-    for (unsigned k = 1; k <= TH_RING; k++) {                          // most recent first
-        const ThEntry& e = g_th_ring[(g_th_next + TH_RING - k) % TH_RING];
-        if (e.geom == geom && e.th) return e.th;
-    }
-    return 0;
-}
-// The forward zeroes the per-Gaussian gradient lines while the host waits for the instance count (the device would idle
-// there); the first backward on those buffers takes that over, a second one (retain_graph) has to zero them itself.
-bool take_zeroed_gradients(const void* geom) {
-    std::lock_guard<std::mutex> lk(g_th_mutex);
-    for (unsigned k = 1; k <= TH_RING; k++) {
-        ThEntry& e = g_th_ring[(g_th_next + TH_RING - k) % TH_RING];
-        if (e.geom == geom && e.th) { const bool z = e.grads_zeroed; e.grads_zeroed = false; return z; }
-    }
-    return false;
-}
+// What the backward (and a shell's phase 2) must know about the forward that made its buffers travels in the one value the
+// interface hands from one to the other, the `num_rendered` int (R3/rasterize_points.cu:123 -> :218; opaque to every caller):
+//     num_rendered = Rp | code,   Rp = instance count rounded up to a multiple of 4,  tile height = 4 << code  (4, 8, 16, 32)
+// Rp sizes and carves the binning buffer on both sides (the list itself has `ranges`), so nothing is looked up by buffer
+// address and cloned / offloaded / checkpointed saved buffers work (the backward rebuilds its view from (P, R, W*H)).
+// Whether the packed gradient lines of the geometry buffer are still all-zero is a word IN that buffer (LG_TOTALS_DIRTY_WORD).
+inline int encode_rendered(size_t R, int TH) { return (int)(((R + 3) & ~(size_t)3) | (size_t)(TH == 8 ? 1 : (TH == 16 ? 2 : (TH == 32 ? 3 : 0)))); }
+inline size_t rendered_capacity(int nr) { return (size_t)(nr & ~3); }
+inline int rendered_tile_rows(int nr) { return 4 << (nr & 3); }
 
 // One pinned 4-KB landing buffer and one event per host thread and device: the host waits for the copy alone, not for what
 // was queued behind it.
@@ -211,8 +187,9 @@ int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* 
     if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
     return (int)e;
 }
-void api_remember_forward(const void* geom, int tile_rows, bool grads_zeroed) { remember_tile_rows(geom, tile_rows, grads_zeroed); }
-bool api_take_zeroed_gradients(const void* geom) { return take_zeroed_gradients(geom); }
+int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }
+size_t api_rendered_capacity(int nr) { return rendered_capacity(nr); }
+int api_rendered_tile_rows(int nr) { return rendered_tile_rows(nr); }
 }  // namespace lg
 
 namespace {
@@ -324,21 +301,23 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     const int TH = choose_tile_rows(inst3);
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (unsigned long long)scan_total));
-    if (R64 > (unsigned long long)std::numeric_limits<int>::max()) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
+    if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
     const size_t R = (size_t)R64;
     if (TH != th_guess) {
         lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
     }
-    remember_tile_rows(geom_p, TH, true);
     t_last_th = TH;
     g_prof.mark("scan+readback", stream);
 
+    // everything a later call on these buffers derives (plan, carving, flag stride) comes from the returned int alone
+    const int rendered = encode_rendered(R, TH);
+    const size_t Rp = rendered_capacity(rendered);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const lg::SegPlan plan = plan_segments(R, grid.waves_per_tile, 0);
-    const int S = lg::choose_segments(R, plan.max_segments);
-    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, R, patches, grid.waves_per_tile, S, nullptr));
+    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
+    const int S = lg::choose_segments(Rp, plan.max_segments);
+    char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, Rp, patches, grid.waves_per_tile, S, nullptr));
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
-    lg::BinView bin; lg::bin_carve(bin_p, R, patches, grid.waves_per_tile, S, &bin);
+    lg::BinView bin; lg::bin_carve(bin_p, Rp, patches, grid.waves_per_tile, S, &bin);
 
     // 3. emit instances in range order, bin them by tile (stable)
     const uint32_t* point_list = bin.val_a;
@@ -367,7 +346,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
     ra.seg = bin.seg; ra.S = S; ra.seg_len = plan.seg_len;
     ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
-    ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = R;
+    ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = Rp;
     ra.transmittance_only = transmittance_pass;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
     if (ra.run_pass1) {
@@ -388,10 +367,9 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = (long long)R; g_counters[3] = -1; g_counters[4] = TH;
     g_counters[5] = grid.num_tiles();
     g_counters[6] = -1; g_counters[7] = S;
-    g_last_flags = ra.flags; g_last_flags_n = (size_t)grid.waves_per_tile * R;
+    g_last_flags = ra.flags; g_last_flags_R = R; g_last_flags_stride = Rp; g_last_flags_planes = grid.waves_per_tile;
     g_last_totals_dev = (uint32_t*)geom.spans;   // R_ref / V are reduced lazily in lidargs_last_counters (word 3 of each span)
-    g_last_stream = stream;
-    return (int)R;
+    return rendered;
 }
 
 int backward_impl(int P, int R, const float* background, int width, int height, const float* means3D,
@@ -412,17 +390,19 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: NULL required pointer%s");
 
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
-    const int TH = recall_tile_rows(geom_buffer);
-    if (!TH) return fail(LIDARGS_ERR_STATE, "backward: these buffers do not come from a forward of this library instance%s");
+    const int TH = rendered_tile_rows(R);                              // the forward's num_rendered carries its tile height
+    const size_t Rp = rendered_capacity(R);
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const lg::SegPlan plan = plan_segments((size_t)R, grid.waves_per_tile, 0);
-    const int S = lg::choose_segments((size_t)R, plan.max_segments);
-    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
+    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
+    const int S = lg::choose_segments(Rp, plan.max_segments);
+    lg::BinView bin; lg::bin_carve(binning_buffer, Rp, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     g_prof.begin(stream, 1);
 
-    if (!take_zeroed_gradients(geom_buffer)) LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
+    // The forward left the packed gradient lines zeroed; the first backward on these buffers marks them dirty (a word of the
+    // geometry buffer, set by k_gaussian_backward), and only a later one (retain_graph) finds the mark and clears them again.
+    lg::launch_zero_if_dirty(geom.totals + LG_TOTALS_DIRTY_WORD, geom.gacc, 16 * (size_t)P, stream);
     g_prof.mark("bwd_zero", stream);
 
     lg::RenderBwdArgs rb;
@@ -430,7 +410,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
     rb.seg = bin.seg; rb.S = S; rb.seg_len = plan.seg_len;
     rb.alive = pass1_gated(plan, S) ? bin.alive : nullptr;
-    rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = (size_t)R;
+    rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = Rp;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
     lg::launch_render_backward(rb, stream);
@@ -441,7 +421,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     gb.P = P; gb.scale_modifier = scale_modifier;
     gb.view = viewmatrix;
     gb.means3D = means3D; gb.scales = scales; gb.rotations = rotations; gb.cov3D_precomp = cov3D_precomp; gb.radii = radii;
-    gb.gacc = geom.gacc;
+    gb.gacc = geom.gacc; gb.dirty = geom.totals + LG_TOTALS_DIRTY_WORD;
     gb.dL_dmean2D = dL_dmean2D; gb.dL_dconic = dL_dconic; gb.dL_dopacity = dL_dopacity; gb.dL_dcolor = dL_dcolor;
     gb.dL_ddepths = dL_ddepths; gb.dL_dbasis_u1 = dL_dbasis_u1; gb.dL_dbasis_u2 = dL_dbasis_u2;
     gb.dL_dsphere = dL_dsphere_means3D; gb.dL_dmean3D = dL_dmean3D; gb.dL_dcov3D = dL_dcov3D; gb.dL_dscale = dL_dscale;
@@ -553,13 +533,13 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     hipStream_t stream = (hipStream_t)stream_;
     if (P <= 0 || R < 0 || !geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "render_shell: missing forward buffers%s");
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
-    const int TH = recall_tile_rows(geom_buffer);
-    if (!TH) return fail(LIDARGS_ERR_STATE, "render_shell: these buffers do not come from a forward of this library instance%s");
+    const int TH = rendered_tile_rows(R);
+    const size_t Rp = rendered_capacity(R);
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const lg::SegPlan plan = plan_segments((size_t)R, grid.waves_per_tile, 0);
-    const int S = lg::choose_segments((size_t)R, plan.max_segments);
-    lg::BinView bin; lg::bin_carve(binning_buffer, (size_t)R, patches, grid.waves_per_tile, S, &bin);
+    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
+    const int S = lg::choose_segments(Rp, plan.max_segments);
+    lg::BinView bin; lg::bin_carve(binning_buffer, Rp, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     lg::RenderFwdArgs ra;
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = bin.val_a; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
@@ -569,7 +549,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.seg = bin.seg; ra.S = S; ra.seg_len = plan.seg_len;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0;
     ra.alive = pass1_gated(plan, S) ? bin.alive : nullptr;        // written, like the flags, by the shell's phase 1
-    ra.flags = bin.flags; ra.R = (size_t)R;      // written by the shell's phase 1 (lidargs_forward_shell)
+    ra.flags = bin.flags; ra.R = Rp;             // written by the shell's phase 1 (lidargs_forward_shell)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
@@ -671,11 +651,13 @@ int lidargs_last_counters(long long* out, int n) {
         }
         free(h);
     }
-    if (g_counters[6] < 0 && g_last_flags && g_last_flags_n) {
-        uint8_t* h = (uint8_t*)malloc(g_last_flags_n);
-        if (h && hipMemcpy(h, g_last_flags, g_last_flags_n, hipMemcpyDeviceToHost) == hipSuccess) {
+    if (g_counters[6] < 0 && g_last_flags && g_last_flags_R) {
+        const size_t nbytes = g_last_flags_stride * (size_t)g_last_flags_planes;
+        uint8_t* h = (uint8_t*)malloc(nbytes);
+        if (h && hipMemcpy(h, g_last_flags, nbytes, hipMemcpyDeviceToHost) == hipSuccess) {
             long long c = 0;
-            for (size_t i = 0; i < g_last_flags_n; i++) c += h[i] != 0;
+            for (int pl = 0; pl < g_last_flags_planes; pl++)
+                for (size_t i = 0; i < g_last_flags_R; i++) c += h[(size_t)pl * g_last_flags_stride + i] != 0;
             g_counters[6] = c;
         }
         free(h);
@@ -690,15 +672,14 @@ size_t lidargs_shell_select_scratch_bytes(int P) {
     return sizeof(uint32_t) * (2 * n + lg::scan_scratch_words(n) + 64) + 256;
 }
 
-int lidargs_shell_select(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
-                         const float* viewmatrix, float shell_lo, float shell_hi, int* idx_out, float* out_means3D, float* out_colors,
-                         float* out_opacities, float* out_scales, float* out_rotations, char* scratch, size_t scratch_bytes, void* stream_) {
+// Two steps, so that the caller can allocate exactly M output rows per frame (the selection a forward saves for its backward must
+// not be overwritten by the next forward's): count = flags + scan + the one host read; gather = the dense copies.
+int lidargs_shell_select_count(int P, const float* means3D, const float* viewmatrix, float shell_lo, float shell_hi, char* scratch,
+                               size_t scratch_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: P < 0%s");
     if (P == 0) return 0;
-    if (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !idx_out || !out_means3D || !out_colors || !out_opacities ||
-        !out_scales || !out_rotations || !scratch)
-        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: NULL pointer%s");
+    if (!means3D || !viewmatrix || !scratch) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: NULL pointer%s");
     if (scratch_bytes < lidargs_shell_select_scratch_bytes(P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: scratch too small%s");
     lg::Carver c(scratch);
     uint32_t* flags = c.take<uint32_t>((size_t)P);
@@ -707,12 +688,38 @@ int lidargs_shell_select(int P, const float* means3D, const float* colors, const
     uint32_t* scan_scratch = c.take<uint32_t>(lg::scan_scratch_words((size_t)P));
     lg::launch_shell_flags(P, means3D, viewmatrix, shell_lo, shell_hi, flags, stream);
     lg::launch_exclusive_scan(flags, offs, (size_t)P, total, scan_scratch, stream);
+    uint32_t total_h = 0;
+    LG_HIP((hipError_t)lg::api_read_words_zero_behind(total, 1, &total_h, nullptr, 0, stream));
+    return (int)total_h;
+}
+
+int lidargs_shell_select_gather(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                                const float* rotations, int* idx_out, float* out_means3D, float* out_colors, float* out_opacities,
+                                float* out_scales, float* out_rotations, char* scratch, size_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: P < 0%s");
+    if (P == 0) return 0;
+    if (!means3D || !colors || !opacities || !scales || !rotations || !idx_out || !out_means3D || !out_colors || !out_opacities ||
+        !out_scales || !out_rotations || !scratch)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: NULL pointer%s");
+    if (scratch_bytes < lidargs_shell_select_scratch_bytes(P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: scratch too small%s");
+    lg::Carver c(scratch);
+    uint32_t* flags = c.take<uint32_t>((size_t)P);
+    uint32_t* offs = c.take<uint32_t>((size_t)P);
     lg::launch_shell_gather(P, flags, offs, means3D, colors, opacities, scales, rotations, idx_out, out_means3D, out_colors, out_opacities,
                             out_scales, out_rotations, stream);
-    uint32_t total_h = 0;
-    LG_HIP(hipMemcpyAsync(&total_h, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LG_HIP(hipStreamSynchronize(stream));
-    return (int)total_h;
+    return check_launch(stream, 0, "shell select gather");
+}
+
+// both steps in one call, into P-row arrays
+int lidargs_shell_select(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
+                         const float* viewmatrix, float shell_lo, float shell_hi, int* idx_out, float* out_means3D, float* out_colors,
+                         float* out_opacities, float* out_scales, float* out_rotations, char* scratch, size_t scratch_bytes, void* stream_) {
+    const int M = lidargs_shell_select_count(P, means3D, viewmatrix, shell_lo, shell_hi, scratch, scratch_bytes, stream_);
+    if (M <= 0) return M;
+    const int rc = lidargs_shell_select_gather(P, means3D, colors, opacities, scales, rotations, idx_out, out_means3D, out_colors, out_opacities,
+                                               out_scales, out_rotations, scratch, scratch_bytes, stream_);
+    return rc < 0 ? rc : M;
 }
 
 int lidargs_shell_pack_grad_rows(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors, const float* dL_dopacity,

@@ -76,6 +76,9 @@ inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 // instance counts for tile heights 4 / 8 / 16 + pad), one 32-byte slot per group of preprocess blocks
 #define LG_INST_SLOTS 64
 #define LG_TOTALS_SLOT_WORD 8
+// word 4 of the totals: 0 while the packed gradient lines (gacc) are all-zero as the forward left them, 1 once a backward has
+// accumulated into them (k_gaussian_backward sets it; a further backward on the same buffers then clears the lines first)
+#define LG_TOTALS_DIRTY_WORD 4
 #define LG_TOTALS_WORDS (LG_TOTALS_SLOT_WORD + 8 * LG_INST_SLOTS)
 struct GeomView {
     float4* rec;
@@ -85,7 +88,7 @@ struct GeomView {
     uint32_t* key_a; uint32_t* key_b;   // range keys ping/pong
     uint32_t* id_a; uint32_t* id_b;     // Gaussian ids ping/pong (id_sorted ends in id_a)
     uint32_t* block_off;                // [scan_blocks(P)] exclusive instance offset of each block of SCAN_BLOCK range-consecutive Gaussians
-    uint32_t* totals;                   // [0]=#instances, [1]=#visible, [2..3]=R_ref (u64)
+    uint32_t* totals;                   // [0]=#instances of the scan, [4]=gacc dirty flag, [8..] instance-total slots
     float* gacc;                        // [16P] packed per-Gaussian gradient accumulators (backward)
     uint32_t* scratch;                  // sort + scan scratch
     size_t scratch_words;
@@ -204,8 +207,12 @@ SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel);
 // Device -> host read of `n` (<= 1024) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
 // for the copy only.  Returns a hipError_t.
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s);
-void api_remember_forward(const void* geom, int tile_rows, bool grads_zeroed);
-bool api_take_zeroed_gradients(const void* geom);
+// num_rendered = instance capacity (multiple of 4) | tile-height code: all a later call on the forward's buffers needs (api.hip)
+int api_encode_rendered(size_t R, int TH);
+size_t api_rendered_capacity(int num_rendered);
+int api_rendered_tile_rows(int num_rendered);
+// clears `n` floats at `acc` if *dirty != 0 (device-side decision; a launch whose workgroups retire at once when it is clean)
+void launch_zero_if_dirty(const uint32_t* dirty, float* acc, size_t n, hipStream_t s);
 
 // kernels / launchers (defined in the .hip files)
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);
@@ -311,6 +318,7 @@ struct GaussBwdArgs {
     int P; float scale_modifier; const float* view;   // device pointer
     const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const int* radii;
     const float* gacc;             // packed sums from the backward blend
+    uint32_t* dirty;               // set to 1: gacc now holds sums (see LG_TOTALS_DIRTY_WORD)
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepths;
     float* dL_dbasis_u1; float* dL_dbasis_u2;
     float* dL_dsphere; float* dL_dmean3D; float* dL_dcov3D; float* dL_dscale; float* dL_drot;

@@ -11,6 +11,7 @@
 // t_i^T Sigma t_j with t_i = Rv^T u_i the world-space tangent directions (two symmetric
 // mat-vecs and three dots), and the backward is written as vector-Jacobian products.
 #include "lidargs_common.h"
+#include <algorithm>
 
 namespace lg {
 
@@ -358,6 +359,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view, unsigne
 //   gx*u1' + gy*u2' (R3/cr/backward.cu:759-777 sums exactly these per-pixel terms).
 __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && a.dirty) *a.dirty = 1u;                            // the packed lines now hold this backward's sums
     if (idx >= a.P) return;
     const float* vm = a.view;
 
@@ -504,6 +506,20 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
         gq[2] = 2.f * x * (F10 + F01) + 2.f * r * (F20 - F02) + 2.f * z * (F12 + F21) - 4.f * y * (F22 + F00);
         gq[3] = 2.f * r * (F01 - F10) + 2.f * x * (F20 + F02) + 2.f * y * (F12 + F21) - 4.f * z * (F11 + F00);
     }
+}
+
+// A second backward on the same forward buffers (retain_graph) must start from zeroed lines again; whether it is the second is
+// known on the device only (the dirty word travels with the buffer), so the decision is taken there: clean = every workgroup
+// reads one word and retires.
+__global__ void __launch_bounds__(256) k_zero_if_dirty(const uint32_t* __restrict__ dirty, float4* __restrict__ acc, size_t n4) {
+    if (*dirty == 0u) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) acc[i] = z;
+}
+void launch_zero_if_dirty(const uint32_t* dirty, float* acc, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;                                           // n is a multiple of 16
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 2048);
+    if (blocks) hipLaunchKernelGGL(k_zero_if_dirty, dim3(blocks), dim3(256), 0, s, dirty, reinterpret_cast<float4*>(acc), n4);
 }
 
 void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s) {

@@ -89,11 +89,13 @@ struct SfPreArgs {
     const float* means3D; const float* scales; const float* rotations; const float* opacities; const float* colors; const float* beams;
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
+    uint32_t* dirty;       // the geometry buffer's "gradient lines hold sums" word (LG_TOTALS_DIRTY_WORD): cleared here
 };
 
 template <bool FILTER>
 __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!FILTER && idx == 0 && a.dirty) *a.dirty = 0u;
     // the beam table is binary-searched five times per surfel: keep it in LDS when it fits (as k_preprocess does)
     constexpr int BEAMS_LDS = 1024;
     __shared__ float s_beams[BEAMS_LDS];
@@ -653,13 +655,14 @@ void launch_sf_render_backward(const SfBwdArgs& a, hipStream_t s) {
 struct SfGaussBwdArgs {
     int P, W, H;
     const float* view; const float* means3D; const float* scales; const float* rotations; const float* beams; const int* radii;
-    const float* gacc;
+    const float* gacc; uint32_t* dirty;
     float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D; float* dL_dtransMat;
     float* dL_dtransMat_2dtemp; float* dL_dscale; float* dL_drot; float* depth;
 };
 
 __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && a.dirty) *a.dirty = 1u;                            // the packed lines now hold this backward's sums
     if (idx >= a.P) return;
     if (!(a.radii[idx] > 0)) {                                         // every output row is written (zeros here)
         for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; }

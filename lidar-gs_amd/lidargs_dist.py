@@ -176,40 +176,48 @@ class HipShellBackend:
         from diff_lidargs_rasterization import _C
         self._C = _C
         self.lib = _C._lib
-        for name in ("lidargs_shell_select", "lidargs_shell_transmittance", "lidargs_shell_compose", "lidargs_shell_pack_grad_rows",
+        for name in ("lidargs_shell_select", "lidargs_shell_select_count", "lidargs_shell_select_gather", "lidargs_shell_transmittance", "lidargs_shell_compose", "lidargs_shell_pack_grad_rows",
                      "lidargs_shell_unpack_grad_rows", "lidargs_shell_chunk_counts", "lidargs_shell_scatter_radii"):
             getattr(self.lib, name).restype = C.c_int
         self.lib.lidargs_shell_select_scratch_bytes.restype = C.c_size_t
-        self._sel = {}              # persistent selection buffers per (device, P): no per-frame allocation
+        self._scratch = {}          # persistent scratch of the selection (flags + offsets) per (device, P); never saved for a backward
 
     def select(self, inp, lo, hi):
-        """Step 0: dense copies of the Gaussians with range in [lo, hi) + their indices (ascending)."""
+        """Step 0: dense copies of the Gaussians with range in [lo, hi) + their indices (ascending).
+
+        The M-row tensors are allocated PER CALL (caching allocator: no device malloc in steady state): a forward's selection
+        is saved for its backward, and a second forward before that backward (several views per step, gradient accumulation,
+        an eval render) must not overwrite it.  Only the flags/offsets scratch, dead when this returns, is persistent."""
         _C, lib = self._C, self.lib
         m3 = inp["means3D"]
         _C._require_device(m3, "means3D")
         dev, P = m3.device, int(m3.shape[0])
         key = (dev, P)
-        buf = self._sel.get(key)
-        if buf is None:
-            f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        scr = self._scratch.get(key)
+        if scr is None:
             nb = int(lib.lidargs_shell_select_scratch_bytes(C.c_int(P)))
-            buf = dict(idx=torch.empty(P, dtype=torch.int32, device=dev), means3D=f(P, 3), colors=f(P, 2), opacities=f(P, 1),
-                       scales=f(P, 3), rotations=f(P, 4), scratch=torch.empty(nb, dtype=torch.uint8, device=dev), nb=nb)
-            self._sel = {key: buf}
+            scr = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
+            self._scratch = {key: scr}
+        p = _C._ptr
         M = 0
         if P:
-            p = _C._ptr
             with torch.cuda.device(dev):
-                M = lib.lidargs_shell_select(C.c_int(P), p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), p(inp["rotations"]),
-                                             p(inp["viewmatrix"]), C.c_float(lo), C.c_float(hi), p(buf["idx"]), p(buf["means3D"]),
-                                             p(buf["colors"]), p(buf["opacities"]), p(buf["scales"]), p(buf["rotations"]), p(buf["scratch"]),
-                                             C.c_size_t(buf["nb"]), _C._stream(dev))
+                M = lib.lidargs_shell_select_count(C.c_int(P), p(m3), p(inp["viewmatrix"]), C.c_float(lo), C.c_float(hi), p(scr[0]),
+                                                   C.c_size_t(scr[1]), _C._stream(dev))
             if M < 0:
-                _C._raise(M, "lidargs_shell_select")
+                _C._raise(M, "lidargs_shell_select_count")
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        idx = torch.empty(M, dtype=torch.int32, device=dev)
         sel = dict(inp)
-        for k in ROW_KEYS:
-            sel[k] = buf[k][:M]
-        return buf["idx"][:M], sel
+        sel.update(means3D=f(M, 3), colors=f(M, 2), opacities=f(M, 1), scales=f(M, 3), rotations=f(M, 4))
+        if M:
+            with torch.cuda.device(dev):
+                rc = lib.lidargs_shell_select_gather(C.c_int(P), p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]),
+                                                     p(inp["rotations"]), p(idx), p(sel["means3D"]), p(sel["colors"]), p(sel["opacities"]),
+                                                     p(sel["scales"]), p(sel["rotations"]), p(scr[0]), C.c_size_t(scr[1]), _C._stream(dev))
+            if rc < 0:
+                _C._raise(rc, "lidargs_shell_select_gather")
+        return idx, sel
 
     def forward(self, inp, lo, hi):
         _C, lib = self._C, self.lib
@@ -385,7 +393,9 @@ def shell_forward(module, means3D, colors, opacities, scales, rotations):
         assert rows < (1 << 24)
         tail = torch.empty(comm.world, dtype=torch.float32, device=dev)
         be.chunk_counts(idx, rows, comm.world, tail)
-    st, T_pass = be.forward(sel, lo, hi)                                          # 1
+    # `sel` already holds exactly this shell's rows: the shell test is NOT repeated inside the forward (two kernels need not
+    # round the same range expression identically; a Gaussian one ulp from an edge could be selected here and culled there)
+    st, T_pass = be.forward(sel, float("-inf"), float("inf"))                     # 1
     radii = be.scatter_radii(idx, st["radii"], P)
     wait_radii = comm.all_reduce_async(radii) if comm.world > 1 else (lambda: None)   # overlaps the rendering
     allT = comm.all_gather(T_pass if tail is None else torch.cat([T_pass, tail]))  # 2   [G, N (+G)]

@@ -163,12 +163,22 @@ class _Decode(torch.autograd.Function):
         return (d_feat, d_anchor, d_offset, d_scaling, *g_params, None, None, None)
 
 
-def _linear_pair(seq, what):
+def _linear_pair(seq, what, head):
+    """Weights of one of the four MLPs after checking its WHOLE layout: the native decode hard-codes Linear(din, 32) - ReLU -
+    Linear(32, dout) followed by `head` (scene/gaussian_model.py:113-142: Tanh for opacity, none for cov, Sigmoid for colour and
+    ray-drop).  Anything else -- another activation, a missing head, an extra layer -- would decode and back-propagate silently
+    wrong, so it is refused like every other unsupported option."""
     import torch.nn as nn
-    lin = [m for m in seq if isinstance(m, nn.Linear)]
-    if len(lin) != 2 or lin[0].out_features != 32 or lin[1].in_features != 32:
-        raise NotImplementedError(f"neural_gaussians: unsupported {what} MLP (the native decode handles Linear(din,32)-ReLU-Linear(32,dout))")
-    return lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias
+    mods = list(seq)
+    want = [nn.Linear, nn.ReLU, nn.Linear] + ([head] if head is not None else [])
+    ok = len(mods) == len(want) and all(type(m) is w for m, w in zip(mods, want))
+    if ok:
+        ok = mods[0].out_features == 32 and mods[2].in_features == 32 and mods[0].bias is not None and mods[2].bias is not None
+    if not ok:
+        layout = "-".join(type(m).__name__ for m in mods)
+        raise NotImplementedError(f"neural_gaussians: unsupported {what} MLP [{layout}]: the native decode handles exactly "
+                                  f"Linear(din,32)-ReLU-Linear(32,dout){'-' + head.__name__ if head is not None else ''}")
+    return mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias
 
 
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
@@ -185,8 +195,9 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     k = int(pc.n_offsets)
     if k not in (4, 5, 6, 8, 10) or offset.shape[1] != k:
         raise NotImplementedError("neural_gaussians: n_offsets must be 4, 5, 6, 8 or 10")
-    params = (*_linear_pair(pc.get_opacity_mlp, "opacity"), *_linear_pair(pc.get_cov_mlp, "cov"),
-              *_linear_pair(pc.get_color_mlp, "color"), *_linear_pair(pc.get_raydrop_mlp, "raydrop"))
+    import torch.nn as nn
+    params = (*_linear_pair(pc.get_opacity_mlp, "opacity", nn.Tanh), *_linear_pair(pc.get_cov_mlp, "cov", None),
+              *_linear_pair(pc.get_color_mlp, "color", nn.Sigmoid), *_linear_pair(pc.get_raydrop_mlp, "raydrop", nn.Sigmoid))
     flags = (bool(pc.add_opacity_dist), bool(pc.add_cov_dist), bool(pc.add_color_dist))
     cam = viewpoint_camera.camera_center.detach().to("cpu", torch.float32).reshape(3).tolist()
     xyz, color, opacity, scal, rot, neural_opacity, mask = _Decode.apply(anchor_feat, anchor, offset, scaling, *params, cam, visible_mask, flags)

@@ -149,3 +149,25 @@ def test_surfel_package_mirrors_the_reference_interface(hip_lib_built):
         r(m3, m2, op, colors_precomp=torch.zeros(P, 2), scales=torch.ones(P, 2), rotations=torch.ones(P, 4))
     with pytest.raises(RuntimeError, match="HIP device"):
         r.visible_filter(m3, torch.ones(P, 2), torch.ones(P, 4))
+
+
+def test_decode_refuses_mlp_layouts_it_does_not_implement(hip_lib_built):
+    """The native anchor decode hard-codes Linear-ReLU-Linear + (Tanh | none | Sigmoid | Sigmoid): any other Sequential must be a
+    loud NotImplementedError before a kernel runs, never a silently different network."""
+    from torch import nn
+    import neural_gaussians as ng
+    good = nn.Sequential(nn.Linear(36, 32), nn.ReLU(True), nn.Linear(32, 6), nn.Tanh())
+    assert len(ng._linear_pair(good, "opacity", nn.Tanh)) == 4
+    assert len(ng._linear_pair(nn.Sequential(nn.Linear(36, 32), nn.ReLU(True), nn.Linear(32, 42)), "cov", None)) == 4
+    bad = [
+        (nn.Sequential(nn.Linear(36, 32), nn.ReLU(True), nn.Linear(32, 6), nn.Sigmoid()), nn.Tanh),       # wrong head
+        (nn.Sequential(nn.Linear(36, 32), nn.ReLU(True), nn.Linear(32, 6)), nn.Tanh),                     # head missing
+        (nn.Sequential(nn.Linear(36, 32), nn.LeakyReLU(), nn.Linear(32, 6), nn.Tanh()), nn.Tanh),         # wrong hidden activation
+        (nn.Sequential(nn.Linear(36, 32), nn.ReLU(True), nn.Linear(32, 42), nn.Tanh()), None),            # extra head on cov
+        (nn.Sequential(nn.Linear(36, 64), nn.ReLU(True), nn.Linear(64, 6), nn.Tanh()), nn.Tanh),          # hidden width
+        (nn.Sequential(nn.Linear(36, 32), nn.ReLU(True), nn.Linear(32, 32), nn.ReLU(True), nn.Linear(32, 6), nn.Tanh()), nn.Tanh),
+        (nn.Sequential(nn.Linear(36, 32, bias=False), nn.ReLU(True), nn.Linear(32, 6), nn.Tanh()), nn.Tanh),
+    ]
+    for seq, head in bad:
+        with pytest.raises(NotImplementedError, match="unsupported"):
+            ng._linear_pair(seq, "mlp", head)

@@ -245,3 +245,41 @@ def test_unused_outputs_have_no_gradient(hip_lib_built):
     zeros = torch.autograd.grad([color, depth, occ], inputs, [gc, torch.zeros_like(gd), torch.zeros_like(go)])
     for a, b in zip(only_color, zeros):
         parity("color-only backward", a.cpu().numpy(), b.cpu().numpy(), verbose=False)
+
+
+@pytest.mark.parametrize("how", ["clone", "save_on_cpu"])
+def test_backward_on_cloned_buffers(how, hip_lib_built):
+    """the backward rebuilds its view from (P, R, W*H) and the buffers' contents alone.  Every saved tensor
+    (the three opaque buffers included) is relocated between forward and backward -- cloned to a new address, or offloaded
+    to the host and brought back -- and the backward, run twice, must return what an undisturbed run returns.  Run at two
+    tile heights: the height the forward chose travels in `num_rendered`, not in a host table."""
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import to_torch, make_settings
+    for H, W, P, seed, mod in ((32, 500, 8000, 33, 1.0), (64, 600, 20000, 23, 6.0)):      # 4-row tiles / adaptive 8- or 16-row tiles
+        scene = sc.make_scene("street", P, H, seed, random_view=True)
+        st = to_torch(scene)
+        leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+        means2D = torch.zeros((P, 4), device="cuda", requires_grad=True)
+        rast = GaussianRasterizer(make_settings(st, W, H, scale_modifier=mod))
+        gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, seed))
+        call = lambda: rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                            scales=leaves["scales"], rotations=leaves["rotations"])
+        inputs = list(leaves.values()) + [means2D]
+        plain = torch.autograd.grad(list(call()[:3]), inputs, [gc, gd, go])
+        moved = []
+        if how == "clone":
+            def pack(t):
+                moved.append(t.data_ptr())
+                return t.clone()
+            hooks = torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t.clone())      # a fresh address at every unpack too
+        else:
+            hooks = torch.autograd.graph.save_on_cpu(pin_memory=False)
+        with hooks:
+            color, depth, occ, _ = call()
+        call()                                                # other forwards in between: nothing of theirs may leak in
+        first = torch.autograd.grad([color, depth, occ], inputs, [gc, gd, go], retain_graph=True)
+        second = torch.autograd.grad([color, depth, occ], inputs, [gc, gd, go])
+        for a, b, c in zip(plain, first, second):
+            parity("relocated buffers", b.cpu().numpy(), a.cpu().numpy(), verbose=False)
+            parity("relocated buffers, 2nd backward", c.cpu().numpy(), a.cpu().numpy(), verbose=False)
