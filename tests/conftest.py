@@ -35,3 +35,38 @@ def hip_lib_built():
     """Build the HIP library if needed (hipcc cross-compiles without a GPU)."""
     import build_hip
     return build_hip.build()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How much of the parity budget of tests/util.py the session really used: worst case per quantity over every parity() call
+    (HIP vs oracle).  Printed, and written to gpurun_out/parity_budget.json on the GPU box so that the numbers quoted in DESIGN.md
+    section 3 come from a file."""
+    try:
+        import util
+    except Exception:
+        return
+    log = [s for s in util.PARITY_LOG if s.get("n", 0) > 0]
+    if not log:
+        return
+    worst_p999 = max(log, key=lambda s: s["p999"])
+    worst_max = max(log, key=lambda s: s["max"])
+    worst_frac = max(log, key=lambda s: s["outlier_frac_used"])
+    with_out = [s for s in log if s["outliers"] > 0]
+    tr = terminalreporter
+    tr.write_sep("-", "parity budget used (tests/util.py: rtol 1e-4 with floor 1e-3 max|ref|)")
+    tr.write_line(f"parity() calls: {len(log)}; calls with any entry over rtol: {len(with_out)}")
+    tr.write_line(f"worst p99.9 : {worst_p999['p999']:.3e}  ({worst_p999['name']}, n={worst_p999['n']})")
+    tr.write_line(f"worst max   : {worst_max['max']:.3e}  ({worst_max['name']}, n={worst_max['n']}); cap {worst_max['outlier_max']:g}")
+    tr.write_line(f"worst outlier fraction: {worst_frac['outlier_frac_used']:.3e} = {worst_frac['outliers']} of {worst_frac['n']} "
+                  f"({worst_frac['name']}); allowed {worst_frac['allowed']}")
+    try:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out) or os.environ.get("GRAFT_REPO_ROOT"):
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "parity_budget.json"), "w") as f:
+                json.dump(dict(calls=len(log), calls_with_outliers=len(with_out), worst_p999=worst_p999, worst_max=worst_max,
+                               worst_outlier_fraction=worst_frac,
+                               over_rtol=[dict(name=s["name"], n=s["n"], outliers=s["outliers"], max=s["max"]) for s in with_out]), f, indent=1)
+    except Exception as e:      # the summary must never fail a run
+        tr.write_line(f"(parity_budget.json not written: {e})")

@@ -7,7 +7,11 @@ size-independent properties of the path plus a spot comparison against the oracl
   * background enters only as T_final * bg;
   * the colour gradient is the exact adjoint of the (linear) colour forward: <g, J d> == <dL/dcolors, d>;
   * every gradient finite; Gaussians with radii == 0 get exactly zero gradient rows;
-  * invariance to the internal tiling/segmentation knobs is covered at small size in test_parity_gpu.
+  * invariance to the internal tiling/segmentation knobs is covered at small size in test_parity_gpu;
+  * VALUE checks of the production code path (test_fullsize_wedge_matches_oracle): the FULL frame is rendered on the GPU -- so the
+    segment plan, slot count, gated pass-1 rounds, `alive` limits and the adaptive tile height are the ones the bench's
+    number comes from -- and the oracle renders every Gaussian that can reach an azimuth wedge of it; the wedge's pixels and
+    the gradients of the Gaussians whose whole footprint rect lies inside the wedge are compared value by value.
 """
 import numpy as np
 import pytest
@@ -104,3 +108,60 @@ def test_crop_of_fullsize_scene_matches_oracle(hip_lib_built):
     assert int((hip["radii"] != ref["radii"]).sum()) <= max(1, int(1e-4 * keep.sum()))
     for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
         parity(k, hip[k], ref[k])
+
+
+def _wedge_subset(scene, W, radii, c0, c1):
+    """Gaussians that can touch pixel columns [c0, c1): projected column within the Gaussian's own pixel radius (+ margin) of the
+    wedge.  `radii` = max(rx, ry) >= rx from the HIP forward; culled Gaussians (radii 0) are kept when within 64 columns, so that
+    a cull decision that flips between the two sides shows up as a radii mismatch instead of being hidden by the selection."""
+    vm = scene["viewmatrix"].astype(np.float64)
+    p = scene["means3D"].astype(np.float64) @ vm[:3, :3] + vm[3, :3]
+    pc = (np.pi - np.arctan2(p[:, 1], p[:, 0])) / (2 * np.pi / W)
+    reach = np.where(radii > 0, radii.astype(np.float64) + 32.0, 64.0)
+    return (pc >= c0 - reach) & (pc <= c1 + reach)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_fullsize_wedge_matches_oracle(cfg, hip_lib_built):
+    """The headline frame's own code path, value by value (see the module docstring).  cfg4 (8 M Gaussians @ 128 x 4096) runs at
+    the adaptive 16-row tile height; cfg2 / cfg3 on the fine segment plan (64-entry segments, 45 slots, gated first round)."""
+    from diff_lidargs_rasterization import _C
+    from util import GRAD_KEYS_SR, hip_forward_backward, oracle_forward_backward, parity
+    kind, P, H, W, seed = sc.BASELINE_CONFIGS[cfg]
+    scene = sc.make_scene(kind, P, H, seed)
+    grads = sc.upstream_grads(H, W, seed)
+    hip = hip_forward_backward(scene, W, H, grads)                    # the FULL frame
+    cnt = _C.last_counters()
+    print(f"[wedge] {cfg}: instances {cnt['instances']}, tile_rows {cnt['tile_rows']}, segment slots {cnt['segments']}, "
+          f"visible {int((hip['radii'] > 0).sum())}")
+    if cfg == "cfg4":
+        assert cnt["tile_rows"] == 16, cnt                            # the adaptive choice the bench line of this config runs with
+    else:
+        assert cnt["tile_rows"] == 4 and cnt["segments"] == 45, cnt   # the fine plan of api.hip plan_segments
+    half = 96 if cfg != "cfg4" else 64
+    # two wedges: looking down the street (long lists, early saturation) and at a wall / across the shell
+    for centre in (W // 2, W // 4 + 8):
+        c0 = (centre - half) // 16 * 16
+        c1 = c0 + 2 * half
+        keep = _wedge_subset(scene, W, hip["radii"], c0, c1)
+        sub = dict(scene)
+        for k in ("means3D", "scales", "rotations", "opacities", "colors"):
+            sub[k] = np.ascontiguousarray(scene[k][keep])
+        ref = oracle_forward_backward(sub, W, H, grads)
+        rows = np.nonzero(keep)[0]
+        mism = int((hip["radii"][rows] != ref["radii"]).sum())
+        print(f"[wedge] {cfg} columns [{c0},{c1}): {keep.sum()} Gaussians in reach, radii mismatches {mism}")
+        assert mism <= max(1, int(1e-4 * keep.sum()))
+        for k in ("color", "depth", "occ"):
+            parity(f"{cfg}.{k}[{c0}:{c1}]", hip[k][..., c0:c1], ref[k][..., c0:c1])
+        # Gaussians whose whole reference rect (R3/cr/auxiliary.h:80-92, 16-pixel tile columns) lies inside the wedge: every pixel
+        # that feeds their gradient was rendered by both sides from the same, complete, list
+        m2 = ref["fwd"].array("means2D").reshape(-1, 2)
+        rx = ref["fwd"].array("radii_xy").reshape(-1, 2)[:, 0].astype(np.float64)
+        x_lo = np.floor((m2[:, 0] - rx) / 16.0) * 16
+        x_hi = np.floor((m2[:, 0] + rx + 15.0) / 16.0) * 16
+        inside = (ref["radii"] > 0) & (hip["radii"][rows] > 0) & (x_lo >= c0) & (x_hi <= c1)
+        assert inside.sum() > 2000, inside.sum()
+        print(f"[wedge] {cfg} columns [{c0},{c1}): {int(inside.sum())} Gaussians with their whole rect inside")
+        for k in GRAD_KEYS_SR:
+            parity(f"{cfg}.{k}[wedge]", hip[k][rows[inside]], ref[k][inside])

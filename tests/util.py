@@ -15,6 +15,8 @@ RTOL = 1e-4
 FLOOR = 1e-3
 OUTLIER_FRAC = 2e-3
 OUTLIER_MAX = 5e-2
+# every parity() call of the session, for the "budget used" summary conftest.py prints and writes (gpurun_out/parity_budget.json)
+PARITY_LOG = []
 
 
 def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, outlier_frac=OUTLIER_FRAC, outlier_max=OUTLIER_MAX, verbose=True, scale=None):
@@ -34,6 +36,8 @@ def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, outlier_frac=OUTLIER_FRAC, ou
         print(f"[parity] {name:18s} n={ref.size:9d} scale={scale:.3e} median={stats['median']:.2e} "
               f"p99.9={stats['p999']:.2e} max={stats['max']:.2e} outliers(>{rtol:g})={nbad}")
     allowed = max(2, int(outlier_frac * ref.size))
+    stats.update(allowed=allowed, outlier_frac_used=nbad / ref.size, rtol=rtol, outlier_max=outlier_max)
+    PARITY_LOG.append(stats)
     assert nbad <= allowed, f"{name}: {nbad} of {ref.size} entries exceed rtol={rtol} (allowed {allowed}); max err {err.max():.3e}"
     assert err.max() <= outlier_max, f"{name}: largest error {err.max():.3e} exceeds the outlier cap {outlier_max}"
     return stats
