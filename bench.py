@@ -11,12 +11,14 @@ range shell across the ranks: RCCL all-gather of the per-shell transmittance pla
 W x H x 5 partial planes, reduce-scatter of the packed per-Gaussian gradient rows (lidargs_dist.py).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     for the dominant kernel (whichever of the forward blend K7 = 68*R_ref + 24*N bytes and the backward
-               blend K8 = 68*R_ref + 24*N + 84*V bytes takes longer; SURVEY.md 8d / DESIGN.md section 5):
-               ALGORITHMIC bytes per launch / mean duration measured with HIP events on the op's own stream
-               inside the timed region, vs 8 TB/s HBM; `traffic` = PMC bytes from the committed profile.
-  cpu_baseline the CPU oracle (oracle/lidargs_oracle.c, 1 thread) on a bounded sample of the same
-               workload, timed on this box's host cores.
+  roofline     for the longest single launch of the frame (k_render_backward on the headline workload): ALGORITHMIC bytes of
+               THAT launch in its own units -- 68 B per instance this frame binned (R') + 24 B per pixel + 84 B per visible
+               Gaussian, SURVEY.md 8d's K8 on R' -- / its mean duration from HIP events on the op's own stream inside the timed
+               region, vs 8 TB/s HBM (0 < frac <= 1 by construction); `traffic` = PMC bytes and `compute` = VALU issue rate from
+               the committed profile OF THE SAME WORKLOAD; `kernels` = the same for every other launch group of the frame;
+               `vs_reference_dataflow` = the reference data flow's bytes (on its R_ref 16x1 instances) against our frame time.
+  cpu_baseline the CPU oracle (oracle/lidargs_oracle.c) on a bounded sample of the same workload, timed on this box's host
+               cores: one thread, all cores (one frame per core), the numpy projector restatement, and K1 as torch-CPU ops.
 """
 import argparse
 import json
@@ -33,16 +35,54 @@ import numpy as np
 import torch
 
 STAGE_EVERY = 8           # frames between two frames whose stages are bracketed by HIP events
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32
+# vector = 64 flop/clk/SIMD = one PACKED fp32 fma wave-instruction per 4 clocks) -> 614.4 G wave-instructions/s
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 
 
-def algorithmic_bytes(P, V, R_ref, N, T):
-    """SURVEY.md 8d compact form; returns (fwd, bwd, K7 forward blend, K8 backward blend) bytes per frame."""
+def reference_dataflow_bytes(P, V, R_ref, N, T):
+    """SURVEY.md 8d compact form, priced on the REFERENCE's 16x1 instances (R_ref): (fwd, bwd, K7, K8) bytes per frame.  Not a
+    roofline for our launches (they process R' << R_ref instances); reported as `vs_reference_dataflow`."""
     fwd = 48 * P + 112 * V + 112 * R_ref + 8 * T + 24 * N
     bwd = 112 * P + 192 * V + 68 * R_ref + 24 * N
-    blend_fwd = 68 * R_ref + 24 * N               # record gather per reference instance + per-pixel outputs
-    blend_bwd = 68 * R_ref + 24 * N + 84 * V      # + raster gradients written once per visible Gaussian
-    return fwd, bwd, blend_fwd, blend_bwd
+    return fwd, bwd, 68 * R_ref + 24 * N, 68 * R_ref + 24 * N + 84 * V
+
+
+def raster_kernel_table(P, V, R, N, stages, surfel=False):
+    """ALGORITHMIC bytes of each launch in ITS OWN units: R = the instances this frame binned (R'),
+    V = visible Gaussians, N = pixels.  rec = bytes gathered per list entry (id 4 + record 64/80 + row span 4), pix = per-pixel
+    planes.  `stage` = the lidargs_profile stage that brackets the launch(es); `launches` = launches inside that stage."""
+    rec = 88 if surfel else 68                                  # 3-D: SURVEY 8d's 68 B/instance (id + 64-B record; the row span rides in it)
+    pix_f = 56 if surfel else 24                                # surfel: 2 + 7 output planes, 3 accum planes, 2 count planes
+    acc = 128 if surfel else 84                                 # per visible Gaussian: the raster-gradient line the backward blend fills
+    pin = 40 if surfel else 44
+    t = [
+        dict(kernel="k_sf_preprocess" if surfel else "k_preprocess", stage="preprocess", launches=1, bound="hbm",
+             bytes=(pin + 36) * P + (88 if surfel else 76) * V,
+             units=f"{pin} B in + 36 B (radii, radii_xy, key, id, spans) out per Gaussian, + record / row span / colours per visible one"),
+        dict(kernel="radix sort of the range keys (hist + prefix + scatter) x4", stage="range_sort", launches=12, bound="hbm",
+             bytes=4 * 20 * P, units="4 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per Gaussian"),
+        dict(kernel="forward blend group (reference K7): T-only walk x2 + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
+             launches=5, bound="hbm", bytes=rec * R + pix_f * N, units=f"{rec} B per binned instance + {pix_f} B per pixel (SURVEY 8d K7 on R')"),
+        dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
+             bytes=rec * R + pix_f * N + acc * V, units=f"{rec} B per binned instance + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on R')"),
+        dict(kernel="k_sf_gaussian_backward" if surfel else "k_gaussian_backward", stage="gaussian_bwd", launches=1, bound="hbm",
+             bytes=(pin + 4 + (108 if surfel else 92)) * P + (128 if surfel else 64) * V,
+             units="inputs + radii in, every returned gradient row out per Gaussian, + the packed gradient line per visible one"),
+    ]
+    ms = lambda st: sum(stages.get(x, (0.0, 0))[0] for x in (st if isinstance(st, tuple) else (st,)))
+    out = []
+    for k in t:
+        k = dict(k)
+        k["ms"] = ms(k["stage"])
+        if k["ms"] <= 0:
+            continue
+        k["achieved_GBs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        k["frac"] = k["achieved_GBs"] / HBM_PEAK_GBS
+        k["stage"] = "+".join(k["stage"]) if isinstance(k["stage"], tuple) else k["stage"]
+        out.append(k)
+    return out
 
 
 def clock_ramp(step, seconds=0.5, fixed_steps=None):
@@ -60,62 +100,159 @@ def clock_ramp(step, seconds=0.5, fixed_steps=None):
         torch.cuda.synchronize()
 
 
-def pmc_traffic(kernel_names):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), corrected as
-    MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950); None when no profile is committed."""
+def committed_profile(kind, workload):
+    """The newest committed profiles/*_pmc_<kind>*.json taken on THIS workload (its "workload" field; files of round 1 carry none
+    and were all taken on cfg3).  kind = "traffic" (FETCH_SIZE / WRITE_SIZE passes) or "sq" (SQ_* passes).  None if there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    k = json.load(open(files[-1]))["kernels"]
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}*.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("workload", "cfg3") == workload:
+            best = (f, j)
+    return best
+
+
+def pmc_lookup(kind, workload, kernel_names, field):
+    """Sum of `field` over (kernel, launches) pairs from the committed profile of this workload; (None, None) if any is missing."""
+    prof = committed_profile(kind, workload)
+    if prof is None:
+        return None, None
+    f, j = prof
     tot = 0
     for name in kernel_names:
         name, times = name if isinstance(name, tuple) else (name, 1)
-        if name not in k:
-            return None
-        tot += times * k[name]["hbm_bytes_per_launch_corrected"]
-    return tot
+        hit = [v for k, v in j["kernels"].items() if k == name or k.startswith(name + "<") or k == "void " + name]
+        if not hit or field not in hit[0]:
+            return None, os.path.basename(f)
+        tot += times * hit[0][field]
+    return tot, os.path.basename(f)
 
 
-def cpu_baseline(kind, P_full, H, W, seed, budget_s=20.0):
-    """Oracle (single thread) forward+backward on a P/20 sample of the workload, same image size."""
+def cpu_baseline(kind, P_full, H, W, seed, fwd_only=False, surfel=False, budget_s=24.0):
+    """The CPU legs of SURVEY 8d on this box's host cores, on a bounded 1/20 sample of the workload (same image size):
+      (1) the oracle (oracle/lidargs_oracle.c | lidargs_surfel_oracle.c), one thread -> `value`;
+      (1b) the same on ALL host cores, one independent frame per core (frames are independent, the C port is single-threaded);
+      (2) the reference's numpy per-point projector restated (oracle/range_view.py), one core -> projector_points_per_s;
+      (3) K1 as vectorised torch-CPU ops with torch.set_num_threads(nproc) (oracle/preprocess_torch.py)."""
     import lidargs_scenes as sc
-    from oracle import lgo
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import lgo, lgo_surfel
     lgo.build()
     P = max(1000, P_full // 20)
     scene = sc.make_scene(kind, P, H, seed)
-    grads = sc.upstream_grads(H, W, seed)
+    if surfel:
+        scene["scales"] = np.ascontiguousarray(scene["scales"][:, :2])
+        rng = np.random.default_rng(seed + 200)
+        grads = (rng.normal(size=(2, H, W)).astype(np.float32), rng.normal(size=(7, H, W)).astype(np.float32))
+    else:
+        grads = sc.upstream_grads(H, W, seed)
+
+    def frame():
+        if surfel:
+            f = lgo_surfel.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
+                                   scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"])
+            if not fwd_only:
+                lgo_surfel.backward(f, *grads)
+        else:
+            f = lgo.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
+                            scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"])
+            if not fwd_only:
+                lgo.backward(f, *grads)
+
     frames, t0 = 0, time.perf_counter()
     while True:
-        f = lgo.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
-                        scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"])
-        lgo.backward(f, *grads)
+        frame()
         frames += 1
         el = time.perf_counter() - t0
-        if el > budget_s * 0.5 or frames >= 8:
+        if el > budget_s * 0.25 or frames >= 8:
             break
     fps = frames / el
-    # baseline B2 (BASELINE.md): the reference's numpy per-point projector on one 64x2650 sweep's worth of points
-    from oracle import range_view
-    pts = np.concatenate([scene["means3D"][:20000], scene["colors"][:20000, :1]], 1)
+    # (1b) every host core, one frame each, twice (ctypes releases the GIL; the oracle keeps its state per handle)
+    cores = os.cpu_count() or 1
+    per_core = 2 if el / frames * 2 * 1.5 < budget_s * 0.4 else 1
     t1 = time.perf_counter()
-    range_view.points_to_pano(pts, H, W, scene["beams"])
-    pps = pts.shape[0] / (time.perf_counter() - t1)
-    return {
-        "projector_points_per_s": pps,
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda _i: [frame() for _ in range(per_core)], range(cores)))
+    el_all = time.perf_counter() - t1
+    fps_all = cores * per_core / el_all
+    what = "forward" if fwd_only else "fwd+bwd"
+    out = {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{frames} fwd+bwd frames of a {P}-Gaussian (1/20) {kind} scene at {H}x{W}, oracle/lidargs_oracle.c, "
-                  f"1 thread of {os.cpu_count()} host cores; linear-in-P estimate for the full workload: {fps * P / P_full:.4f} frames/s",
+        "sample": f"{frames} {what} frames of a {P}-{'surfel' if surfel else 'Gaussian'} (1/20) {kind} scene at {H}x{W}, "
+                  f"oracle/{'lidargs_surfel_oracle.c' if surfel else 'lidargs_oracle.c'}, 1 thread of {cores} host cores; linear-in-P "
+                  f"estimate for the full workload: {fps * P / P_full:.4f} frames/s",
+        "all_cores": {"value": fps_all, "unit": "frames/s", "cores": cores,
+                      "sample": f"{cores * per_core} independent {what} frames of the same 1/20 scene, one per host core at a time "
+                                f"({cores} threads, {per_core} each): {el_all:.1f} s; linear-in-P estimate for the full workload: "
+                                f"{fps_all * P / P_full:.3f} frames/s"},
     }
+    if not surfel:
+        # (2) baseline B2 (BASELINE.md): the reference's numpy per-point projector on one sweep's worth of points
+        from oracle import range_view
+        pts = np.concatenate([scene["means3D"][:20000], scene["colors"][:20000, :1]], 1)
+        t2 = time.perf_counter()
+        range_view.points_to_pano(pts, H, W, scene["beams"])
+        out["projector_points_per_s"] = pts.shape[0] / (time.perf_counter() - t2)
+        # (3) baseline B3: K1 as torch-CPU ops on all cores, at the FULL Gaussian count
+        from oracle import preprocess_torch as pt
+        full = sc.make_scene(kind, P_full, H, seed)
+        tt = {k: torch.from_numpy(full[k]) for k in ("means3D", "scales", "rotations", "viewmatrix", "beams")}
+        old = torch.get_num_threads()
+        torch.set_num_threads(cores)
+        try:
+            pt.preprocess(tt["means3D"], tt["scales"], tt["rotations"], tt["viewmatrix"], tt["beams"], W, H)      # warm
+            t3, reps = time.perf_counter(), 0
+            while time.perf_counter() - t3 < 3.0 and reps < 20:
+                pt.preprocess(tt["means3D"], tt["scales"], tt["rotations"], tt["viewmatrix"], tt["beams"], W, H)
+                reps += 1
+            out["torch_cpu_preprocess"] = {"ms": (time.perf_counter() - t3) / max(1, reps) * 1e3, "threads": cores,
+                                           "what": f"K1 of all {P_full} Gaussians as vectorised torch-CPU ops (oracle/preprocess_torch.py)"}
+        finally:
+            torch.set_num_threads(old)
+    return out
+
+
+def roofline_object(table, workload, blend_kernels_pmc, ref_flow=None):
+    """The contract's `roofline`: the launch with the longest mean duration (a single kernel, so that the rocprofv3 kernel-trace
+    CSV next to the bench line can be checked against it), priced on ITS OWN units; every other launch group in `kernels`."""
+    single = [k for k in table if k["launches"] == 1]
+    dom = max(single, key=lambda k: k["ms"])
+    roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac"], "algorithmic_bytes_per_launch": dom["bytes"], "kernel_ms": dom["ms"], "units": dom["units"],
+            "traffic": None, "traffic_GBs": None, "traffic_profile": None}
+    names = blend_kernels_pmc.get(dom["kernel"])
+    if names:
+        tr, src = pmc_lookup("traffic", workload, names, "hbm_bytes_per_launch_corrected")
+        roof["traffic"], roof["traffic_profile"] = tr, src
+        if tr:
+            roof["traffic_GBs"] = tr / (dom["ms"] * 1e-3) / 1e9
+        insts, src2 = pmc_lookup("sq", workload, names, "SQ_INSTS_VALU")
+        if insts:
+            g = insts / (dom["ms"] * 1e-3) / 1e9
+            roof["compute"] = {"bound": "valu-issue", "achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                               "frac": g / VALU_PEAK_GINST, "valu_insts_per_launch": insts, "profile": src2,
+                               "note": "SQ_INSTS_VALU of the committed profile / this run's launch time; peak = 256 CU x 4 SIMD x 2.4 GHz / 4 "
+                                       "clocks per wave64 instruction.  The nearer roof of the two is the one to read."}
+            if roof["compute"]["frac"] > roof["frac"]:
+                roof["nearer_roof"] = "valu-issue"
+            else:
+                roof["nearer_roof"] = "hbm"
+    roof["kernels"] = [{k2: (round(v, 5) if isinstance(v, float) else v) for k2, v in k.items()} for k in table]
+    if ref_flow is not None:
+        roof["vs_reference_dataflow"] = ref_flow
+    return roof
 
 
 def bench_surfel(args, sc, kind, P, H, W, seed):
     """BASELINE config 5: the 2DGS laser-surfel variant, single GPU, same metric (fwd+bwd frames/s); not the headline line."""
-    import numpy as np
     assert args.gpus == 1, "config 5 is a single-GPU configuration"
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU path"
     import build_hip
     build_hip.build()
+    from diff_lidargs_rasterization import _C as base_C
     from diff_lidargs_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = torch.device("cuda", 0)
     scene = sc.make_scene(kind, P, H, seed)
@@ -130,6 +267,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     rng = np.random.default_rng(seed + 200)
     gc = torch.from_numpy(rng.normal(size=(2, H, W)).astype(np.float32)).to(dev)
     go = torch.from_numpy(rng.normal(size=(7, H, W)).astype(np.float32)).to(dev)
+    info = {}
 
     def step():
         for t in list(leaves.values()) + [means2D]:
@@ -138,23 +276,139 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
                                           colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
         torch.autograd.backward([color, others], [gc, go])
         return radii
+    base_C.profile_enable(True)
     clock_ramp(step)
     for _ in range(args.warmup):
         radii = step()
     torch.cuda.synchronize()
+    base_C.profile_enable(STAGE_EVERY)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    print(json.dumps({
+    base_C.profile_enable(False)
+    stages = base_C.profile_summary()
+    V = int((radii > 0).sum())
+    info["R"] = int(base_C.last_counters()["instances"])
+    table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True)
+    pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess"],
+                 "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"]}
+    out = {
         "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cfg5: {P} surfels ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, diff_lidargs_surfel_rasterization "
                                f"(2DGS laser-surfel variant), lidar_far=80 lidar_near=0, bg=0",
-                   "visible_surfels": int((radii > 0).sum())},
-        "roofline": None, "cpu_baseline": None}))
+                   "visible_surfels": V, "instances_binned": info.get("R", 0), "tile_rows": 4},
+        "roofline": roofline_object(table, "cfg5", pmc_names),
+        "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
+        "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",
+        "clock_ramp": "0.5 s of untimed frames ran before the warm-up steps (first frames of a fresh process run 5-8 % slow)"}
+    out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(kind, P, H, W, seed, surfel=True)
+    print(json.dumps(out))
+
+
+def bench_render_fps(args):
+    """The reference's own FPS definition (train.py:408-414, :454): per view, between two device synchronisations,
+    prefilter_voxel (K2 visible_filter on the anchors, gaussian_renderer/__init__.py:252-257) + render (anchor decode + rasterizer
+    FORWARD), under no_grad.  FPS = 1 / mean(per-view seconds).  667 k anchors x 6 offsets of the 2 M-Gaussian street scene."""
+    import types
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    import lidargs_scenes as sc
+    from diff_lidargs_rasterization import GaussianRasterizer, _C
+    from neural_gaussians import generate_neural_gaussians
+    kind, P, H, W, seed = sc.BASELINE_CONFIGS["cfg3"]
+    N, k = 666_667, 6
+    scene = sc.make_scene(kind, N, H, seed)
+    p, _cam, _vis, rng = sc.make_anchor_model(N, k, seed)
+    p["anchor"] = scene["means3D"].astype(np.float32)
+    p["offset"] = (0.5 * rng.normal(size=(N, k, 3))).astype(np.float32)
+    p["scaling"] = np.concatenate([np.full((N, 3), 0.3, np.float32), scene["scales"].astype(np.float32) * 2.0], 1)
+    pc = sc.anchor_model_to_torch(p)
+    camera = types.SimpleNamespace(camera_center=torch.zeros(3).cuda(), uid=0)
+    st = {k_: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k_, v in scene.items() if k_ in ("viewmatrix", "beams", "bg")}
+    rast = GaussianRasterizer(sc.raster_settings(st, W, H))
+    anchor_rot = torch.from_numpy(scene["rotations"]).cuda()             # pc.get_rotation (unit quaternions per anchor)
+    info = {}
+
+    def view():
+        with torch.no_grad():
+            radii_pure = rast.visible_filter(means3D=pc.get_anchor, scales=pc.get_scaling[:, :3], rotations=anchor_rot, cov3D_precomp=None)
+            mask = radii_pure > 0                                        # prefilter_voxel
+            xyz, color, opacity, scaling, rot = generate_neural_gaussians(camera, pc, mask, is_training=False)
+            means2D = torch.zeros((xyz.shape[0], 4), device="cuda")
+            image, depth, occ, radii = rast(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color, scales=scaling, rotations=rot)
+        info.update(visible_anchors=mask, gaussians=xyz.shape[0], radii=radii)
+        return image
+
+    clock_ramp(view)
+    for _ in range(args.warmup):
+        view()
+    per = []
+    for _ in range(args.steps):                                           # the reference's own bracket: sync, t, work, sync, t
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        view()
+        torch.cuda.synchronize(); per.append(time.perf_counter() - t0)
+    mean_s = float(np.mean(per))
+    # back-to-back (no per-view synchronisation), for comparison with the other lines
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        view()
+    torch.cuda.synchronize()
+    piped = (time.perf_counter() - t0) / args.steps
+    # stage split of one view, events on the current stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(5):
+        with torch.no_grad():
+            ev[0].record()
+            mask = rast.visible_filter(means3D=pc.get_anchor, scales=pc.get_scaling[:, :3], rotations=anchor_rot, cov3D_precomp=None) > 0
+            ev[1].record()
+            xyz, color, opacity, scaling, rot = generate_neural_gaussians(camera, pc, mask, is_training=False)
+            ev[2].record()
+            rast(means3D=xyz, means2D=torch.zeros((xyz.shape[0], 4), device="cuda"), opacities=opacity, colors_precomp=color, scales=scaling, rotations=rot)
+            ev[3].record()
+        torch.cuda.synchronize()
+        for q in range(3):
+            acc[q] += ev[q].elapsed_time(ev[q + 1]) / 5
+    n_vis = int(info["visible_anchors"].sum())
+    # K2 is an HBM stream: 12 + 12 + 16 B in (anchor, first three scales of a 6-float row -> the whole 24-B row is fetched), 4 + 8 B out
+    k2_bytes = (12 + 24 + 16 + 12) * N
+    out = {"metric": "rendered range-view frames/sec (prefilter_voxel + decode + rasterize forward, the reference's FPS, train.py:408-414)",
+           "value": 1.0 / mean_s, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": mean_s * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"render_fps: {N} anchors x {k} offsets ({n_vis} anchors pass visible_filter) -> {info['gaussians']} Gaussians "
+                                  f"({int((info['radii'] > 0).sum())} on screen) @ {H}x{W}, no_grad, device synchronised around every view as the reference times it",
+                      "back_to_back_ms_per_view": piped * 1e3},
+           "stage_ms": {"visible_filter(K2)": acc[0], "generate_neural_gaussians": acc[1], "rasterize_forward": acc[2]},
+           "roofline": {"bound": "hbm", "kernel": "k_preprocess<FILTER> (reference K2 filter_preprocessCUDA, R3/cr/forward.cu:388-497)",
+                        "achieved": k2_bytes / (acc[0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": k2_bytes / (acc[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": k2_bytes, "kernel_ms": acc[0],
+                        "units": "64 B per anchor: mean 12 + the 24-B scaling row its three scales live in + quaternion 16 in, radii 4 + radii_xy 8 out",
+                        "traffic": None, "note": "stage time from events around the Python call (one launch + two fills); the other two stages have their own lines "
+                                                 "(--workload decode, --workload cfg2)"},
+           "clock_ramp": "0.5 s of untimed views ran before the warm-up steps"}
+    if not args.no_cpu_baseline:
+        from oracle import lgo
+        lgo.build()
+        Ns = N // 20
+        sm = sc.make_scene(kind, Ns, H, seed)
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 5.0 and reps < 20:
+            lgo.visible_filter(sm["means3D"], sm["scales"], sm["rotations"], sm["viewmatrix"], sm["beams"], W, H)
+            f = lgo.forward(sm["means3D"], sm["colors"], sm["opacities"], sm["scales"], sm["rotations"], sm["viewmatrix"], sm["beams"], W, H, bg=sm["bg"])
+            reps += 1
+        t = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": 1.0 / t, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} x (visible_filter + rasterizer forward) of a {Ns}-Gaussian (1/20) scene with oracle/lidargs_oracle.c, 1 thread of "
+                                         f"{os.cpu_count()} host cores (the decode is not in this leg: its CPU port is timed by --workload decode); "
+                                         f"linear-in-P estimate for the full workload: {1.0 / (t * 20):.4f} frames/s"}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
 
 
 def bench_decode(args):
@@ -416,7 +670,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--workload", default="cfg3",
+                    help="cfg3 (headline) | cfg2 (forward only, as BASELINE.json states it) | cfg4 | cfg5 | render_fps | decode | loss | train_step | chamfer")
+    ap.add_argument("--fwd-only", action="store_true", help="time the rasterizer forward alone (default for cfg2)")
+    ap.add_argument("--fwd-bwd", action="store_true", help="forward + backward also for cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -428,10 +685,13 @@ def main():
         return bench_train_step(args)
     if args.workload == "chamfer":
         return bench_chamfer(args)
+    if args.workload == "render_fps":
+        return bench_render_fps(args)
     import lidargs_scenes as sc
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[args.workload]
     if args.workload == "cfg5":
         return bench_surfel(args, sc, kind, P, H, W, seed)
+    fwd_only = (args.fwd_only or args.workload == "cfg2") and not args.fwd_bwd
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -448,6 +708,7 @@ def main():
         if force_shells:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert not fwd_only, "the sharded path is timed forward + backward"
 
     if rank == 0:
         import build_hip
@@ -463,18 +724,24 @@ def main():
     st = to_torch(scene, dev)
     gc, gd, go = (torch.from_numpy(g).to(dev) for g in sc.upstream_grads(H, W, seed))
     settings = make_settings(st, W, H)
-    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
-    means2D = torch.zeros((P, 4), dtype=torch.float32, device=dev, requires_grad=True)
+    leaves = {k: st[k].clone().requires_grad_(not fwd_only) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((P, 4), dtype=torch.float32, device=dev, requires_grad=not fwd_only)
 
     if world == 1 and not force_shells:
         rast = GaussianRasterizer(settings)
 
-        def step():
-            for t in list(leaves.values()) + [means2D]:
-                t.grad = None
-            color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
-                                            colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
-            torch.autograd.backward([color, depth, occ], [gc, gd, go])
+        if fwd_only:
+            def step():
+                with torch.no_grad():
+                    rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                         scales=leaves["scales"], rotations=leaves["rotations"])
+        else:
+            def step():
+                for t in list(leaves.values()) + [means2D]:
+                    t.grad = None
+                color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                                colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+                torch.autograd.backward([color, depth, occ], [gc, gd, go])
     else:
         import lidargs_dist
         comm = lidargs_dist.TorchDistComm()
@@ -555,45 +822,46 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         N_pix, T_ref = H * W, H * ((W + 15) // 16)
-        fwd_b, bwd_b, k7_b, k8_b = algorithmic_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
-        ms = lambda name: stages.get(name, (0.0, 0))[0]
-        k7_ms = ms("render_pass1") + ms("render_pass2") + ms("render_combine")
-        k8_ms = ms("render_bwd")
-        # the dominant kernel of the frame: the forward blend (3 launches: pass 1, pass 2, combine) or the backward blend
-        if k7_ms >= k8_ms:
-            dom, blend_b, blend_ms = "k_render_forward<T-only> x2 + k_render_alive + k_render_forward + k_render_combine (reference K7)", k7_b, k7_ms
-            # pass 1 runs as two gated rounds (two launches of the T-only kernel) with k_render_alive between them
-            traffic = pmc_traffic([("lg::k_render_forward<true>", 2), "lg::k_render_alive", "lg::k_render_forward<false>",
-                                   "lg::k_render_combine"])
-        else:
-            dom, blend_b, blend_ms = "k_render_backward (reference K8)", k8_b, k8_ms
-            traffic = pmc_traffic(["lg::k_render_backward"])
-        achieved = blend_b / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+        what = "forward only" if fwd_only else "fwd+bwd"
         out = {
-            "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s",
+            "metric": f"LiDAR range-view frames/sec ({what})", "value": args.steps / elapsed, "unit": "frames/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, "
+            "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, {what}, "
                                    f"lidar_far=80 lidar_near=0, bg=0",
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
-                       "tile_rows": cnt["tile_rows"], "sharding": "single GPU" if world == 1 else f"{world} range shells"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_GBs": (traffic / (blend_ms * 1e-3) / 1e9) if traffic and blend_ms > 0 else None,
-                         "note": "achieved = the reference data flow's bytes (SURVEY 8d formula) / measured time, so frac > 1 means the "
-                                 "frame beats what that data flow could do at HBM peak; the bytes this kernel really moves are "
-                                 "`traffic` (PMC, several times fewer: pruned instances, flagged entries, gated segments) and the "
-                                 "kernel is VALU-issue bound (DESIGN.md section 4)",
-                         "algorithmic_bytes_per_launch": blend_b, "kernel_ms": blend_ms,
-                         "frame_algorithmic_bytes": fwd_b + bwd_b,
-                         "frame_achieved_GBs": (fwd_b + bwd_b) / (ms_per_step * 1e-3) / 1e9},
+                       "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
+                       "sharding": "single GPU" if world == 1 else f"{world} range shells"},
+        }
+        if world == 1 and not force_shells:
+            # roofline: every launch (group) priced on what IT processes (R' = the instances this frame binned), the longest single
+            # launch on top; the reference data flow's bytes (R_ref 16x1 instances) against our time are kept apart, they are a
+            # speed-up statement, not a fraction of any roof
+            table = raster_kernel_table(P, cnt["V"], cnt["instances"], N_pix, stages)
+            fwd_b, bwd_b, _k7, _k8 = reference_dataflow_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
+            ref_bytes = fwd_b if fwd_only else fwd_b + bwd_b
+            ref_flow = {"frame_bytes_of_the_reference_dataflow": ref_bytes, "GBs_at_our_frame_time": ref_bytes / (ms_per_step * 1e-3) / 1e9,
+                        "note": "SURVEY 8d formula on R_ref (16x1 instances the reference would bin) / our frame time: above the 8000 GB/s "
+                                "peak means the frame is faster than that data flow could be at HBM speed; NOT a roofline fraction"}
+            pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
+                         "k_gaussian_backward": ["lg::k_gaussian_backward"]}
+            out["roofline"] = roofline_object(table, args.workload, pmc_names, ref_flow)
+            # the frame as a whole against the HBM roof, from the same per-launch units (+ what the table leaves out is small)
+            own = sum(k["bytes"] for k in table)
+            out["roofline"]["frame"] = {"algorithmic_bytes_of_the_listed_launches": own, "GBs": own / (ms_per_step * 1e-3) / 1e9,
+                                        "frac": own / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        else:
+            out["roofline"] = None
+        out.update({
             "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
             "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",
             "frame_ms_spread": spread,
             "hipmalloc_calls_in_timed_region": int(allocs1 - allocs0),
-        }
+            "clock_ramp": "0.5 s of untimed frames (300 frames when sharded) ran before the warm-up steps: the first frames of a fresh "
+                          "process run 5-8 % slower than steady state",
+        })
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kind, P, H, W, seed)
+            out["cpu_baseline"] = cpu_baseline(kind, P, H, W, seed, fwd_only=fwd_only)
         elif world == 1:
             out["cpu_baseline"] = None
         _flush_c_stdio()

@@ -187,6 +187,12 @@ int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* 
     if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
     return (int)e;
 }
+void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans) {   // diagnostics only (lidargs_last_counters)
+    g_counters[0] = P; g_counters[1] = -1; g_counters[2] = R; g_counters[3] = -1; g_counters[4] = TH; g_counters[5] = tiles;
+    g_counters[6] = 0; g_counters[7] = S;
+    g_last_flags = nullptr; g_last_flags_R = 0;
+    g_last_totals_dev = (uint32_t*)spans;
+}
 int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }
 size_t api_rendered_capacity(int nr) { return rendered_capacity(nr); }
 int api_rendered_tile_rows(int nr) { return rendered_tile_rows(nr); }
@@ -225,6 +231,12 @@ struct Profiler {
     }
 };
 Profiler g_prof;   // process-wide: autograd runs backward on its own thread
+}  // namespace
+namespace lg {
+void api_prof_begin(hipStream_t s, int kind) { g_prof.begin(s, kind); }
+void api_prof_mark(const char* name, hipStream_t s) { g_prof.mark(name, s); }
+}  // namespace lg
+namespace {
 
 struct Common {
     int P, W, H;

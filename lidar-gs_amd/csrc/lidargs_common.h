@@ -208,6 +208,10 @@ SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel);
 // for the copy only.  Returns a hipError_t.
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s);
 // num_rendered = instance capacity (multiple of 4) | tile-height code: all a later call on the forward's buffers needs (api.hip)
+// per-stage HIP-event timing (lidargs_profile_*): kind 0 = forward-like call, 1 = backward
+void api_prof_begin(hipStream_t s, int kind);
+void api_prof_mark(const char* name, hipStream_t s);
+void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans);
 int api_encode_rendered(size_t R, int TH);
 size_t api_rendered_capacity(int num_rendered);
 int api_rendered_tile_rows(int num_rendered);

@@ -257,3 +257,16 @@ def test_summation_order_band_of_the_gradients(cfg1):
         scale = np.abs(a[k]).max()
         err = np.abs(a[k] - b[k]) / (np.abs(a[k]) + 1e-3 * scale)
         assert err.max() < 1e-4, (k, err.max())
+
+
+def test_torch_cpu_preprocess_baseline_agrees_with_the_oracle():
+    """Baseline B3 (bench.py cpu_baseline.torch_cpu_preprocess): vectorised torch K1 must compute what the oracle's K1 computes."""
+    import torch
+    from oracle import preprocess_torch as pt
+    for kind, P, H, W, seed, rv in (("street", 20000, 64, 2650, 3, True), ("shell", 8000, 16, 512, 1, False)):
+        s = sc.make_scene(kind, P, H, seed, random_view=rv)
+        f = lgo.forward(s["means3D"], s["colors"], s["opacities"], s["scales"], s["rotations"], s["viewmatrix"], s["beams"], W, H)
+        t = torch.from_numpy
+        radii, tiles = pt.preprocess(t(s["means3D"]), t(s["scales"]), t(s["rotations"]), t(s["viewmatrix"]), t(s["beams"]), W, H)
+        assert (radii.numpy() == f.radii).mean() > 0.999
+        assert abs(int(tiles.sum()) - f.num_rendered) <= 1e-3 * f.num_rendered

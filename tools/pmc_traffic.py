@@ -1,6 +1,6 @@
 """Per-kernel HBM bytes per launch from two rocprofv3 PMC passes (rocpd .db files).
 
-    python tools/pmc_traffic.py <fetch.db> <write.db> "<command that was profiled>" > profiles/rNN_x_pmc_traffic.json
+    python tools/pmc_traffic.py <fetch.db> <write.db> "<command that was profiled>" [workload] > profiles/rNN_x_pmc_traffic_<workload>.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KB; 'corrected' doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950.
 Values of one dispatch are summed over counter instances first, then averaged over the dispatches of a kernel.
@@ -25,7 +25,8 @@ def per_kernel(path, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"command": sys.argv[3] if len(sys.argv) > 3 else "",
+res = {"workload": sys.argv[4] if len(sys.argv) > 4 else "cfg3",      # bench.py picks the profile of the workload it runs
+       "command": sys.argv[3] if len(sys.argv) > 3 else "",
        "note": "KB units as reported by rocprofv3; 'corrected' doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
                "(calibrated there on wide coalesced streams; the blend kernels issue 16-B-per-lane gathers, so treat the corrected read "
                "side as an upper bound). WRITE_SIZE is uncalibrated.",
