@@ -24,7 +24,7 @@ _ARRAYS = {
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lidargs_oracle.c", "lidargs_surfel_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("lidargs_oracle.c", "lidargs_surfel_oracle.c", "lgo_bench.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liblidargs_oracle.so"])
     return _SO
@@ -45,6 +45,8 @@ def lib():
         _lib.lgo_last_error.restype = C.c_char_p
         _lib.lgo_num_rendered.restype = C.c_int
         _lib.lgo_backward.restype = C.c_int
+        _lib.lgo_bench_frames.restype = C.c_double
+        _lib.sfo_num_rendered.restype = C.c_int
     return _lib
 
 
@@ -209,3 +211,18 @@ def mark_visible(means3D, viewmatrix):
     present = np.zeros(P, np.uint8)
     lib().lgo_mark_visible(C.c_int(P), _p(means3D), _p(vm), None, _p(present))
     return present.astype(bool)
+
+
+def bench_frames(scene, W, H, grads, threads, frames_each, fwd_only=False, surfel=False, far=80, near=0):
+    """Wall seconds for threads x frames_each frames rendered by `threads` POSIX threads (oracle/lgo_bench.c): the all-core
+    CPU baseline of bench.py.  grads = (colour, depth, occ) or, surfel, (colour, others)."""
+    a = {k: _f32(scene[k]) for k in ("bg", "means3D", "colors", "opacities", "scales", "rotations", "beams")}
+    vm = _f32(scene["viewmatrix"]).reshape(16)
+    g = [_f32(x).reshape(-1) for x in grads] + [None]
+    s = lib().lgo_bench_frames(C.c_int(int(surfel)), C.c_int(threads), C.c_int(frames_each), C.c_int(int(fwd_only)),
+                               C.c_int(a["means3D"].shape[0]), C.c_int(W), C.c_int(H), C.c_int(far), C.c_int(near), _p(a["bg"]), _p(a["means3D"]),
+                               _p(a["colors"]), _p(a["opacities"]), _p(a["scales"]), _p(a["rotations"]), _p(vm), _p(a["beams"]),
+                               _p(g[0]), _p(g[1]), _p(g[2]) if g[2] is not None else None)
+    if s < 0:
+        raise RuntimeError("lgo_bench_frames: a frame failed: " + lib().lgo_last_error().decode())
+    return float(s)

@@ -194,7 +194,7 @@ def test_random_small_scenes(seed, hip_lib_built):
     assert (hip["radii"] == ref["radii"]).mean() > 0.999
     small = H * W < 4000 or P < 200                       # tiny problems: the outlier budget is a count of 2, judge them absolutely
     for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
-        parity(k, hip[k], ref[k], outlier_frac=(5e-3 if small else 2e-3))
+        parity(k, hip[k], ref[k], outlier_frac=(5e-3 if small else 5e-4))
 
 
 def test_backward_twice_on_one_forward(hip_lib_built):

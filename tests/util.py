@@ -7,13 +7,19 @@ must be <= RTOL = 1e-4 for all but a tiny OUTLIER_FRAC of the entries.  The outl
 because the algorithm has hard thresholds (alpha < 1/255, power > 0, T < 1e-4, ceil/round of the
 footprint rect): an input that lands within one ulp of a threshold can legitimately fall on either
 side when exp/atan2/cos round differently (device libm vs host libm vs CUDA libdevice), and such a
-flip moves a pixel by up to ~0.4 %.  Outliers are counted, bounded in size, and reported.
+flip moves a pixel by up to ~1 % and a gradient row by more.  Outliers are counted, bounded in size, and reported.
+
+Budget vs use (GPU run r02_a, 741 parity() calls, gpurun_out/parity_budget.json; conftest.py prints the summary of every run):
+the rasterizer's worst call had 1.3e-4 of its entries over 1e-4 (8 of 60 000, a dense 64-beam case), the full-size wedge
+checks 0 (cfg2/3/4) to 1.0e-4 (surfel cfg5); the largest single error was 3.5e-2 (one threshold flip); p99.9 of the full-size
+wedges is <= 3e-6.  OUTLIER_FRAC is therefore 5e-4 (it was 2e-3), the cap stays at 5e-2.  For scale: two conforming
+evaluations of the reference itself differ by more (tests/test_ulp_band_cpu.py: 0.2-2.5 % of the gradient entries over 1e-4).
 """
 import numpy as np
 
 RTOL = 1e-4
 FLOOR = 1e-3
-OUTLIER_FRAC = 2e-3
+OUTLIER_FRAC = 5e-4
 OUTLIER_MAX = 5e-2
 # every parity() call of the session, for the "budget used" summary conftest.py prints and writes (gpurun_out/parity_budget.json)
 PARITY_LOG = []
