@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
                                                        const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks) {
     constexpr int BINS = 1 << BITS;
+    constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
     __shared__ uint32_t run[SORT_WAVES][BINS];   // per-wave running digit counts, then wave bases
     __shared__ uint32_t dbase[BINS];             // block-local start of each digit run
     __shared__ uint32_t gbase[BINS];             // global start of this block's run of each digit
@@ -206,18 +207,29 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
         v[r] = valid ? vals_in[i] : 0u;
     }
     // global digit bases: exclusive scan of the digit totals (every block repeats this tiny scan)
-    uint32_t my_tot = 0, my_hist = 0;
-    if (tid < BINS) {
-        my_tot = tot[tid]; my_hist = hist[(size_t)tid * nblocks + blockIdx.x];
-        if (part) my_hist += part[(size_t)tid * chunks + blockIdx.x / chunk];      // two-level cross-block prefix
-    }
     {
-        const uint32_t inc = wave_incl_scan(my_tot, lane);
+        uint32_t my_tot[PER], my_hist[PER], tsum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int d = tid * PER + q;
+            my_tot[q] = 0; my_hist[q] = 0;
+            if (d < BINS) {
+                my_tot[q] = tot[d]; my_hist[q] = hist[(size_t)d * nblocks + blockIdx.x];
+                if (part) my_hist[q] += part[(size_t)d * chunks + blockIdx.x / chunk];      // two-level cross-block prefix
+            }
+            tsum += my_tot[q];
+        }
+        const uint32_t inc = wave_incl_scan(tsum, lane);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
-        uint32_t off = 0;
+        uint32_t off = inc - tsum;
         for (int q = 0; q < w; q++) off += wsum[q];
-        if (tid < BINS) gbase[tid] = off + inc - my_tot + my_hist;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int d = tid * PER + q;
+            if (d < BINS) gbase[d] = off + my_hist[q];
+            off += my_tot[q];
+        }
     }
     for (int d = lane; d < BINS; d += 64) run[w][d] = 0;
     __syncthreads();
@@ -245,19 +257,29 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     __syncthreads();
 
     // B. block-local digit starts: digit-major, then wave-major inside a digit
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, dsum = 0;
-    if (tid < BINS) { c0 = run[0][tid]; c1 = run[1][tid]; c2 = run[2][tid]; c3 = run[3][tid]; dsum = c0 + c1 + c2 + c3; }
     {
-        const uint32_t inc = wave_incl_scan(dsum, lane);
-        __syncthreads();                       // wsum reuse
+        uint32_t c0[PER], c1[PER], c2[PER], c3[PER], tsum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int d = tid * PER + q;
+            c0[q] = c1[q] = c2[q] = c3[q] = 0;
+            if (d < BINS) { c0[q] = run[0][d]; c1[q] = run[1][d]; c2[q] = run[2][d]; c3[q] = run[3][d]; }
+            tsum += c0[q] + c1[q] + c2[q] + c3[q];
+        }
+        const uint32_t inc = wave_incl_scan(tsum, lane);
+        __syncthreads();                       // wsum reuse; every read of run[][] above is done
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
-        uint32_t off = 0;
-        for (int q = 0; q < w; q++) off += wsum[q];
-        if (tid < BINS) {
-            const uint32_t start = off + inc - dsum;
-            dbase[tid] = start;
-            run[0][tid] = start; run[1][tid] = start + c0; run[2][tid] = start + c0 + c1; run[3][tid] = start + c0 + c1 + c2;
+        uint32_t start = inc - tsum;
+        for (int q = 0; q < w; q++) start += wsum[q];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int d = tid * PER + q;
+            if (d < BINS) {
+                dbase[d] = start;
+                run[0][d] = start; run[1][d] = start + c0[q]; run[2][d] = start + c0[q] + c1[q]; run[3][d] = start + c0[q] + c1[q] + c2[q];
+            }
+            start += c0[q] + c1[q] + c2[q] + c3[q];
         }
     }
     __syncthreads();
@@ -285,12 +307,13 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 
 template <int BITS>
 static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, int shift,
-                       uint32_t* scratch, hipStream_t s) {
+                       uint32_t* scratch, hipStream_t s, int max_bits) {
+    const size_t SORT_MAX_BINS = (size_t)1 << max_bits;          // the scratch layout of sort_scratch_words(n, max_bits)
     const unsigned nb = (unsigned)sort_blocks(n);
     constexpr int BINS = 1 << BITS;
     uint32_t* hist = scratch;
-    uint32_t* tot = scratch + (size_t)SORT_BINS * nb;
-    uint32_t* part = tot + SORT_BINS;
+    uint32_t* tot = scratch + (size_t)SORT_MAX_BINS * nb;
+    uint32_t* part = tot + SORT_MAX_BINS;
     const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
     const bool two_level = chunks_all > 2;
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
@@ -307,26 +330,30 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s) {
+                            uint32_t* scratch, hipStream_t s, int max_bits) {
     if (n == 0 || end_bit <= 0) return 0;
+    if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
     int cur = 0;
     int shift = 0;
     while (shift < end_bit) {
         const int left = end_bit - shift;
         uint32_t* kin = cur ? key_b : key_a; uint32_t* vin = cur ? val_b : val_a;
         uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
-        // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4)
-        const int passes_left = (left + SORT_RADIX_BITS - 1) / SORT_RADIX_BITS;
+        // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4; 31 bits at 11 -> 11+10+10)
+        const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
         switch (bits) {
-            case 1: radix_pass<1>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            case 2: radix_pass<2>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            case 3: radix_pass<3>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            case 4: radix_pass<4>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            case 5: radix_pass<5>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            case 6: radix_pass<6>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            case 7: radix_pass<7>(kin, vin, kout, vout, n, shift, scratch, s); break;
-            default: radix_pass<8>(kin, vin, kout, vout, n, shift, scratch, s); break;
+            case 1: radix_pass<1>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 2: radix_pass<2>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 3: radix_pass<3>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 4: radix_pass<4>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 5: radix_pass<5>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 6: radix_pass<6>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 7: radix_pass<7>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 8: radix_pass<8>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 9: radix_pass<9>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 10: radix_pass<10>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            default: radix_pass<11>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
         }
         shift += bits;
         cur ^= 1;
@@ -418,7 +445,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
         const uint32_t o_lo = __shfl(lo, a), o_g = __shfl(g, a), o_nx = __shfl(nx, a), o_x0 = __shfl(x0, a), o_ty0 = __shfl(ty0, a);
         if (t < wave_total) {
             const uint32_t jj = t - o_lo;
-            const uint32_t ry = jj / o_nx, rx = jj - ry * o_nx;
+            // jj / o_nx without the ~25-instruction integer division: float estimate (exact operands below 2^22, beyond which the
+            // integer division runs), one correction step either way makes it exact
+            uint32_t ry;
+            if (jj < (1u << 22)) {
+                ry = (uint32_t)(((float)jj + 0.5f) * __builtin_amdgcn_rcpf((float)o_nx));
+                ry -= (ry * o_nx > jj) ? 1u : 0u;
+                ry += ((ry + 1u) * o_nx <= jj) ? 1u : 0u;
+            } else {
+                ry = jj / o_nx;
+            }
+            const uint32_t rx = jj - ry * o_nx;
             inst_tile[(size_t)wave_base + t] = (o_ty0 + ry) * (uint32_t)tiles_x + o_x0 + rx;
             inst_val[(size_t)wave_base + t] = o_g;
         }
@@ -433,22 +470,32 @@ void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off
                        grid.tiles_x, inst_tile, inst_val);
 }
 
-// R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys; ranges pre-zeroed (:324)
-__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ tile_sorted, size_t R, uint2* __restrict__ ranges) {
+// R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles
+// without instances read (0, 0); here the thread at a boundary writes the empty ranges of the tiles it skips over (and the
+// first / last thread those before the first / behind the last key): every entry is written, no separate fill launch.
+__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ tile_sorted, size_t R, uint2* __restrict__ ranges, uint32_t tiles) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R) return;
     const uint32_t cur = tile_sorted[i];
-    if (i == 0) ranges[cur].x = 0;
-    else {
+    if (i == 0) {
+        for (uint32_t t = 0; t < cur && t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+        ranges[cur].x = 0;
+    } else {
         const uint32_t prev = tile_sorted[i - 1];
-        if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
+        if (cur != prev) {
+            ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i;
+            for (uint32_t t = prev + 1; t < cur; t++) ranges[t] = make_uint2(0u, 0u);
+        }
     }
-    if (i == R - 1) ranges[cur].y = (uint32_t)R;
+    if (i == R - 1) {
+        ranges[cur].y = (uint32_t)R;
+        for (uint32_t t = cur + 1; t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+    }
 }
 
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s) {
-    hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
-    if (R) hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, ranges);
+    if (R) hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, ranges, (uint32_t)tiles);
+    else hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
 }
 
 }  // namespace lg

@@ -57,18 +57,20 @@ struct Carver {
 constexpr int SORT_ITEMS = 16;                  // rounds of 64 keys per wave
 constexpr int SORT_WAVES = 4;                   // waves per sort block
 constexpr int SORT_CHUNK = 64 * SORT_ITEMS * SORT_WAVES;   // keys per block (4096)
-constexpr int SORT_RADIX_BITS = 8;
-constexpr int SORT_BINS = 1 << SORT_RADIX_BITS;
+constexpr int SORT_RADIX_BITS = 8;               // default digit width (tile binning: short digit runs must stay whole lines)
+constexpr int SORT_MAX_RADIX_BITS = 11;          // the range sort of the P Gaussians: 31 key bits in 3 passes (11 + 10 + 10)
+constexpr int SORT_MAX_BINS = 1 << SORT_MAX_RADIX_BITS;
 constexpr int SCAN_BLOCK = 1024;                // elements per scan block (256 threads x 4)
 
 inline size_t sort_blocks(size_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
 inline size_t scan_blocks(size_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
 // u32 words of scratch needed to sort n pairs: digit histogram [BINS x blocks] + per-digit totals
 constexpr unsigned SORT_PREFIX_CHUNK = 1024;     // blocks per wave in the two-level cross-block prefix (used above 2 chunks)
-inline size_t sort_scratch_words(size_t n) {
-    size_t h = (size_t)SORT_BINS * sort_blocks(n);
+inline size_t sort_scratch_words(size_t n, int max_bits = SORT_RADIX_BITS) {
+    const size_t bins = (size_t)1 << max_bits;
+    size_t h = bins * sort_blocks(n);
     size_t chunks = (sort_blocks(n) + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
-    return h + SORT_BINS + (size_t)SORT_BINS * chunks + 64;
+    return h + bins + bins * chunks + 64;
 }
 inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 
@@ -106,7 +108,7 @@ inline size_t geom_carve(char* base, size_t P, GeomView* v) {
     g.block_off = c.take<uint32_t>(scan_blocks(P) + 64);
     g.totals = c.take<uint32_t>(LG_TOTALS_WORDS);
     g.gacc = c.take<float>(16 * P);
-    g.scratch_words = sort_scratch_words(P) + scan_scratch_words(P);
+    g.scratch_words = sort_scratch_words(P, SORT_MAX_RADIX_BITS) + scan_scratch_words(P);
     g.scratch = c.take<uint32_t>(g.scratch_words);
     if (v) *v = g;
     return (size_t)(c.p - base) + 128;
@@ -238,9 +240,10 @@ void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, con
                          const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
                          float* o_scales, float* o_rot, hipStream_t s);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s);
-// sorts (key,val) pairs on key bits [0,end_bit); result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
+// sorts (key,val) pairs on key bits [0,end_bit) in digits of at most max_bits (<= SORT_MAX_RADIX_BITS; 0 = SORT_RADIX_BITS);
+// result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s);
+                            uint32_t* scratch, hipStream_t s, int max_bits = 0);
 void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
                              size_t P, hipStream_t s);
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,

@@ -131,6 +131,13 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     }
     const float* __restrict__ beams = a.beams;
     auto beam = [&](int q) { return lds_beams ? s_beams[q] : beams[q]; };
+    // tan(|beam[i] - beam[i-1]|) of R3/cr/forward.cu:361 depends on the beam interval only: H - 1 values per workgroup instead of
+    // one tanf (~60 instructions) per Gaussian; same function on the same argument, so the row radius is bit-identical
+    __shared__ float s_tan_gap[BEAMS_LDS];
+    if (lds_beams) {
+        for (int q = threadIdx.x + 1; q < pp.H; q += blockDim.x) s_tan_gap[q] = tanf(fabsf(s_beams[q] - s_beams[q - 1]));
+        __syncthreads();
+    }
 
     int out_radius = 0, rx = 0, ry = 0;
     uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0, t4 = 0, t8 = 0, t16 = 0;
@@ -199,6 +206,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         }
         float before, after, p_r;
         const float guard = 0.002f * 2;                                // Ray_Divergence_Angle*2, :22/:347/:356
+        const int gap = bi > 0 ? bi : 1;                               // the interval (gap - 1, gap) whose width scales the row radius
         if (bi > 0) {
             before = beam(bi - 1); after = beam(bi);
             p_r = (float)(bi - 1) + (alpha - before) / (after - before);
@@ -210,7 +218,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         }
         p_r = (float)H - p_r - 1.f;                                    // :359
 
-        ry = (int)ceilf(3.f * my_radius / tanf(fabsf(after - before)));   // :361
+        ry = (int)ceilf(3.f * my_radius / (lds_beams ? s_tan_gap[gap] : tanf(fabsf(after - before))));   // :361
         rx = (int)ceilf(3.f * my_radius / pp.tan_col_step);            // :362
 
         // reference rect in 16x1 tiles (R3/cr/auxiliary.h:80-92); x truncates, y rounds
