@@ -686,6 +686,8 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="time the rasterizer forward alone (default for cfg2)")
     ap.add_argument("--fwd-bwd", action="store_true", help="forward + backward also for cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--enqueue-only", action="store_true",
+                    help="render with GaussianRasterizer.enqueue_only (lidargs_forward_enqueue: no host wait per frame); single GPU only")
     args = ap.parse_args()
 
     if args.workload == "decode":
@@ -740,6 +742,7 @@ def main():
 
     if world == 1 and not force_shells:
         rast = GaussianRasterizer(settings)
+        rast.enqueue_only = bool(args.enqueue_only)
 
         if fwd_only:
             def step():
@@ -842,6 +845,7 @@ def main():
                                    f"lidar_far=80 lidar_near=0, bg=0",
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
                        "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
+                       "forward": "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)",
                        "sharding": "single GPU" if world == 1 else f"{world} range shells"},
         }
         if world == 1 and not force_shells:

@@ -99,6 +99,50 @@ int lidargs_forward(
     int debug,
     void* stream);
 
+/* lidargs_forward without its one host wait (no reference counterpart: the reference blocks on a cudaMemcpy of the instance
+ * count, R3/cr/rasterizer_impl.cu:292, to size the binning buffer).  The caller states the capacity instead:
+ *   instance_capacity  (Gaussian, 16 x tile_rows tile) instances the binning buffer is sized for (e.g. 1.25 x what the previous
+ *                      frame needed -- the int lidargs_forward returned, low two bits cleared);
+ *   tile_rows          list-tile height 4, 8, 16 or 32 (what a previous lidargs_forward chose: 4 << (num_rendered & 3));
+ *   status_host        NULL, or 16 words of PINNED host memory the stream fills behind the launches: [0] instances the frame
+ *                      needed, [1] instances binned = min(needed, capacity), [2..7] 64-bit instance totals for tile heights
+ *                      4 / 8 / 16, [8] = 1 if the capacity was too small, [9] capacity.  Valid once the stream has passed the copy.
+ * Every count the later stages need stays on the device, so the call only enqueues work (it can be captured in a HIP graph, and
+ * the host can run ahead).  If [8] comes back 1, instances were dropped: that frame's outputs are wrong and it must be redone
+ * with a larger capacity (or with lidargs_forward).  The returned int and the three buffers go to lidargs_backward as usual. */
+int lidargs_forward_enqueue(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,
+    int width, int height,
+    const float* means3D,
+    const float* shs,
+    const float* colors_precomp,
+    const float* opacities,
+    const float* scales,
+    float scale_modifier,
+    const float* rotations,
+    const float* cov3D_precomp,
+    const float* viewmatrix,
+    const float* projmatrix,
+    const float* cam_pos,
+    const float* beam_inclinations,
+    int prefiltered,
+    int lidar_far,
+    int lidar_near,
+    float* out_color,
+    float* out_depth,
+    float* out_occ,
+    int* radii,
+    int* radii_xy,
+    int debug,
+    int instance_capacity,
+    int tile_rows,
+    unsigned* status_host,
+    void* stream);
+
 /* Rasterizer::backward -- R3/cr/rasterizer.h:86-122, R3/cr/rasterizer_impl.cu:431-549.
  * All dL_d* outputs are caller-allocated.  The reference zero-initialises them (R3/rasterize_points.cu:163-175)
  * and accumulates with atomics; this library instead WRITES every one of the P rows of every output (zeros for

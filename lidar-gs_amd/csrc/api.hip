@@ -164,6 +164,11 @@ void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive
     ra.seg_lo = 0; ra.seg_hi = S;
 }
 
+// digit width of the range sort of the P Gaussians: LIDARGS_RANGE_SORT_BITS = 8 (4 passes over the 31 key bits) .. 11 (3 passes)
+int range_sort_bits() {
+    static const int b = [] { const char* e = getenv("LIDARGS_RANGE_SORT_BITS"); const int v = e ? atoi(e) : 8; return (v >= 8 && v <= lg::SORT_MAX_RADIX_BITS) ? v : 8; }();
+    return b;
+}
 int ceil_log2(uint32_t n) {
     int b = 0;
     while ((1u << b) < n && b < 31) b++;
@@ -177,6 +182,7 @@ int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 int api_check_launch(hipStream_t s, int debug, const char* what) { return check_launch(s, debug, what); }
 int api_tile_rows() { return tile_rows(); }
 int api_ceil_log2(uint32_t n) { return ceil_log2(n); }
+int api_range_sort_bits() { return range_sort_bits(); }
 SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel) { return plan_segments(R, waves_per_tile, surfel); }
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s) {
     if (n > HostRead::WORDS || !t_host_read.ready()) return (int)hipErrorOutOfMemory;
@@ -249,7 +255,16 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
                  float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* beams, float near_f, float far_f, float shell_lo, float shell_hi, const float* T_in,
                  int transmittance_pass, float* out_color, float* out_depth, float* out_occ, float* T_out, int* radii,
-                 int* radii_xy, int debug, hipStream_t stream) {
+                 int* radii_xy, int debug, hipStream_t stream, long long instance_capacity = 0, int fixed_tile_rows = 0,
+                 unsigned* status_host = nullptr) {
+    // instance_capacity > 0: ENQUEUE-ONLY mode.  Nothing is read back: the binning buffer is sized for `instance_capacity`
+    // instances at the caller's tile height, every count the later stages need stays on the device, and the 16 status words
+    // (binning.hip k_finish_totals: instances needed / binned, totals per tile height, overflow flag) are copied to
+    // `status_host` (pinned, optional) by the stream.  The call can therefore be captured in a HIP graph.
+    const bool enqueue_only = instance_capacity > 0;
+    if (enqueue_only && !(fixed_tile_rows == 4 || fixed_tile_rows == 8 || fixed_tile_rows == 16 || fixed_tile_rows == 32))
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward (enqueue-only): tile_rows must be 4, 8, 16 or 32%s");
+    if (enqueue_only && instance_capacity > (long long)std::numeric_limits<int>::max() - 4) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward (enqueue-only): capacity overflows int%s");
     if (P < 0 || width <= 0 || height <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: bad sizes%s");
     if (height < 2) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: need at least 2 beams%s");
     if (height > 65535 || width > 65535 * 16) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: image too large%s");
@@ -288,7 +303,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 1. range sort of the Gaussians on the low 31 key bits, 3 passes of 11 + 10 + 10: ranges are positive floats (bit 31 clear), and a
     //    culled Gaussian's key 0xFFFFFFFF still sorts behind every valid one (valid keys are < bits(lidar_far) < 0x7FFFFFFF)
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
-                                                 lg::SORT_MAX_RADIX_BITS);
+                                                 range_sort_bits());
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
     LG_STAGE_CHECK("range sort");
     g_prof.mark("range_sort", stream);
@@ -298,29 +313,44 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     //    4 / 8 / 16 -> tile height, R.  Only if another height wins are the offsets recomputed.
     // the likeliest tile height: the one the last frame on this thread chose (a training loop renders similar frames in a row)
     thread_local int t_last_th = 4;
-    const int th_guess = forced_tile_rows() ? forced_tile_rows() : t_last_th;
-    lg::launch_instance_offsets(ids_sorted, geom.spans, th_guess, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
-    LG_STAGE_CHECK("instance scan");
-    uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
-    // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
-    LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, LG_TOTALS_WORDS, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
-    unsigned long long inst[3] = {0, 0, 0};
-    for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
-        unsigned long long v[4];
-        memcpy(v, totals_h + LG_TOTALS_SLOT_WORD + 8 * slot, sizeof v);
-        inst[0] += v[0]; inst[1] += v[1]; inst[2] += v[2];
-    }
-    const uint32_t scan_total = totals_h[0];
-    const unsigned long long inst3[3] = {inst[0], inst[1], inst[2]};
-    const int TH = choose_tile_rows(inst3);
-    const lg::TileGrid grid = lg::make_grid(width, height, TH);
-    unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (unsigned long long)scan_total));
-    if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
-    const size_t R = (size_t)R64;
-    if (TH != th_guess) {
+    int TH;
+    size_t R;
+    uint32_t* status_dev = geom.totals + LG_TOTALS_STATUS_WORD;
+    if (!enqueue_only) {
+        const int th_guess = forced_tile_rows() ? forced_tile_rows() : t_last_th;
+        lg::launch_instance_offsets(ids_sorted, geom.spans, th_guess, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        LG_STAGE_CHECK("instance scan");
+        uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
+        // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
+        LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, LG_TOTALS_WORDS, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
+        unsigned long long inst[3] = {0, 0, 0};
+        for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
+            unsigned long long v[4];
+            memcpy(v, totals_h + LG_TOTALS_SLOT_WORD + 8 * slot, sizeof v);
+            inst[0] += v[0]; inst[1] += v[1]; inst[2] += v[2];
+        }
+        const uint32_t scan_total = totals_h[0];
+        const unsigned long long inst3[3] = {inst[0], inst[1], inst[2]};
+        TH = choose_tile_rows(inst3);
+        unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (unsigned long long)scan_total));
+        if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
+        R = (size_t)R64;
+        if (TH != th_guess) {
+            lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        }
+        t_last_th = TH;
+    } else {
+        TH = fixed_tile_rows;
+        R = (size_t)instance_capacity;                                     // the capacity stands in for the count everywhere on the host
         lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        LG_STAGE_CHECK("instance scan");
+        LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
+        lg::launch_finish_totals(geom.totals, reinterpret_cast<const unsigned long long*>(geom.totals + LG_TOTALS_SLOT_WORD),
+                                 (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);
+        if (status_host) LG_HIP(hipMemcpyAsync(status_host, status_dev, LG_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
-    t_last_th = TH;
+    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    const uint32_t* R_dev = enqueue_only ? status_dev + 1 : nullptr;       // instances binned = min(needed, capacity), on the device
     g_prof.mark("scan+readback", stream);
 
     // everything a later call on these buffers derives (plan, carving, flag stride) comes from the returned int alone
@@ -337,11 +367,11 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     const uint32_t* point_list = bin.val_a;
     if (R) {
         lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, (size_t)P, grid,
-                                  bin.tile_a, bin.val_a, stream);
+                                  bin.tile_a, bin.val_a, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
         const int bits = ceil_log2((uint32_t)grid.num_tiles());
-        const int bside = lg::launch_radix_sort_pairs(bin.tile_a, bin.tile_b, bin.val_a, bin.val_b, R, bits, bin.scratch, stream);
+        const int bside = lg::launch_radix_sort_pairs(bin.tile_a, bin.tile_b, bin.val_a, bin.val_b, R, bits, bin.scratch, stream, 0, R_dev);
         if (bside) {   // keep the backward's view independent of the pass count: result always in (tile_a, val_a)
             LG_HIP(hipMemcpyAsync(bin.tile_a, bin.tile_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
             LG_HIP(hipMemcpyAsync(bin.val_a, bin.val_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
@@ -349,7 +379,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         LG_STAGE_CHECK("tile bin");
         g_prof.mark("tile_bin", stream);
     }
-    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream);
+    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev);
     LG_STAGE_CHECK("tile ranges");
     g_prof.mark("ranges", stream);
 
@@ -466,6 +496,22 @@ int lidargs_forward(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidarg
                         height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                         beam_inclinations, (float)lidar_near, (float)lidar_far, -inf, inf, nullptr, 0, out_color, out_depth,
                         out_occ, nullptr, radii, radii_xy, debug, (hipStream_t)stream);
+}
+
+int lidargs_forward_enqueue(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                            lidargs_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                            int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                            const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, const float* beam_inclinations,
+                            int prefiltered, int lidar_far, int lidar_near, float* out_color, float* out_depth, float* out_occ,
+                            int* radii, int* radii_xy, int debug, int instance_capacity, int tile_rows, unsigned* status_host, void* stream) {
+    (void)D; (void)M; (void)shs; (void)projmatrix; (void)cam_pos; (void)prefiltered;
+    if (instance_capacity <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_enqueue: instance_capacity must be positive%s");
+    const float inf = std::numeric_limits<float>::infinity();
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
+                        height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        beam_inclinations, (float)lidar_near, (float)lidar_far, -inf, inf, nullptr, 0, out_color, out_depth,
+                        out_occ, nullptr, radii, radii_xy, debug, (hipStream_t)stream, (long long)instance_capacity, tile_rows, status_host);
 }
 
 int lidargs_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

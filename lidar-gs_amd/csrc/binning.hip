@@ -110,10 +110,13 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 //                         LDS, then streams it out: consecutive threads write consecutive addresses inside each digit
 //                         run, so the pass writes whole lines instead of 4-byte crumbs (measured 5x write
 //                         amplification with direct per-key scatter).
+// `n_dev` (nullable): the pair count lives on the device (enqueue-only forward: the host never learns it); the launch then covers the
+// capacity `n` and the blocks behind *n_dev see no keys (their histograms are zero, their scatter retires).
 template <int BITS>
-__global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, int shift,
+__global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev, int shift,
                                                     uint32_t* __restrict__ hist, unsigned nblocks) {
     constexpr int BINS = 1 << BITS;
+    if (n_dev) n = min(n, (size_t)*n_dev);
     __shared__ uint32_t cnt[BINS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t base = (size_t)blockIdx.x * SORT_CHUNK + (size_t)w * (64 * SORT_ITEMS);
@@ -184,11 +187,13 @@ __global__ void __launch_bounds__(256) k_radix_chunk_prefix(uint32_t* __restrict
 template <int BITS>
 __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                       size_t n, int shift, const uint32_t* __restrict__ hist,
+                                                       size_t n, const uint32_t* __restrict__ n_dev, int shift, const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
                                                        const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks) {
     constexpr int BINS = 1 << BITS;
     constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * SORT_CHUNK >= n) return;     // wave-uniform, before any barrier
     __shared__ uint32_t run[SORT_WAVES][BINS];   // per-wave running digit counts, then wave bases
     __shared__ uint32_t dbase[BINS];             // block-local start of each digit run
     __shared__ uint32_t gbase[BINS];             // global start of this block's run of each digit
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 }
 
 template <int BITS>
-static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, int shift,
+static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
                        uint32_t* scratch, hipStream_t s, int max_bits) {
     const size_t SORT_MAX_BINS = (size_t)1 << max_bits;          // the scratch layout of sort_scratch_words(n, max_bits)
     const unsigned nb = (unsigned)sort_blocks(n);
@@ -317,7 +322,7 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
     const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
     const bool two_level = chunks_all > 2;
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
-    hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
+    hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb);
     // single level: the chunk sums ARE the digit totals, written straight to `tot`
     const dim3 pgrid((BINS * chunks + 3) / 4);
     uint32_t* const pout = two_level ? part : tot;
@@ -325,12 +330,12 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
     else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<16>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     else hipLaunchKernelGGL(k_radix_digit_prefix<32>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
-    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, shift, hist, tot, nb,
+    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
                        two_level ? part : (const uint32_t*)nullptr, chunk, chunks);
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s, int max_bits) {
+                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev) {
     if (n == 0 || end_bit <= 0) return 0;
     if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
     int cur = 0;
@@ -343,17 +348,17 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
         const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
         switch (bits) {
-            case 1: radix_pass<1>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 2: radix_pass<2>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 3: radix_pass<3>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 4: radix_pass<4>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 5: radix_pass<5>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 6: radix_pass<6>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 7: radix_pass<7>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 8: radix_pass<8>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 9: radix_pass<9>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            case 10: radix_pass<10>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
-            default: radix_pass<11>(kin, vin, kout, vout, n, shift, scratch, s, max_bits); break;
+            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
         }
         shift += bits;
         cur ^= 1;
@@ -412,7 +417,7 @@ void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int
 // R3/cr/rasterizer_impl.cu:70-112, whose per-thread trip count varies 1..100s).
 __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ block_off,
                                                                const uint2* __restrict__ span_sorted, size_t P, int th_shift, int tiles_x,
-                                                               uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val) {
+                                                               uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap) {
     __shared__ uint32_t s_tot[SCAN_BLOCK / 64];                        // instance count of each wave's 64 Gaussians
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
@@ -443,7 +448,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
             if (v <= t) a = mid; else b = mid - 1;
         }
         const uint32_t o_lo = __shfl(lo, a), o_g = __shfl(g, a), o_nx = __shfl(nx, a), o_x0 = __shfl(x0, a), o_ty0 = __shfl(ty0, a);
-        if (t < wave_total) {
+        if (t < wave_total && wave_base + t < cap) {                  // cap: the binning buffer's capacity (enqueue-only forward); UINT_MAX otherwise
             const uint32_t jj = t - o_lo;
             // jj / o_nx without the ~25-instruction integer division: float estimate (exact operands below 2^22, beyond which the
             // integer division runs), one correction step either way makes it exact
@@ -463,18 +468,24 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
 }
 
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,
-                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s) {
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap) {
     int sh = 0;
     while ((1 << sh) < grid.TH) sh++;
     hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted, P, sh,
-                       grid.tiles_x, inst_tile, inst_val);
+                       grid.tiles_x, inst_tile, inst_val, cap);
 }
 
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles
 // without instances read (0, 0); here the thread at a boundary writes the empty ranges of the tiles it skips over (and the
 // first / last thread those before the first / behind the last key): every entry is written, no separate fill launch.
-__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ tile_sorted, size_t R, uint2* __restrict__ ranges, uint32_t tiles) {
+__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ tile_sorted, size_t R, const uint32_t* __restrict__ R_dev,
+                                                     uint2* __restrict__ ranges, uint32_t tiles) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (R_dev) R = min(R, (size_t)*R_dev);                             // enqueue-only forward: the count lives on the device
+    if (R == 0) {                                                      // nothing binned: every tile is empty
+        if (blockIdx.x == 0) for (uint32_t t = threadIdx.x; t < tiles; t += 256) ranges[t] = make_uint2(0u, 0u);
+        return;
+    }
     if (i >= R) return;
     const uint32_t cur = tile_sorted[i];
     if (i == 0) {
@@ -493,9 +504,33 @@ __global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict_
     }
 }
 
-void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s) {
-    if (R) hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, ranges, (uint32_t)tiles);
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev) {
+    if (R) hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, R_dev, ranges, (uint32_t)tiles);
     else hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
+}
+
+// Enqueue-only forward: what the host would have read, folded on the device.  status[0] = instances the frame needs at the chosen
+// tile height (the scan total), [1] = instances binned = min(needed, capacity), [2..7] = 64-bit instance totals for tile heights
+// 4 / 8 / 16, [8] = 1 if the capacity was too small (instances were dropped: the frame is wrong and must be redone), [9] = capacity.
+__global__ void __launch_bounds__(64) k_finish_totals(const uint32_t* __restrict__ totals, const unsigned long long* __restrict__ slots, uint32_t cap,
+                                                      uint32_t* __restrict__ status) {
+    const int lane = threadIdx.x;
+    unsigned long long v[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        v[q] = lane < LG_INST_SLOTS ? slots[4 * lane + q] : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+    }
+    if (lane == 0) {
+        const uint32_t need = totals[0];
+        status[0] = need; status[1] = need < cap ? need : cap;
+        for (int q = 0; q < 3; q++) { status[2 + 2 * q] = (uint32_t)v[q]; status[3 + 2 * q] = (uint32_t)(v[q] >> 32); }
+        status[8] = need > cap ? 1u : 0u; status[9] = cap;
+    }
+}
+void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish_totals, dim3(1), dim3(64), 0, s, totals, slots, cap, status);
 }
 
 }  // namespace lg

@@ -81,7 +81,10 @@ inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 // word 4 of the totals: 0 while the packed gradient lines (gacc) are all-zero as the forward left them, 1 once a backward has
 // accumulated into them (k_gaussian_backward sets it; a further backward on the same buffers then clears the lines first)
 #define LG_TOTALS_DIRTY_WORD 4
-#define LG_TOTALS_WORDS (LG_TOTALS_SLOT_WORD + 8 * LG_INST_SLOTS)
+// behind the slots: the 16 status words of an enqueue-only forward (binning.hip k_finish_totals)
+#define LG_TOTALS_STATUS_WORD (LG_TOTALS_SLOT_WORD + 8 * LG_INST_SLOTS)
+#define LG_STATUS_WORDS 16
+#define LG_TOTALS_WORDS (LG_TOTALS_STATUS_WORD + LG_STATUS_WORDS)
 struct GeomView {
     float4* rec;
     uint32_t* rowspan;
@@ -204,6 +207,7 @@ int api_fail(int code, const char* msg);
 int api_check_launch(hipStream_t s, int debug, const char* what);
 int api_tile_rows();
 int api_ceil_log2(uint32_t n);
+int api_range_sort_bits();
 struct SegPlan { int seg_len, max_segments, n_rounds, rounds[8]; };   // api.hip plan_segments
 SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel);
 // Device -> host read of `n` (<= 1024) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
@@ -242,13 +246,15 @@ void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, con
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s);
 // sorts (key,val) pairs on key bits [0,end_bit) in digits of at most max_bits (<= SORT_MAX_RADIX_BITS; 0 = SORT_RADIX_BITS);
 // result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
+// n_dev (nullable): the pair count lives on the device and n is only the capacity the launches cover
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s, int max_bits = 0);
+                            uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr);
+void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
 void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
                              size_t P, hipStream_t s);
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,
-                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s);
-void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s);
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr);
 
 #ifdef __HIPCC__
 // blockIdx -> (patch, segment): segment-fastest, with S ODD.  Workgroups are dealt round-robin to the 8 XCDs (b % 8) and

@@ -29,7 +29,7 @@ if not os.path.exists(_SO_PATH):
 _lib = C.CDLL(_SO_PATH)
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib.lidargs_last_error.restype = C.c_char_p
-for _name in ("lidargs_forward", "lidargs_backward", "lidargs_visible_filter", "lidargs_mark_visible",
+for _name in ("lidargs_forward", "lidargs_forward_enqueue", "lidargs_backward", "lidargs_visible_filter", "lidargs_mark_visible",
               "lidargs_forward_shell", "lidargs_render_shell", "lidargs_backward_shell", "lidargs_abi_version",
               "lidargs_profile_read", "lidargs_profile_summary", "lidargs_last_counters"):
     getattr(_lib, _name).restype = C.c_int
@@ -73,6 +73,10 @@ def _ptr(t):
 
 
 _scratch_registry = {}
+# LIDARGS_POISON_SCRATCH=1 (tests): every scratch buffer handed to the library is filled with 0xFF bytes (NaN floats, huge
+# integers) first, so that a kernel reading scratch memory nobody wrote shows up deterministically instead of depending on what
+# the caching allocator happens to recycle.
+_POISON = os.environ.get("LIDARGS_POISON_SCRATCH", "0") == "1"
 
 
 @_ALLOC_FN
@@ -83,6 +87,8 @@ def _alloc_cb(user, nbytes):
         return 0
     try:
         sc.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=sc.device)
+        if _POISON:
+            sc.tensor.fill_(255)
         return sc.tensor.data_ptr()
     except Exception:  # surface as LIDARGS_ERR_ALLOC instead of unwinding through C
         return 0
@@ -121,11 +127,14 @@ def _stream(device):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, image_height, image_width, beam_inclinations, sh, degree, campos,
-                        prefiltered, far, near, debug):
+                        prefiltered, far, near, debug, enqueue=None):
     """RasterizeGaussiansCUDA (R3/rasterize_points.cu:35-124).
 
     Returns (num_rendered, out_color[2,H,W], out_depth[1,H,W], out_occ[1,H,W], radii[P] int32,
-    geomBuffer, binningBuffer, imgBuffer) -- the last three opaque uint8 tensors."""
+    geomBuffer, binningBuffer, imgBuffer) -- the last three opaque uint8 tensors.
+
+    enqueue = (instance_capacity, tile_rows, status) switches to lidargs_forward_enqueue (no host wait, graph-capturable;
+    include/lidargs_rasterizer.h): `status` is None or a pinned int32[16] host tensor the stream fills behind the launches."""
     if means3D.ndim != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_device(means3D, "means3D")
@@ -150,16 +159,22 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         for t, n in ((bg, "bg"), (col, "colors_precomp"), (opa, "opacities"), (vm, "viewmatrix"), (beams, "beam_inclinations")):
             if t.numel():
                 _require_device(t, n)
+        common = (_alloc_cb, geom.user, _alloc_cb, binning.user, _alloc_cb, img.user,
+                  C.c_int(P), C.c_int(int(degree)), C.c_int(M), _ptr(bg), C.c_int(W), C.c_int(H),
+                  _ptr(m3), _ptr(shc if shc.is_cuda else None), _ptr(col), _ptr(opa), _ptr(sc if sc.is_cuda else None),
+                  C.c_float(float(scale_modifier)), _ptr(rot if rot.is_cuda else None), _ptr(cov if cov.is_cuda else None),
+                  _ptr(vm), _ptr(pm if pm.is_cuda else None), _ptr(cp if cp.is_cuda else None), _ptr(beams),
+                  C.c_int(int(bool(prefiltered))), C.c_int(int(far)), C.c_int(int(near)),
+                  _ptr(out_color), _ptr(out_depth), _ptr(out_occ), _ptr(radii), _ptr(radii_xy), C.c_int(int(bool(debug))))
         with torch.cuda.device(dev):
-            rendered = _lib.lidargs_forward(
-                _alloc_cb, geom.user, _alloc_cb, binning.user, _alloc_cb, img.user,
-                C.c_int(P), C.c_int(int(degree)), C.c_int(M), _ptr(bg), C.c_int(W), C.c_int(H),
-                _ptr(m3), _ptr(shc if shc.is_cuda else None), _ptr(col), _ptr(opa), _ptr(sc if sc.is_cuda else None),
-                C.c_float(float(scale_modifier)), _ptr(rot if rot.is_cuda else None), _ptr(cov if cov.is_cuda else None),
-                _ptr(vm), _ptr(pm if pm.is_cuda else None), _ptr(cp if cp.is_cuda else None), _ptr(beams),
-                C.c_int(int(bool(prefiltered))), C.c_int(int(far)), C.c_int(int(near)),
-                _ptr(out_color), _ptr(out_depth), _ptr(out_occ), _ptr(radii), _ptr(radii_xy),
-                C.c_int(int(bool(debug))), _stream(dev))
+            if enqueue is None:
+                rendered = _lib.lidargs_forward(*common, _stream(dev))
+            else:
+                cap, tile_rows, status = enqueue
+                if status is not None and not (status.dtype == torch.int32 and status.numel() >= 16 and status.is_pinned()):
+                    raise RuntimeError("enqueue status must be a pinned int32 host tensor of at least 16 elements")
+                rendered = _lib.lidargs_forward_enqueue(*common, C.c_int(int(cap)), C.c_int(int(tile_rows)),
+                                                        C.c_void_p(status.data_ptr()) if status is not None else None, _stream(dev))
         if rendered < 0:
             geom.take(); binning.take(); img.take()
             _raise(rendered, "rasterize_gaussians")

@@ -14,6 +14,8 @@ The native side is lidar-gs_amd/csrc/*.hip behind the C ABI of include/lidargs_r
 """
 from typing import NamedTuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -44,27 +46,87 @@ def _snapshot(args):
     return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
 
 
+class _EnqueueState:
+    """Caller-side state of the enqueue-only forward (lidargs_forward_enqueue): the binning capacity and tile height, learnt from
+    one ordinary frame and then kept with headroom, plus the pinned status words of the last enqueue-only frame.  It lives in the
+    GaussianRasterizer module (the caller), not in the library."""
+    HEADROOM = 1.25
+
+    def __init__(self):
+        self.cap, self.th = None, 4
+        self.status = None            # pinned int32[16]
+        self.event, self.pending = None, False
+        self.frames = 0
+
+    def learn(self, num_rendered):
+        """From an ordinary frame's num_rendered (instance capacity | tile-height code)."""
+        need = int(num_rendered) & ~3
+        self.th = 4 << (int(num_rendered) & 3)
+        self.cap = max(int(need * self.HEADROOM) + 4096, self.cap or 0)
+
+    def plan(self):
+        """(capacity, tile_rows, status) for the next frame, or None while nothing has been learnt.  Looks at the status of
+        the previous enqueue-only frame if the stream has passed it (never waits): grows the capacity early, and raises if
+        that frame overflowed -- its outputs were wrong."""
+        if self.cap is None:
+            return None
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.pending and not capturing and self.event.query():
+            self.pending = False
+            need, over = int(self.status[0]), int(self.status[8])
+            if need * 1.08 > self.cap:
+                self.cap = int(need * self.HEADROOM) + 4096
+            if over:
+                raise RuntimeError(f"diff_lidargs_rasterization: an enqueue-only frame needed {need} list instances but its binning "
+                                   f"buffer held {int(self.status[9])}; that frame's outputs are invalid (capacity raised to {self.cap}, "
+                                   "re-render it)")
+        if self.status is None:
+            self.status = torch.zeros(16, dtype=torch.int32).pin_memory()
+        return self.cap, self.th, self.status
+
+    def submitted(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.event is None:
+            self.event = torch.cuda.Event()
+        self.event.record()
+        self.pending = True
+        self.frames += 1
+
+    def read_status(self):
+        """Synchronises; dict of the last enqueue-only frame's status words."""
+        torch.cuda.synchronize()
+        st = self.status.tolist() if self.status is not None else [0] * 16
+        return dict(needed=st[0], binned=st[1], overflow=bool(st[8]), capacity=st[9], tile_rows=self.th)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """Autograd node: marshals to `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` with the
     argument order of R3/diff_lidargs_rasterization/__init__.py:60-81 and :113-136."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, enqueue_state=None):
         rs = raster_settings
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.image_height, rs.image_width, rs.beam_inclinations, sh, rs.sh_degree,
                 rs.campos, rs.prefiltered, rs.lidar_far, rs.lidar_near, rs.debug)
+        plan = enqueue_state.plan() if enqueue_state is not None else None     # None: an ordinary frame (one host wait)
         if rs.debug:
             saved = _snapshot(args)  # copied before anything can corrupt them
             try:
-                out = _C.rasterize_gaussians(*args)
+                out = _C.rasterize_gaussians(*args, enqueue=plan)
             except Exception:
                 torch.save(saved, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            out = _C.rasterize_gaussians(*args)
+            out = _C.rasterize_gaussians(*args, enqueue=plan)
         num_rendered, color, depth, occ, radii, geom_buffer, binning_buffer, img_buffer = out
+        if enqueue_state is not None:
+            if plan is None:
+                enqueue_state.learn(num_rendered)
+            else:
+                enqueue_state.submitted()
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
@@ -97,12 +159,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_means2D, grad_colors, grad_opacities, grad_means3D, grad_cov3Ds, grad_sh, grad_scales, grad_rotations = grads
         # one slot per forward input, in forward's order (R3/.../__init__.py:150-160)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds, None)
+                grad_cov3Ds, None, None)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        enqueue_state=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, enqueue_state)
 
 
 def _or_empty(t):
@@ -112,9 +175,24 @@ def _or_empty(t):
 
 
 class GaussianRasterizer(nn.Module):
+    """Same constructor and methods as the reference's module (R3/diff_lidargs_rasterization/__init__.py:181-263).
+
+    One addition, off by default: `enqueue_only` (attribute, or LIDARGS_ENQUEUE_ONLY=1 in the environment).  The reference's
+    forward blocks the host once per frame (cudaMemcpy of the instance count, R3/cr/rasterizer_impl.cu:292) and so does the
+    default forward here; with enqueue_only the first frame runs that way and tells the module how many list instances the
+    view needs, every later frame only ENQUEUES work (lidargs_forward_enqueue: capacity = 1.25 x what was needed, counts stay
+    on the device) -- the host runs ahead and the frame can be captured in a HIP graph.  The price: a view that suddenly needs
+    more than the capacity is detected one frame late (RuntimeError from the next forward; `enqueue_status()` asks now)."""
+
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
+        self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"
+        self._enqueue = _EnqueueState()
+
+    def enqueue_status(self):
+        """Synchronises the device; {needed, binned, overflow, capacity, tile_rows} of the last enqueue-only frame."""
+        return self._enqueue.read_status()
 
     def markVisible(self, positions):
         """bool[P]: view-space z > 0.2, the camera-style test the reference keeps (R3/cr/auxiliary.h:175-200)."""
@@ -130,7 +208,8 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, _or_empty(shs), _or_empty(colors_precomp), opacities,
-                                   _or_empty(scales), _or_empty(rotations), _or_empty(cov3D_precomp), self.raster_settings)
+                                   _or_empty(scales), _or_empty(rotations), _or_empty(cov3D_precomp), self.raster_settings,
+                                   self._enqueue if self.enqueue_only else None)
 
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         """radii[P] int32 of the cull/footprint test only (prefilter_voxel, gaussian_renderer/__init__.py:252-257)."""

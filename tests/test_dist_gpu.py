@@ -17,21 +17,42 @@ pytestmark = pytest.mark.gpu
 
 
 class ThreadComm:
-    """All ranks live in one process: all_gather/all_reduce through shared slots + a barrier."""
+    """All ranks live in one process: all_gather/all_reduce through shared slots + a barrier.
+
+    The virtual ranks share ONE device and ONE stream, and the library's contract is one caller thread per stream
+    (INTEGRATION.md section 3), so the rank threads take turns: a rank holds `turn` whenever it runs (library calls, torch ops)
+    and gives it up only while it waits at a collective.  The schedule is then that of a single caller interleaving the ranks
+    phase by phase, which is what N processes on N GPUs amount to -- without 8 threads enqueueing on one stream at once."""
 
     class Shared:
         def __init__(self, world):
             self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
+            self.turn = threading.Lock()
 
     def __init__(self, shared, rank):
         self.sh, self.rank, self.world = shared, rank, shared.world
+        self.sh.turn.acquire()               # released while waiting in _exchange and by finish()
+
+    def finish(self):
+        if self.sh.turn.locked():
+            try:
+                self.sh.turn.release()
+            except RuntimeError:
+                pass
+
+    def _wait(self):
+        self.sh.turn.release()
+        try:
+            self.sh.barrier.wait(timeout=240)
+        finally:
+            self.sh.turn.acquire()
 
     def _exchange(self, t):
         torch.cuda.synchronize()
         self.sh.slots[self.rank] = t
-        self.sh.barrier.wait(timeout=240)
+        self._wait()
         vals = list(self.sh.slots)
-        self.sh.barrier.wait(timeout=240)
+        self._wait()
         return vals
 
     def all_gather(self, t):
@@ -66,11 +87,13 @@ class ThreadComm:
 def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results):
     """Drives lidargs_dist.shell_forward / shell_backward directly: torch's autograd engine executes all
     CUDA nodes on ONE worker thread per device, which would serialise (and deadlock) the virtual ranks."""
+    comm = None
     try:
         import lidargs_dist
         torch.cuda.set_device(0)
+        comm = ThreadComm(shared, rank)
         st = to_torch(scene)
-        mod = lidargs_dist.ShellRasterizer(make_settings(st, W, H), ThreadComm(shared, rank), grad_sync=grad_sync)
+        mod = lidargs_dist.ShellRasterizer(make_settings(st, W, H), comm, grad_sync=grad_sync)
         (color, depth, occ, radii), saved = lidargs_dist.shell_forward(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
         gc, gd, go = (torch.from_numpy(g).cuda() for g in grads)
         g = lidargs_dist.shell_backward(mod, saved, gc, gd, go)
@@ -81,6 +104,9 @@ def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results):
     except Exception as e:  # pragma: no cover
         results[rank] = e
         shared.barrier.abort()
+    finally:
+        if comm is not None:
+            comm.finish()
 
 
 CASES = [

@@ -283,3 +283,115 @@ def test_backward_on_cloned_buffers(how, hip_lib_built):
         for a, b, c in zip(plain, first, second):
             parity("relocated buffers", b.cpu().numpy(), a.cpu().numpy(), verbose=False)
             parity("relocated buffers, 2nd backward", c.cpu().numpy(), a.cpu().numpy(), verbose=False)
+
+
+def _enqueue_setup(P=20000, H=32, W=600, seed=71, kind="street"):
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import to_torch, make_settings
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    st = to_torch(scene)
+    leaves = {k: st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros((P, 4), device="cuda", requires_grad=True)
+    grads = [torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, seed)]
+    make = lambda: GaussianRasterizer(make_settings(st, W, H))
+    call = lambda rast: rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], colors_precomp=leaves["colors"],
+                             scales=leaves["scales"], rotations=leaves["rotations"])
+    return make, call, list(leaves.values()) + [means2D], grads
+
+
+def test_enqueue_only_forward_matches_the_ordinary_one(hip_lib_built):
+    """lidargs_forward_enqueue (no host wait: capacity from the caller, counts on the device) must produce the ordinary forward's
+    image bit for bit -- the forward has no atomics -- and gradients inside the summation-order band; a capacity that is too
+    small must be reported (status words, and a RuntimeError from the next call), never silently rendered."""
+    import torch
+    make, call, inputs, grads = _enqueue_setup()
+    exact = make()
+    ref = call(exact)
+    g_ref = torch.autograd.grad(list(ref[:3]), inputs, grads)
+    eq = make()
+    eq.enqueue_only = True
+    first = call(eq)                                     # learns capacity and tile height (an ordinary frame)
+    assert eq._enqueue.cap is not None and eq._enqueue.frames == 0
+    second = call(eq)                                    # enqueue-only
+    assert eq._enqueue.frames == 1
+    g_eq = torch.autograd.grad(list(second[:3]), inputs, grads)
+    for a, b, c in zip(ref, first, second):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b in zip(g_ref, g_eq):
+        parity("enqueue-only backward", b.cpu().numpy(), a.cpu().numpy(), verbose=False)
+    st = eq.enqueue_status()
+    assert st["needed"] == st["binned"] and not st["overflow"] and st["capacity"] >= st["needed"] > 0, st
+    # too small a capacity: flagged on the device, raised by the next forward, and the frame after that is right again
+    eq._enqueue.cap = max(64, (st["needed"] // 3) & ~3)
+    eq._enqueue.pending = False                           # (the module would otherwise see the last frame's need and grow first)
+    bad = call(eq)
+    st2 = eq.enqueue_status()
+    assert st2["overflow"] and st2["binned"] < st2["needed"], st2
+    assert bool(torch.isfinite(bad[0]).all())            # dropped instances, not garbage
+    with pytest.raises(RuntimeError, match="binning"):
+        call(eq)
+    good = call(eq)
+    assert not eq.enqueue_status()["overflow"]
+    for a, b in zip(ref, good):
+        assert torch.equal(a, b)
+
+
+def test_hip_graph_capture_of_forward_and_backward(hip_lib_built):
+    """The enqueue-only frame is capturable: forward + backward recorded once in a HIP graph and replayed; every replay gives the
+    eager image bit for bit and the eager gradients within the summation-order band (the backward's float atomics).  Runs in a
+    process of its own: a capture is invalidated by unrelated runtime calls made while it records (another test's pinned host
+    memory being released, an event query), and a broken capture must fail this test, not take the session down."""
+    import os, subprocess, sys
+    code = r"""
+import sys, gc
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch
+import lidargs_scenes as sc
+from test_parity_gpu import _enqueue_setup
+from util import parity
+make, call, inputs, grads = _enqueue_setup(P=30000, H=64, W=800, seed=72)
+# (the eager reference is computed AFTER the replays: an autograd graph built on the default stream and still alive would tie
+#  the leaves' AccumulateGrad nodes to that stream, which PyTorch warns breaks the capture of a backward -- and it does)
+rast = make()
+rast.enqueue_only = True
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):                         # warm-up off the default stream, as graph capture asks
+    for _ in range(3):
+        for t in inputs:
+            t.grad = None
+        out = call(rast)
+        torch.autograd.backward(list(out[:3]), grads)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+assert rast._enqueue.frames >= 2
+for t in inputs:
+    t.grad = None
+gc.collect()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    out = call(rast)
+    torch.autograd.backward(list(out[:3]), grads)
+replays = []
+for _rep in range(3):
+    graph.replay()
+    torch.cuda.synchronize()
+    replays.append(([o.clone() for o in out], [t.grad.clone() for t in inputs]))
+assert not rast.enqueue_status()["overflow"]
+del graph
+exact = make()
+ref = [t.detach() for t in call(exact)]
+g_ref = torch.autograd.grad(list(call(exact)[:3]), inputs, grads)
+for outs, gs in replays:
+    for a, b in zip(ref, outs):
+        assert torch.equal(a, b)                      # image planes and radii: bit for bit, every replay
+    for a, b in zip(g_ref, gs):
+        parity("graph replay backward", b.cpu().numpy(), a.cpu().numpy(), verbose=False)
+print("GRAPH-OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "lidar-gs_amd"), os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "GRAPH-OK" in r.stdout

@@ -73,11 +73,16 @@ def measure(edges):
     errs = []
 
     def record(r):
+        comm = None
         try:
             torch.cuda.set_device(0)
-            frame(lidargs_dist.ShellRasterizer(settings, RecordComm(shared, r, logs[r]), edges=edges))
+            comm = RecordComm(shared, r, logs[r])
+            frame(lidargs_dist.ShellRasterizer(settings, comm, edges=edges))
         except Exception as e:
             errs.append(e); shared.barrier.abort()
+        finally:
+            if comm is not None:
+                comm.finish()
 
     th = [threading.Thread(target=record, args=(r,)) for r in range(world)]
     for t in th: t.start()
