@@ -49,10 +49,15 @@ def reference_dataflow_bytes(P, V, R_ref, N, T):
     return fwd, bwd, 68 * R_ref + 24 * N, 68 * R_ref + 24 * N + 84 * V
 
 
-def raster_kernel_table(P, V, R, N, stages, surfel=False):
+def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
     """ALGORITHMIC bytes of each launch in ITS OWN units: R = the instances this frame binned (R'),
     V = visible Gaussians, N = pixels.  rec = bytes gathered per list entry (id 4 + record 64/80 + row span 4), pix = per-pixel
-    planes.  `stage` = the lidargs_profile stage that brackets the launch(es); `launches` = launches inside that stage."""
+    planes.  `stage` = the lidargs_profile stage that brackets the launch(es); `launches` = launches inside that stage.
+    The blends are priced on `taken` = the (16x4 patch, instance) pairs some pixel really takes (the contribution flags pass 1
+    writes, counted on the host after the timed region): every correct blend must fetch each of them once, while the
+    instances BEHIND a patch's saturation point are never needed -- pricing those (R') made a launch that rightly skips them
+    look faster than the memory system (r02_a: cfg4 1.9 'of peak')."""
+    Rb = taken if taken else R                      # no flags (single-segment frames): every binned instance is walked
     rec = 88 if surfel else 68                                  # 3-D: SURVEY 8d's 68 B/instance (id + 64-B record; the row span rides in it)
     pix_f = 56 if surfel else 24                                # surfel: 2 + 7 output planes, 3 accum planes, 2 count planes
     acc = 128 if surfel else 84                                 # per visible Gaussian: the raster-gradient line the backward blend fills
@@ -64,9 +69,9 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False):
         dict(kernel="radix sort of the range keys (hist + prefix + scatter) x4", stage="range_sort", launches=12, bound="hbm",
              bytes=4 * 20 * P, units="4 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per Gaussian"),
         dict(kernel="forward blend group (reference K7): T-only walk x2 + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
-             launches=5, bound="hbm", bytes=rec * R + pix_f * N, units=f"{rec} B per binned instance + {pix_f} B per pixel (SURVEY 8d K7 on R')"),
+             launches=5, bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
-             bytes=rec * R + pix_f * N + acc * V, units=f"{rec} B per binned instance + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on R')"),
+             bytes=rec * Rb + pix_f * N + acc * V, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on what the frame takes)"),
         dict(kernel="k_sf_gaussian_backward" if surfel else "k_gaussian_backward", stage="gaussian_bwd", launches=1, bound="hbm",
              bytes=(pin + 4 + (108 if surfel else 92)) * P + (128 if surfel else 64) * V,
              units="inputs + radii in, every returned gradient row out per Gaussian, + the packed gradient line per visible one"),
@@ -301,8 +306,9 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     base_C.profile_enable(False)
     stages = base_C.profile_summary()
     V = int((radii > 0).sum())
-    info["R"] = int(base_C.last_counters()["instances"])
-    table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True)
+    cnt = base_C.last_counters()
+    info["R"] = int(cnt["instances"])
+    table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]))
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess"],
                  "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"]}
     out = {
@@ -311,7 +317,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cfg5: {P} surfels ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, diff_lidargs_surfel_rasterization "
                                f"(2DGS laser-surfel variant), lidar_far=80 lidar_near=0, bg=0",
-                   "visible_surfels": V, "instances_binned": info.get("R", 0), "tile_rows": 4},
+                   "visible_surfels": V, "instances_binned": info.get("R", 0), "patch_instance_pairs_taken": int(cnt["taken_instances"]), "tile_rows": 4},
         "roofline": roofline_object(table, "cfg5", pmc_names),
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
         "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",
@@ -844,7 +850,7 @@ def main():
             "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, {what}, "
                                    f"lidar_far=80 lidar_near=0, bg=0",
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
-                       "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
+                       "patch_instance_pairs_taken": cnt["taken_instances"], "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
                        "forward": "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)",
                        "sharding": "single GPU" if world == 1 else f"{world} range shells"},
         }
@@ -852,7 +858,7 @@ def main():
             # roofline: every launch (group) priced on what IT processes (R' = the instances this frame binned), the longest single
             # launch on top; the reference data flow's bytes (R_ref 16x1 instances) against our time are kept apart, they are a
             # speed-up statement, not a fraction of any roof
-            table = raster_kernel_table(P, cnt["V"], cnt["instances"], N_pix, stages)
+            table = raster_kernel_table(P, cnt["V"], cnt["instances"], N_pix, stages, taken=cnt["taken_instances"])
             fwd_b, bwd_b, _k7, _k8 = reference_dataflow_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
             ref_bytes = fwd_b if fwd_only else fwd_b + bwd_b
             ref_flow = {"frame_bytes_of_the_reference_dataflow": ref_bytes, "GBs_at_our_frame_time": ref_bytes / (ms_per_step * 1e-3) / 1e9,

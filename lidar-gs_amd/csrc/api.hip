@@ -193,10 +193,11 @@ int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* 
     if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
     return (int)e;
 }
-void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans) {   // diagnostics only (lidargs_last_counters)
+void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans, const uint8_t* flags, size_t flags_stride,
+                      int flags_planes) {   // diagnostics only (lidargs_last_counters)
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = R; g_counters[3] = -1; g_counters[4] = TH; g_counters[5] = tiles;
-    g_counters[6] = 0; g_counters[7] = S;
-    g_last_flags = nullptr; g_last_flags_R = 0;
+    g_counters[6] = flags ? -1 : 0; g_counters[7] = S;
+    g_last_flags = flags; g_last_flags_R = (size_t)R; g_last_flags_stride = flags_stride; g_last_flags_planes = flags_planes;
     g_last_totals_dev = (uint32_t*)spans;
 }
 int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }

@@ -217,7 +217,8 @@ int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* 
 // per-stage HIP-event timing (lidargs_profile_*): kind 0 = forward-like call, 1 = backward
 void api_prof_begin(hipStream_t s, int kind);
 void api_prof_mark(const char* name, hipStream_t s);
-void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans);
+void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans, const uint8_t* flags, size_t flags_stride,
+                      int flags_planes);
 int api_encode_rendered(size_t R, int TH);
 size_t api_rendered_capacity(int num_rendered);
 int api_rendered_tile_rows(int num_rendered);
