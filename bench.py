@@ -692,6 +692,9 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="time the rasterizer forward alone (default for cfg2)")
     ap.add_argument("--fwd-bwd", action="store_true", help="forward + backward also for cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", default="wedges", choices=["wedges", "shells"],
+                    help="N > 1: column wedges (every rank renders its pixel columns; image all-gather + gradient all-to-all) or range "
+                         "shells (the north star's cut by range: two-phase transmittance exchange)")
     ap.add_argument("--enqueue-only", action="store_true",
                     help="render with GaussianRasterizer.enqueue_only (lidargs_forward_enqueue: no host wait per frame); single GPU only")
     args = ap.parse_args()
@@ -769,9 +772,16 @@ def main():
         import math
         beams = st["beams"]
         tile_rad = (16 * 2 * math.pi / W, 4 * float(beams[-1] - beams[0]) / max(1, H - 1))      # 16 columns x 4 rows per tile
-        cut = lambda shares: comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
-                                                                     tile_rad=tile_rad, shares=shares), 0)
-        rast = lidargs_dist.ShellRasterizer(settings, comm, edges=cut(None))
+        if args.shard == "shells":
+            cut = lambda shares: comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
+                                                                         tile_rad=tile_rad, shares=shares), 0)
+            rast = lidargs_dist.ShellRasterizer(settings, comm, edges=cut(None))
+        else:
+            def cut(shares):
+                e = torch.tensor(lidargs_dist.wedge_edges(st["means3D"], st["viewmatrix"], W, world, scales=st["scales"], shares=shares),
+                                 dtype=torch.int32, device=dev)
+                return [int(x) for x in comm.broadcast(e, 0).tolist()]
+            rast = lidargs_dist.WedgeRasterizer(settings, comm, edges=cut(None))
 
         def step():
             for t in list(leaves.values()) + [means2D]:
@@ -852,7 +862,8 @@ def main():
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
                        "patch_instance_pairs_taken": cnt["taken_instances"], "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
                        "forward": "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)",
-                       "sharding": "single GPU" if world == 1 else f"{world} range shells"},
+                       "sharding": "single GPU" if world == 1 and not force_shells else
+                                   (f"{world} range shells" if args.shard == "shells" else f"{world} column wedges")},
         }
         if world == 1 and not force_shells:
             # roofline: every launch (group) priced on what IT processes (R' = the instances this frame binned), the longest single

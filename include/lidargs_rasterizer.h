@@ -307,6 +307,50 @@ int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, floa
 int lidargs_shell_compose(int G, int rank, int N, const float* planes, const float* background, float* out_color,
                           float* out_depth, float* out_occ, float* T_final, float* behind, void* stream);
 
+/* ---- column-wedge helpers (multi-GPU, lidar-gs_amd/lidargs_dist.py WedgeRasterizer; no reference counterpart) --------------------
+ * Rank g owns the pixel columns [col_lo, col_hi) (whole 16-pixel tile columns; col_hi may be the image width).  Pixels are
+ * independent, so a rank that bins every Gaussian that can reach its columns renders them exactly as a single GPU would -- same
+ * lists, same order, no transmittance exchange.
+ * lidargs_wedge_select_count flags the Gaussians whose reference rect can reach the wedge (a bound from above on the rect's
+ * half-width from the largest scale; scales / rotations may be NULL = point-like / unit quaternions), leaves flags + offsets in
+ * `scratch` (lidargs_shell_select_scratch_bytes(P) bytes) and returns their number (one host read); lidargs_shell_select_gather
+ * then fills the caller's M-row arrays.
+ * lidargs_forward_wedge = lidargs_forward restricted to the wedge's tile columns (binning AND blend launches cover them only):
+ * out_* hold the wedge's pixel columns, the other columns are NOT written; radii / radii_xy are the Gaussians' full
+ * (unrestricted) values.  Its buffers go to lidargs_backward_wedge with the same columns (lidargs_backward would walk patches
+ * the forward never rendered); upstream gradients are full-size planes of which only the wedge's columns are read.
+ * lidargs_wedge_unpack_grad_rows_add: as lidargs_shell_unpack_grad_rows (blocked layout), but rows carrying the same index are
+ * ADDED: a Gaussian straddling a wedge boundary has partial gradient rows on both sides. */
+int lidargs_wedge_select_count(int P, const float* means3D, const float* scales, const float* rotations, float scale_modifier,
+                               const float* viewmatrix, int width, int col_lo, int col_hi, char* scratch, size_t scratch_bytes,
+                               void* stream);
+int lidargs_forward_wedge(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, const float* background, int width, int height,
+    const float* means3D, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* beam_inclinations, int lidar_far, int lidar_near,
+    int col_lo, int col_hi,
+    float* out_color, float* out_depth, float* out_occ, int* radii, int* radii_xy, int debug, void* stream);
+int lidargs_backward_wedge(
+    int P, int R, const float* background, int width, int height,
+    const float* means3D, const float* colors_precomp, const float* scales, float scale_modifier,
+    const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* beam_inclinations,
+    const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer, int col_lo, int col_hi,
+    const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ,
+    float* dL_dmean2D, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale,
+    float* dL_drot, int debug, void* stream);
+int lidargs_wedge_unpack_grad_rows_add(int n, const float* rows, int P, float* dense, void* stream);
+/* The image exchange of the column wedges, one launch each way: pack = the rank's columns [col_lo, col_hi) of colour[2,H,W],
+ * depth[H,W], occ[H,W] as a dense f32[4][H][wmax] block (zero padding behind col_hi - col_lo); unpack = G gathered blocks
+ * (block g at blocks + g * block_stride floats) -> the full planes, edges_host = G + 1 HOST ints 0 = e_0 < ... < e_G = width. */
+int lidargs_wedge_pack_columns(int height, int width, int col_lo, int col_hi, int wmax, const float* color, const float* depth,
+                               const float* occ, float* out, void* stream);
+int lidargs_wedge_unpack_columns(int G, int height, int width, int wmax, size_t block_stride, const int* edges_host,
+                                 const float* blocks, float* color, float* depth, float* occ, void* stream);
+
 /* Gradient exchange of the range shells (lidargs_dist step 6), one launch each:
  * lidargs_shell_pack_grad_rows    rows f32[M*18] = per selected Gaussian (dL_dmeans3D 3, dL_dmeans2D 4, dL_dcolors 2, dL_dopacity 1,
  *                                 dL_dscales 3, dL_drotations 4, bit pattern of its global index idx[i]): what the all-to-all ships.

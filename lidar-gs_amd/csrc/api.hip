@@ -257,7 +257,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
                  const float* beams, float near_f, float far_f, float shell_lo, float shell_hi, const float* T_in,
                  int transmittance_pass, float* out_color, float* out_depth, float* out_occ, float* T_out, int* radii,
                  int* radii_xy, int debug, hipStream_t stream, long long instance_capacity = 0, int fixed_tile_rows = 0,
-                 unsigned* status_host = nullptr) {
+                 unsigned* status_host = nullptr, int col_lo = -1, int col_hi = -1) {
     // instance_capacity > 0: ENQUEUE-ONLY mode.  Nothing is read back: the binning buffer is sized for `instance_capacity`
     // instances at the caller's tile height, every count the later stages need stays on the device, and the 16 status words
     // (binning.hip k_finish_totals: instances needed / binned, totals per tile height, overflow flag) are copied to
@@ -291,6 +291,12 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     pp.P = P; pp.W = width; pp.H = height; pp.TH = 4; pp.tiles_x = grid4.tiles_x; pp.tiles_y = grid4.tiles_y;
     pp.scale_modifier = scale_modifier;
     pp.near_f = near_f; pp.far_f = far_f; pp.shell_lo = shell_lo; pp.shell_hi = shell_hi;
+    pp.tile_x_lo = 0; pp.tile_x_hi = grid4.tiles_x;
+    if (col_lo >= 0) {                                                   // column wedge: whole 16-pixel tile columns
+        if (col_lo % LG_TILE_W || (col_hi % LG_TILE_W && col_hi != width) || col_hi <= col_lo || col_hi > width)
+            return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: a column wedge must be [multiple of 16, multiple of 16 or width)%s");
+        pp.tile_x_lo = col_lo / LG_TILE_W; pp.tile_x_hi = (col_hi + LG_TILE_W - 1) / LG_TILE_W;
+    }
     const float pi_f = 3.14159265358979323846f;
     pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;                                    // R3/cr/forward.cu:334
     pp.tan_col_step = tanf(2 * pi_f / width);                          // R3/cr/forward.cu:362
@@ -350,7 +356,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
                                  (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);
         if (status_host) LG_HIP(hipMemcpyAsync(status_host, status_dev, LG_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
-    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    lg::TileGrid grid = lg::make_grid(width, height, TH);
+    if (col_lo >= 0) { grid.x_lo = pp.tile_x_lo; grid.x_n = pp.tile_x_hi - pp.tile_x_lo; }   // the blends cover the wedge's own tile columns only
     const uint32_t* R_dev = enqueue_only ? status_dev + 1 : nullptr;       // instances binned = min(needed, capacity), on the device
     g_prof.mark("scan+readback", stream);
 
@@ -424,7 +431,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
                   const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ, float* dL_dmean2D,
                   float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepths, float* dL_dmean3D,
                   float* dL_dsphere_means3D, float* dL_dbasis_u1, float* dL_dbasis_u2, float* dL_dcov3D, float* dL_dscale,
-                  float* dL_drot, int debug, hipStream_t stream) {
+                  float* dL_drot, int debug, hipStream_t stream, int col_lo = -1, int col_hi = -1) {
     (void)colors_precomp; (void)beams;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: bad sizes%s");
     if (P == 0) return 0;   // R3/rasterize_points.cu:177
@@ -437,7 +444,11 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);
     const int TH = rendered_tile_rows(R);                              // the forward's num_rendered carries its tile height
     const size_t Rp = rendered_capacity(R);
-    const lg::TileGrid grid = lg::make_grid(width, height, TH);
+    lg::TileGrid grid = lg::make_grid(width, height, TH);
+    if (col_lo >= 0) {                                                 // a column wedge's buffers: only its own patches were rendered
+        if (col_lo % LG_TILE_W || col_hi <= col_lo || col_hi > width) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: bad column wedge%s");
+        grid.x_lo = col_lo / LG_TILE_W; grid.x_n = (col_hi + LG_TILE_W - 1) / LG_TILE_W - grid.x_lo;
+    }
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
     const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
     const int S = lg::choose_segments(Rp, plan.max_segments);
@@ -551,6 +562,7 @@ int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user,
     pp.scale_modifier = scale_modifier;
     pp.near_f = (float)lidar_near; pp.far_f = (float)lidar_far;
     pp.shell_lo = -std::numeric_limits<float>::infinity(); pp.shell_hi = std::numeric_limits<float>::infinity();
+    pp.tile_x_lo = 0; pp.tile_x_hi = grid.tiles_x;
     const float pi_f = 3.14159265358979323846f;
     pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;
     pp.tan_col_step = tanf(2 * pi_f / width);
@@ -586,6 +598,79 @@ int lidargs_forward_shell(lidargs_alloc_fn geometry_alloc, void* geometry_user, 
                         height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                         beam_inclinations, (float)lidar_near, (float)lidar_far, shell_lo, shell_hi, T_in, transmittance_pass,
                         out_color, out_depth, out_occ, T_out, radii, radii_xy, debug, (hipStream_t)stream);
+}
+
+// ---- column wedges (multi-GPU): rank g bins and renders the tile columns of pixel columns [col_lo, col_hi) only --------------------
+int lidargs_forward_wedge(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                          lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
+                          const float* means3D, const float* colors_precomp, const float* opacities, const float* scales,
+                          float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                          const float* beam_inclinations, int lidar_far, int lidar_near, int col_lo, int col_hi, float* out_color,
+                          float* out_depth, float* out_occ, int* radii, int* radii_xy, int debug, void* stream) {
+    if (col_lo < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_wedge: col_lo < 0%s");
+    const float inf = std::numeric_limits<float>::infinity();
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
+                        height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        beam_inclinations, (float)lidar_near, (float)lidar_far, -inf, inf, nullptr, 0, out_color, out_depth, out_occ,
+                        nullptr, radii, radii_xy, debug, (hipStream_t)stream, 0, 0, nullptr, col_lo, col_hi);
+}
+
+int lidargs_backward_wedge(int P, int R, const float* background, int width, int height, const float* means3D, const float* colors_precomp,
+                           const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                           const float* beam_inclinations, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                           int col_lo, int col_hi, const float* dL_dpix, const float* dL_dout_depth, const float* dL_dout_occ, float* dL_dmean2D,
+                           float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug,
+                           void* stream) {
+    if (col_lo < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward_wedge: col_lo < 0%s");
+    return backward_impl(P, R, background, width, height, means3D, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                         beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, nullptr, nullptr, 0, dL_dpix, dL_dout_depth,
+                         dL_dout_occ, dL_dmean2D, nullptr, dL_dopacity, dL_dcolor, nullptr, dL_dmean3D, nullptr, nullptr, nullptr, dL_dcov3D,
+                         dL_dscale, dL_drot, debug, (hipStream_t)stream, col_lo, col_hi);
+}
+
+int lidargs_wedge_select_count(int P, const float* means3D, const float* scales, const float* rotations, float scale_modifier,
+                               const float* viewmatrix, int width, int col_lo, int col_hi, char* scratch, size_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || col_lo < 0 || col_hi <= col_lo) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select: bad sizes%s");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !scratch) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select: NULL pointer%s");
+    if (scratch_bytes < lidargs_shell_select_scratch_bytes(P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select: scratch too small%s");
+    lg::Carver c(scratch);
+    uint32_t* flags = c.take<uint32_t>((size_t)P);
+    uint32_t* offs = c.take<uint32_t>((size_t)P);
+    uint32_t* total = c.take<uint32_t>(64);
+    uint32_t* scan_scratch = c.take<uint32_t>(lg::scan_scratch_words((size_t)P));
+    lg::launch_wedge_flags(P, means3D, scales, rotations, scale_modifier, viewmatrix, width, col_lo, col_hi, flags, stream);
+    lg::launch_exclusive_scan(flags, offs, (size_t)P, total, scan_scratch, stream);
+    uint32_t total_h = 0;
+    LG_HIP((hipError_t)lg::api_read_words_zero_behind(total, 1, &total_h, nullptr, 0, stream));
+    return (int)total_h;
+}
+
+int lidargs_wedge_pack_columns(int height, int width, int col_lo, int col_hi, int wmax, const float* color, const float* depth, const float* occ,
+                               float* out, void* stream) {
+    if (height <= 0 || width <= 0 || col_lo < 0 || col_hi <= col_lo || col_hi > width || wmax < col_hi - col_lo || !color || !depth || !occ || !out)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_pack_columns: bad argument%s");
+    lg::launch_wedge_pack_columns(height, width, col_lo, col_hi, wmax, color, depth, occ, out, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "wedge pack columns");
+}
+int lidargs_wedge_unpack_columns(int G, int height, int width, int wmax, size_t block_stride, const int* edges_host, const float* blocks,
+                                 float* color, float* depth, float* occ, void* stream) {
+    if (G < 1 || G > 64 || height <= 0 || width <= 0 || wmax <= 0 || !edges_host || !blocks || !color || !depth || !occ || block_stride < (size_t)4 * height * wmax)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_unpack_columns: bad argument%s");
+    if (edges_host[0] != 0 || edges_host[G] != width) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_unpack_columns: edges must run from 0 to width%s");
+    for (int g = 0; g < G; g++)
+        if (edges_host[g + 1] <= edges_host[g] || edges_host[g + 1] - edges_host[g] > wmax) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_unpack_columns: bad edges%s");
+    lg::launch_wedge_unpack_columns(G, height, width, wmax, block_stride, edges_host, blocks, color, depth, occ, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "wedge unpack columns");
+}
+int lidargs_wedge_unpack_grad_rows_add(int n, const float* rows, int P, float* dense, void* stream) {
+    if (n < 0 || P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_unpack_grad_rows_add: bad sizes%s");
+    if (P == 0) return 0;
+    if (!dense || (n > 0 && !rows)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_unpack_grad_rows_add: NULL pointer%s");
+    LG_HIP(hipMemsetAsync(dense, 0, sizeof(float) * 17 * (size_t)P, (hipStream_t)stream));
+    if (n) lg::launch_shell_unpack_rows_add(n, rows, P, dense, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, 0, "wedge unpack rows");
 }
 
 int lidargs_render_shell(int P, int R, const float* background, int width, int height, char* geom_buffer, char* binning_buffer,

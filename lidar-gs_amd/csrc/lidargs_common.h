@@ -178,7 +178,16 @@ struct TileGrid {
     int tiles_x, tiles_y;   // list tiles
     int ref_tiles_x;        // == tiles_x (16-wide), reference grid.x
     int waves_per_tile;
+    int x_lo, x_n;          // tile-column window the blend launches cover (a column wedge's own tiles); 0, tiles_x otherwise
     __host__ __device__ int num_tiles() const { return tiles_x * tiles_y; }
+    // the blend kernels are launched over the window's patches only; this maps a launch-local patch index to the global one
+    // (tile = ty * tiles_x + tx, patch = tile * waves_per_tile + sub), which is what ranges / alive / segment planes are indexed by
+    __host__ __device__ int window_patches() const { return x_n * tiles_y * waves_per_tile; }
+    __host__ __device__ int global_patch(int lp) const {
+        const int lt = lp / waves_per_tile, sub = lp - lt * waves_per_tile;
+        const int ty = lt / x_n, tx = x_lo + (lt - ty * x_n);
+        return (ty * tiles_x + tx) * waves_per_tile + sub;
+    }
 };
 
 inline TileGrid make_grid(int W, int H, int TH) {
@@ -188,6 +197,7 @@ inline TileGrid make_grid(int W, int H, int TH) {
     g.tiles_y = (H + TH - 1) / TH;
     g.ref_tiles_x = g.tiles_x;
     g.waves_per_tile = TH / LG_WAVE_ROWS;
+    g.x_lo = 0; g.x_n = g.tiles_x;
     return g;
 }
 
@@ -196,6 +206,7 @@ struct PreprocessParams {
     float scale_modifier;
     float near_f, far_f;        // reference int near/far converted to float (R3/cr/forward.cu:304)
     float shell_lo, shell_hi;   // extra float range shell: keep lo <= range < hi (multi-GPU); +-inf otherwise
+    int tile_x_lo, tile_x_hi;   // tile-column window [lo, hi) this call bins and renders (multi-GPU column wedges); 0, tiles_x otherwise
     float col_step;             // 2*pi/W        (float, as the reference evaluates it)
     float inv_col_step;         // a bound from above on 1 / col_step (footprint pruning only)
     float tan_col_step;         // tanf(2*pi/W)  (host libm)
@@ -240,7 +251,13 @@ void launch_shell_scatter_i32(int M, const int* idx, const int* src, int P, int*
 void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s);
 void launch_shell_compose(int G, int rank, int N, const float* planes, const float* bg, float* out_color, float* out_depth, float* out_occ,
                           float* T_final, float* behind, hipStream_t s);
+void launch_wedge_pack_columns(int H, int W, int c0, int c1, int wmax, const float* color, const float* depth, const float* occ, float* out, hipStream_t s);
+void launch_wedge_unpack_columns(int G, int H, int W, int wmax, size_t stride, const int* edges, const float* blocks, float* color, float* depth,
+                                 float* occ, hipStream_t s);
 void launch_shell_flags(int P, const float* means3D, const float* view, float lo, float hi, uint32_t* flags, hipStream_t s);
+void launch_wedge_flags(int P, const float* means3D, const float* scales, const float* rotations, float scale_modifier, const float* view,
+                        int W, int col_lo, int col_hi, uint32_t* flags, hipStream_t s);
+void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s);
 void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, const float* means3D, const float* colors, const float* opacities,
                          const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
                          float* o_scales, float* o_rot, hipStream_t s);

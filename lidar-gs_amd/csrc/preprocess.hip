@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
                 ty_hi = min(ty_hi, H - i_lo);
             }
         }
+        tx0 = max(tx0, pp.tile_x_lo); tx1 = min(tx1, pp.tile_x_hi);    // column wedge (multi-GPU): other ranks bin the other tile columns
         if (tx1 <= tx0 || ty_hi <= ty_lo) { tiles = 0; tx0 = tx1 = xmin; ty_lo = ty_hi = ymin; }
         else {
             tiles = (uint32_t)(tx1 - tx0);                              // tile columns; the rows depend on the tile height chosen later
@@ -566,6 +567,43 @@ __global__ void __launch_bounds__(256) k_shell_gather(int P, const uint32_t* __r
     reinterpret_cast<float4*>(o_rot)[c] = reinterpret_cast<const float4*>(rotations)[idx];
 }
 
+// Column-wedge selection (multi-GPU): flag every Gaussian whose reference rect CAN reach pixel columns [col_lo, col_hi).  The exact
+// rect needs K1; this is a bound from above on its half-width, from the largest scale alone:
+//   every entry of the 2x2 footprint is <= A = (s_max^2 |q|^4 + 0.01) / range^2   (quaternion NOT normalised, R3/cr/forward.cu:228),
+//   lambda_max <= 2 A + sqrt(1e-9) (the floor of :328-330 included), radius = sqrt(lambda), rx = ceil(3 radius / tan(2 pi / W)) (:362),
+//   rect columns = [p_c - rx - 16, p_c + rx + 16) (R3/cr/auxiliary.h:80-92), + 2 pixels for atan2f rounding against K1's.
+// A Gaussian flagged here and found out of reach by K1 costs a preprocess row; one NOT flagged can reach no pixel of the wedge.
+__global__ void __launch_bounds__(256) k_wedge_flags(int P, const float* __restrict__ means3D, const float* __restrict__ scales,
+                                                     const float* __restrict__ rotations, float mod, const float* __restrict__ vm, float inv_col_step,
+                                                     float inv_tan_step, float col_lo, float col_hi, uint32_t* __restrict__ flags) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float3 pw = f3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 p = f3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12],
+                        vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+                        vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+    const float d2 = p.x * p.x + p.y * p.y + p.z * p.z;
+    float smax = 0.f, nq = 1.f;
+    if (scales) smax = mod * fmaxf(fabsf(scales[3 * idx]), fmaxf(fabsf(scales[3 * idx + 1]), fabsf(scales[3 * idx + 2])));
+    if (rotations) {
+        const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+        nq = fmaxf(1.f, q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    }
+    const float A = (smax * smax * nq * nq * 1.0001f + 0.01f) / fmaxf(d2, 1e-12f);
+    const float rx = 3.f * sqrtf(2.f * A + 3.2e-5f) * inv_tan_step * 1.001f + 1.f;
+    const float pi_f = 3.14159265358979323846f;
+    const float p_c = (pi_f - atan2f(p.y, p.x)) * inv_col_step;
+    const float reach = rx + 18.f;
+    flags[idx] = (p_c + reach >= col_lo && p_c - reach < col_hi && d2 > 0.f) ? 1u : 0u;
+}
+void launch_wedge_flags(int P, const float* means3D, const float* scales, const float* rotations, float scale_modifier, const float* view,
+                        int W, int col_lo, int col_hi, uint32_t* flags, hipStream_t s) {
+    const float pi_f = 3.14159265358979323846f;
+    const float step = 2 * pi_f / (float)W;
+    hipLaunchKernelGGL(k_wedge_flags, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, scales, rotations, scale_modifier, view, 1.f / step,
+                       1.f / tanf(step), (float)col_lo, (float)col_hi, flags);
+}
+
 void launch_shell_flags(int P, const float* means3D, const float* view, float lo, float hi, uint32_t* flags, hipStream_t s) {
     hipLaunchKernelGGL(k_shell_flags, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, lo, hi, flags);
 }
@@ -618,6 +656,28 @@ __global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* _
     dense[9 * Ps + gs] = r[9];
     d = dense + 10 * Ps + 3 * gs;         d[0] = r[10]; d[1] = r[11]; d[2] = r[12];
     d = dense + 13 * Ps + 4 * gs;         d[0] = r[13]; d[1] = r[14]; d[2] = r[15]; d[3] = r[16];
+}
+// Column wedges: a Gaussian whose rect straddles a wedge boundary has gradient rows on two (or more) ranks; the owner ADDS them.
+// dense = six contiguous blocks (blocked layout), zeroed by the caller.
+__global__ void __launch_bounds__(256) k_shell_unpack_rows_add(int n, const float* __restrict__ rows, int P, float* __restrict__ dense) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rows + 18 * (size_t)i;
+    const int g = __float_as_int(r[17]);
+    if (g < 0 || g >= P) return;
+    const size_t Ps = (size_t)P, gs = (size_t)g;
+    const int off[6] = {0, 3, 7, 9, 10, 13}, wid[6] = {3, 4, 2, 1, 3, 4};
+#pragma unroll
+    for (int b = 0; b < 6; b++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < wid[b]) {
+                const float v = r[off[b] + k];
+                if (v != 0.f) atomicAdd(dense + off[b] * Ps + wid[b] * gs + k, v);
+            }
+}
+void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_unpack_rows_add, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense);
 }
 // counts[d] = #(idx in [d * chunk, (d + 1) * chunk)), idx ascending: the split sizes of the gradient all-to-all
 __global__ void __launch_bounds__(64) k_shell_chunk_counts(int M, const int* __restrict__ idx, int chunk, int world, float* __restrict__ counts) {

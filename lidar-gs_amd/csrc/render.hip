@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
     int patch, seg;                                                    // patch = tile * waves_per_tile + sub
-    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, a.seg_hi - a.seg_lo, patch, seg)) return;
+    if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), a.seg_hi - a.seg_lo, patch, seg)) return;
+    patch = a.grid.global_patch(patch);
     seg += a.seg_lo;
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const uint2 tr = a.ranges[tile];
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
 __global__ void __launch_bounds__(64) k_render_alive(const RenderFwdArgs a) {
     const int lane = threadIdx.x;
     const int S = a.S;
-    const int patch = blockIdx.x;
+    const int patch = a.grid.global_patch(blockIdx.x);
     if (a.seg_lo > 0 && a.alive[patch] != 255) return;                 // closed by an earlier round
     const int wpt = a.grid.waves_per_tile;
     const int tile = patch / wpt, sub = patch - tile * wpt;
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(64) k_render_alive(const RenderFwdArgs a) {
 __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     const int lane = threadIdx.x;
     const int S = a.S;
-    const int patch = blockIdx.x;
+    const int patch = a.grid.global_patch(blockIdx.x);
     const int wpt = a.grid.waves_per_tile;
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const TileGrid& g = a.grid;
@@ -281,19 +282,19 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
 }
 
 void launch_render_alive(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    const unsigned patches = (unsigned)a.grid.window_patches();
     hipLaunchKernelGGL(k_render_alive, dim3(patches), dim3(64), 0, s, a);
 }
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo);
+    const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
     hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
 }
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo);
+    const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
     hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
 }
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned patches = (unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile);
+    const unsigned patches = (unsigned)a.grid.window_patches();
     hipLaunchKernelGGL(k_render_combine, dim3(patches), dim3(64), 0, s, a);
 }
 
@@ -359,7 +360,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
     int patch, seg;
-    if (!block_patch_segment(blockIdx.x, a.grid.num_tiles() * wpt, S, patch, seg)) return;
+    if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), S, patch, seg)) return;
+    patch = a.grid.global_patch(patch);
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const size_t stride = LG_SEG_PLANES * 64;
     // the three things every workgroup decides on are fetched together (the plane address is valid for any slot; what an unwalked
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
 }
 
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.S);
+    const unsigned blocks = segment_grid(a.grid.window_patches(), a.S);
     hipLaunchKernelGGL(k_render_backward, dim3(blocks), dim3(64), 0, s, a);
 }
 
@@ -549,6 +551,49 @@ __global__ void __launch_bounds__(256) k_shell_compose(int G, int rank, int N, c
     out_color[i] = c0 + Tf * g0; out_color[(size_t)N + i] = c1 + Tf * g1;
     out_depth[i] = d; out_occ[i] = 1.f - Tf; T_final[i] = Tf;
     behind[i] = b0; behind[(size_t)N + i] = b1; behind[2 * (size_t)N + i] = bd;
+}
+
+// Column wedges: a rank's own pixel columns [c0, c1) of the four image planes (colour 0/1, depth, occupancy) as one dense
+// [4][H][wmax] block (what the image all-gather ships; columns >= c1 - c0 are padding), and back: G such blocks -> full planes.
+__global__ void __launch_bounds__(256) k_wedge_pack_columns(int H, int W, int c0, int c1, int wmax, const float* __restrict__ color,
+                                                            const float* __restrict__ depth, const float* __restrict__ occ, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 4 * H * wmax;
+    if (i >= n) return;
+    const int x = i % wmax, y = (i / wmax) % H, pl = i / (wmax * H);
+    const int col = c0 + x;
+    float v = 0.f;
+    if (col < c1) {
+        const size_t pix = (size_t)y * W + col;
+        v = pl < 2 ? color[(size_t)pl * H * W + pix] : (pl == 2 ? depth[pix] : occ[pix]);
+    }
+    out[i] = v;
+}
+struct WedgeEdges { int e[65]; };
+__global__ void __launch_bounds__(256) k_wedge_unpack_columns(int G, int H, int W, int wmax, size_t stride, WedgeEdges ed, const float* __restrict__ blocks,
+                                                              float* __restrict__ color, float* __restrict__ depth, float* __restrict__ occ) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)4 * H * W;
+    if (i >= n) return;
+    const int col = (int)(i % W), y = (int)((i / W) % H), pl = (int)(i / ((size_t)W * H));
+    int g = 0;
+    while (g + 1 < G && col >= ed.e[g + 1]) g++;
+    const float v = blocks[(size_t)g * stride + ((size_t)pl * H + y) * wmax + (col - ed.e[g])];
+    const size_t pix = (size_t)y * W + col;
+    if (pl < 2) color[(size_t)pl * H * W + pix] = v;
+    else if (pl == 2) depth[pix] = v;
+    else occ[pix] = v;
+}
+void launch_wedge_pack_columns(int H, int W, int c0, int c1, int wmax, const float* color, const float* depth, const float* occ, float* out, hipStream_t s) {
+    const int n = 4 * H * wmax;
+    hipLaunchKernelGGL(k_wedge_pack_columns, dim3((n + 255) / 256), dim3(256), 0, s, H, W, c0, c1, wmax, color, depth, occ, out);
+}
+void launch_wedge_unpack_columns(int G, int H, int W, int wmax, size_t stride, const int* edges, const float* blocks, float* color, float* depth,
+                                 float* occ, hipStream_t s) {
+    WedgeEdges ed;
+    for (int g = 0; g <= G && g < 65; g++) ed.e[g] = edges[g];
+    const size_t n = (size_t)4 * H * W;
+    hipLaunchKernelGGL(k_wedge_unpack_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, H, W, wmax, stride, ed, blocks, color, depth, occ);
 }
 
 void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s) {

@@ -31,17 +31,20 @@ def _settings(scene, W, H):
                                          t(scene["beams"]), 80, 0, False)
 
 
-def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir, edges=None):
+def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir, edges=None, wedges=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")]
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import lidargs_dist
-    from dist_backend_oracle import OracleShellBackend
+    from dist_backend_oracle import OracleShellBackend, OracleWedgeBackend
     scene = sc.make_scene(kind, P, H, seed, random_view=True)
     scene["bg"] = np.array(bg, np.float32)
-    rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleShellBackend(), grad_sync=grad_sync,
-                                        edges=None if edges is None else torch.tensor(edges, dtype=torch.float32))
+    if wedges:
+        rast = lidargs_dist.WedgeRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleWedgeBackend(), grad_sync=grad_sync, edges=edges)
+    else:
+        rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleShellBackend(), grad_sync=grad_sync,
+                                            edges=None if edges is None else torch.tensor(edges, dtype=torch.float32))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
     leaves = {k: t(scene[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     m2 = torch.zeros(P, 4, requires_grad=True)
@@ -156,3 +159,59 @@ def test_single_comm_world_of_one_equals_plain_oracle():
     parity("color", color.detach().numpy(), ref["color"]); parity("depth", depth.detach().numpy(), ref["depth"])
     parity("dL_dmeans3D", lv["means3D"].grad.numpy(), ref["dL_dmeans3D"])
     parity("dL_dopacity", lv["opacities"].grad.numpy(), ref["dL_dopacity"])
+
+
+# ---- column wedges -------------------------------------------------------------------------------------------------------------
+WEDGE_CASES = [
+    ("w2_shell", 2, "shell", 4000, 16, 256, 61, (0.0, 0.0), "all_reduce", None),
+    ("w2_street_bg", 2, "street", 6000, 16, 256, 62, (0.3, 0.6), "reduce_scatter", None),
+    ("w3_dense", 3, "street", 9000, 16, 160, 63, (0.1, 0.2), "reduce_scatter", None),
+    ("w3_ragged_odd", 3, "shell", 2999, 18, 250, 64, (0.2, 0.0), "reduce_scatter", None),        # W % 16 != 0, P % world != 0
+    ("w4_narrow_first_wedge", 4, "shell", 3000, 16, 256, 65, (0.0, 0.1), "reduce_scatter", [0, 16, 128, 240, 256]),   # one-tile wedges
+    ("w2_none", 2, "shell", 3000, 16, 256, 66, (0.0, 0.0), "none", None),
+]
+
+
+@pytest.mark.parametrize("case", WEDGE_CASES, ids=[c[0] for c in WEDGE_CASES])
+def test_wedge_sharding_matches_single_process(case, tmp_path):
+    """lidargs_dist._WedgeRasterize over gloo: edges, selection bound, image gather, radii max-reduce, gradient all-to-all with
+    addition of the boundary Gaussians' partial rows -- against the plain single-process oracle.  The image must be EXACTLY the
+    single-process one (a rank's lists are the complete lists of its tiles)."""
+    from util import GRAD_KEYS_SR, oracle_forward_backward, parity
+    name, world, kind, P, H, W, seed, bg, grad_sync, edges = case
+    mp.spawn(_worker, args=(world, _free_port(), kind, P, H, W, seed, bg, grad_sync, str(tmp_path), edges, True), nprocs=world, join=True)
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    scene["bg"] = np.array(bg, np.float32)
+    ref = oracle_forward_backward(scene, W, H, sc.upstream_grads(H, W, seed))
+    ranks = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    for r in range(world):
+        np.testing.assert_array_equal(ranks[r]["radii"], ref["radii"])
+        for k in ("color", "depth", "occ"):
+            np.testing.assert_array_equal(ranks[r][k], ref[k])          # bit for bit
+    rows = (P + world - 1) // world
+    for k in GRAD_KEYS_SR:
+        if grad_sync == "all_reduce":
+            full = ranks[0][k]
+            np.testing.assert_array_equal(ranks[1][k], full)
+        elif grad_sync == "none":
+            full = sum(ranks[r][k] for r in range(world))                # partial sums of the wedges' pixels
+        else:
+            full = np.zeros_like(ref[k])
+            for r in range(world):
+                sl = slice(r * rows, min(P, (r + 1) * rows))
+                full[sl] = ranks[r][k][sl]
+                outside = np.ones(P, bool); outside[sl] = False
+                assert float(np.abs(ranks[r][k][outside]).max(initial=0.0)) == 0.0
+        parity(k, full, ref[k])     # dL_dmeans2D[:, 2] is a sum of per-pixel norms (additive over wedges), the rest linear in the pixel sums
+
+
+def test_wedge_edges_cover_and_balance():
+    import lidargs_dist
+    scene = sc.make_scene("street", 50_000, 16, 5)
+    for world, W in ((4, 2650), (8, 2650), (3, 250), (16, 256)):
+        e = lidargs_dist.wedge_edges(torch.from_numpy(scene["means3D"]), torch.from_numpy(scene["viewmatrix"]), W, world,
+                                     scales=torch.from_numpy(scene["scales"]))
+        assert len(e) == world + 1 and e[0] == 0 and e[-1] == W
+        assert all(b > a for a, b in zip(e, e[1:])) and all(x % 16 == 0 for x in e[1:-1])
+    with pytest.raises(ValueError):
+        lidargs_dist.wedge_edges(torch.from_numpy(scene["means3D"]), torch.from_numpy(scene["viewmatrix"]), 64, 8)

@@ -2,7 +2,7 @@
 in-memory communicator that records every collective's result; then each rank is replayed alone (collectives return the
 recorded tensors instantly) and timed.  Gives compute + host glue per rank, i.e. the frame time at world N minus RCCL time.
 
-    python tools/time_shell.py [world] [cfg] [iters]
+    python tools/time_shell.py [world] [cfg] [iters]          (MODE=wedge in the environment: column wedges instead of range shells)
 """
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ import lidargs_scenes as sc
 from test_dist_gpu import ThreadComm
 from util import make_settings, to_torch
 
+MODE = os.environ.get("MODE", "shell")
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
@@ -38,6 +39,8 @@ class RecordComm(ThreadComm):
     def all_reduce(self, t): return self._rec("all_reduce", super().all_reduce(t))
     def all_reduce_async(self, t):
         self.all_reduce(t); return lambda: None
+    def all_reduce_max_async(self, t):
+        super().all_reduce_max_async(t); self.log.append(("all_reduce", t.clone())); return lambda: None
     def all_to_all_rows(self, t, s, r): return self._rec("all_to_all_rows", super().all_to_all_rows(t, s, r))
     def reduce_scatter_rows(self, t): return self._rec("reduce_scatter_rows", super().reduce_scatter_rows(t))
 
@@ -55,14 +58,25 @@ class ReplayComm:
     def all_reduce(self, t): t.copy_(self._next("all_reduce")); return t
     def all_reduce_async(self, t):
         self.all_reduce(t); return lambda: None
+    def all_reduce_max_async(self, t):
+        self.all_reduce(t); return lambda: None
     def all_to_all_rows(self, t, s, r): return self._next("all_to_all_rows")
     def reduce_scatter_rows(self, t): return self._next("reduce_scatter_rows")
     def broadcast(self, t, src=0): return t
 
 
 def frame(mod):
+    if MODE == "wedge":
+        outs, saved = lidargs_dist.wedge_forward(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
+        return lidargs_dist.wedge_backward(mod, saved, gc, gd, go)
     outs, saved = lidargs_dist.shell_forward(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
     return lidargs_dist.shell_backward(mod, saved, gc, gd, go)
+
+
+def make_module(comm, edges):
+    if MODE == "wedge":
+        return lidargs_dist.WedgeRasterizer(settings, comm, edges=edges)
+    return lidargs_dist.ShellRasterizer(settings, comm, edges=edges)
 
 
 def measure(edges):
@@ -77,7 +91,7 @@ def measure(edges):
         try:
             torch.cuda.set_device(0)
             comm = RecordComm(shared, r, logs[r])
-            frame(lidargs_dist.ShellRasterizer(settings, comm, edges=edges))
+            frame(make_module(comm, edges))
         except Exception as e:
             errs.append(e); shared.barrier.abort()
         finally:
@@ -91,7 +105,7 @@ def measure(edges):
     torch.cuda.synchronize()
     walls, stages = [], []
     for r in range(world):
-        mod = lidargs_dist.ShellRasterizer(settings, ReplayComm(r, world, logs[r]), edges=edges)
+        mod = make_module(ReplayComm(r, world, logs[r]), edges)
         for _ in range(3):
             frame(mod)
         torch.cuda.synchronize()
@@ -113,10 +127,13 @@ def measure(edges):
 shares = [1.0 / world] * world
 rounds = int(os.environ.get("TUNE", "0"))
 for it in range(rounds + 1):
-    edges = lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"] if os.environ.get("EDGES", "w") == "w" else None,
-                                     tile_rad=tile_rad, shares=shares)
+    if MODE == "wedge":
+        edges = lidargs_dist.wedge_edges(st["means3D"], st["viewmatrix"], W, world, scales=st["scales"], shares=shares)
+    else:
+        edges = lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"] if os.environ.get("EDGES", "w") == "w" else None,
+                                         tile_rad=tile_rad, shares=shares)
     walls, stages, logs = measure(edges)
-    print(f"world {world} {cfg} round {it}: edges " + " ".join(f"{float(e):.1f}" for e in edges[1:-1]))
+    print(f"{MODE} world {world} {cfg} round {it}: edges " + " ".join(f"{float(e):.1f}" for e in edges[1:-1]))
     print("   per-rank ms (no RCCL time): " + " ".join(f"{t:.3f}" for t in walls) + f"  max {max(walls):.3f}")
     print("   per-rank kernel-stage ms:   " + " ".join(f"{t:.3f}" for t in stages) + f"  max {max(stages):.3f}")
     shares = lidargs_dist.rebalance_shares(shares, stages, fixed=float(os.environ.get("FIXED", "0.25")))
@@ -128,6 +145,6 @@ import json
 out = os.environ.get("OUT_JSON")
 if out:
     json.dump({"what": "per-rank cost of the range-shell path, each virtual rank replayed alone on one MI355X (collectives return recorded "
-                       "tensors instantly: compute + host glue per rank, no RCCL time)", "world": world, "workload": cfg, "iters": iters,
+                       "tensors instantly: compute + host glue per rank, no RCCL time)", "sharding": MODE, "world": world, "workload": cfg, "iters": iters,
                "edges": [float(e) for e in edges[1:-1]], "per_rank_wall_ms_without_rccl": walls, "per_rank_kernel_stage_ms": stages,
                "collective_result_bytes_per_frame": coll}, open(out, "w"), indent=1)
