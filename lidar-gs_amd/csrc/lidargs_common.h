@@ -184,6 +184,7 @@ struct TileGrid {
     // (tile = ty * tiles_x + tx, patch = tile * waves_per_tile + sub), which is what ranges / alive / segment planes are indexed by
     __host__ __device__ int window_patches() const { return x_n * tiles_y * waves_per_tile; }
     __host__ __device__ int global_patch(int lp) const {
+        if (x_n == tiles_x) return lp;                     // the whole image (wave-uniform): no index arithmetic on the common path
         const int lt = lp / waves_per_tile, sub = lp - lt * waves_per_tile;
         const int ty = lt / x_n, tx = x_lo + (lt - ty * x_n);
         return (ty * tiles_x + tx) * waves_per_tile + sub;
@@ -341,7 +342,7 @@ struct RenderBwdArgs {
     const float* behind;           // nullptr or f32[3*N]: colour0, colour1, depth sums of farther shells
     const float* dL_dpix; const float* dL_ddepth; const float* dL_docc;
     float* gacc;                   // [16P], zeroed: slots 0-2 mean2D.xyz, 3-5 conic A,B,C, 6 opacity, 7-8 colour,
-                                   //               9 range, 10-12 du1, 13-15 du2
+                                   //               9 range, 10-12 G1 = sum gx delta, 13-15 G2 = sum gy delta (moments of dL/du1, dL/du2)
 };
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s);
 

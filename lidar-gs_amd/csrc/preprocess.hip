@@ -183,10 +183,17 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         const float conA = cc * det_inv, conB = -cb * det_inv, conC = ca * det_inv;
         const float mid = 0.5f * (ca + cc);
         // :328-330 double max / sqrt (the 1e-9 floor is almost always the active branch)
-        const double disc = sqrt(fmax(1e-9, (double)__fsub_rn(__fmul_rn(mid, mid), det)));
+        // The floor is almost always the active branch of the first max (the footprint's discriminant is O(1e-12)), and sqrt(1e-9)
+        // is a constant: the double-precision square root runs only for the lanes (usually none of the wave) above the floor.
+        const double xd = (double)__fsub_rn(__fmul_rn(mid, mid), det);
+        double disc = 3.1622776601683795e-05;                         // sqrt(1e-9), correctly rounded
+        if (xd > 1e-9) disc = sqrt(xd);
         const float lambda1 = (float)((double)mid + disc);
         const float lambda2 = (float)((double)mid - disc);
-        const float my_radius = (float)sqrt(fmax(1e-9, (double)fmaxf(lambda1, lambda2)));
+        // (float)sqrt((double)L) is the correctly rounded fp32 square root of the float L (53 >= 2 * 24 + 2 bits: rounding twice is
+        // harmless for sqrt), i.e. sqrtf(L); below the floor it is the constant (float)sqrt(1e-9)
+        const float lmax = fmaxf(lambda1, lambda2);
+        const float my_radius = ((double)lmax <= 1e-9) ? (float)3.1622776601683795e-05 : sqrtf(lmax);
 
         const float pi_f = 3.14159265358979323846f;
         const float p_c = (pi_f - atan2f(p.y, p.x)) / pp.col_step;  // :333-334
@@ -363,7 +370,7 @@ void launch_mark_visible(int P, const float* means3D, const float* view, unsigne
 
 // ------------------------------------------------------------------------------------------------
 // K9 + K10 fused.  Inputs are the per-Gaussian sums the backward blend produced (gacc, 64 B per
-// Gaussian): dL/dconic (A,B,C), dL/du1, dL/du2 (direct part), (gx,gy) = dL/dmean2D.xy, dL/drange,
+// Gaussian): dL/dconic (A,B,C), the moments G1, G2 of dL/du1, dL/du2 (direct part), (gx,gy) = dL/dmean2D.xy, dL/drange,
 // dL/dopacity, dL/dcolour.  dL/dsphere is NOT accumulated per pixel: by linearity it equals
 //   gx*u1' + gy*u2' (R3/cr/backward.cu:759-777 sums exactly these per-pixel terms).
 __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
@@ -421,7 +428,18 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float gx = q0.x, gy = q0.y;
     const float gA = q0.w, gB = q1.x, gC = q1.y;
     const float gdep = q2.y;
-    const float3 du1 = f3(q2.z, q2.w, q3.x), du2 = f3(q3.y, q3.z, q3.w);
+    // slots 10-15 hold the moment vectors G1 = sum_pixels gx delta, G2 = sum gy delta; the direct basis gradients the reference
+    // accumulates per pixel (R3/cr/backward.cu:738-750) are  du_i = |u_i'|^2 G_i - 2 u_i' (u_i' . G_i),  u_i' = u_i / (u_i . u_i)
+    float3 du1, du2;
+    {
+        const float w1 = dot3(u1, u1), w2 = dot3(u2, u2);
+        const float j1 = w1 > 0.f ? 1.f / w1 : 0.f, j2 = w2 > 0.f ? 1.f / w2 : 0.f;
+        const float3 G1 = f3(q2.z, q2.w, q3.x), G2 = f3(q3.y, q3.z, q3.w);
+        const float3 p1 = scale3(u1, j1), p2 = scale3(u2, j2);
+        const float c1 = 2.f * dot3(p1, G1), c2 = 2.f * dot3(p2, G2);
+        du1 = f3(j1 * G1.x - c1 * p1.x, j1 * G1.y - c1 * p1.y, j1 * G1.z - c1 * p1.z);
+        du2 = f3(j2 * G2.x - c2 * p2.x, j2 * G2.y - c2 * p2.y, j2 * G2.z - c2 * p2.z);
+    }
     a.dL_dmean2D[4 * idx] = gx; a.dL_dmean2D[4 * idx + 1] = gy; a.dL_dmean2D[4 * idx + 2] = q0.z; a.dL_dmean2D[4 * idx + 3] = 0.f;
     // the reference's scratch gradients (conic, depth, sphere, basis) are materialised only if the caller wants them
     if (a.dL_dconic) { a.dL_dconic[4 * idx] = gA; a.dL_dconic[4 * idx + 1] = gB; a.dL_dconic[4 * idx + 2] = 0.f; a.dL_dconic[4 * idx + 3] = gC; }
