@@ -136,6 +136,34 @@ def pmc_lookup(kind, workload, kernel_names, field):
     return tot, os.path.basename(f)
 
 
+def host_cores():
+    """(usable cores, description): the smaller of the hardware threads, the affinity mask and the cgroup CPU quota -- the GPU
+    boxes show 256 hardware threads but give the container a 16-CPU quota, and 256 busy threads on 16 CPUs time nothing."""
+    n = os.cpu_count() or 1
+    why = f"{n} hardware threads"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, f"affinity mask of {a} CPUs"
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period))
+                if q < n:
+                    n, why = q, f"cgroup CPU quota of {q} (of {os.cpu_count()} hardware threads)"
+            break
+        except Exception:
+            continue
+    return n, why
+
+
 def cpu_baseline(kind, P_full, H, W, seed, fwd_only=False, surfel=False, budget_s=24.0):
     """The CPU legs of SURVEY 8d on this box's host cores, on a bounded 1/20 sample of the workload (same image size):
       (1) the oracle (oracle/lidargs_oracle.c | lidargs_surfel_oracle.c), one thread -> `value`;
@@ -176,7 +204,7 @@ def cpu_baseline(kind, P_full, H, W, seed, fwd_only=False, surfel=False, budget_
             break
     fps = frames / el
     # (1b) every host core: `cores` POSIX threads inside the oracle library (oracle/lgo_bench.c), each rendering its own frames
-    cores = os.cpu_count() or 1
+    cores, cores_why = host_cores()
     per_core = 2 if el / frames < 1.0 else 1
     el_all = lgo.bench_frames(scene, W, H, grads, cores, per_core, fwd_only=fwd_only, surfel=surfel)
     fps_all = cores * per_core / el_all
@@ -184,9 +212,9 @@ def cpu_baseline(kind, P_full, H, W, seed, fwd_only=False, surfel=False, budget_
     out = {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
         "sample": f"{frames} {what} frames of a {P}-{'surfel' if surfel else 'Gaussian'} (1/20) {kind} scene at {H}x{W}, "
-                  f"oracle/{'lidargs_surfel_oracle.c' if surfel else 'lidargs_oracle.c'}, 1 thread of {cores} host cores; linear-in-P "
-                  f"estimate for the full workload: {fps * P / P_full:.4f} frames/s",
-        "all_cores": {"value": fps_all, "unit": "frames/s", "cores": cores,
+                  f"oracle/{'lidargs_surfel_oracle.c' if surfel else 'lidargs_oracle.c'}, 1 thread of {cores} usable host cores ({cores_why}); "
+                  f"linear-in-P estimate for the full workload: {fps * P / P_full:.4f} frames/s",
+        "all_cores": {"value": fps_all, "unit": "frames/s", "cores": cores, "cores_note": cores_why,
                       "sample": f"{cores * per_core} independent {what} frames of the same 1/20 scene, {cores} POSIX threads "
                                 f"x {per_core} frame(s) each (oracle/lgo_bench.c): {el_all:.1f} s; linear-in-P estimate for the full workload: "
                                 f"{fps_all * P / P_full:.3f} frames/s"},
@@ -198,7 +226,7 @@ def cpu_baseline(kind, P_full, H, W, seed, fwd_only=False, surfel=False, budget_
         t2 = time.perf_counter()
         range_view.points_to_pano(pts, H, W, scene["beams"])
         out["projector_points_per_s"] = pts.shape[0] / (time.perf_counter() - t2)
-        # (3) baseline B3: K1 as torch-CPU ops, intra-op threads = all host cores (and 32, in case oversubscription hurts);
+        # (3) baseline B3: K1 as torch-CPU ops, intra-op threads = the usable host cores (and 32, in case oversubscription hurts);
         #     full Gaussian count when one call is estimated under 4 s, else the 1/20 sample scaled linearly
         from oracle import preprocess_torch as pt
         small = {k: torch.from_numpy(scene[k]) for k in ("means3D", "scales", "rotations", "viewmatrix", "beams")}
@@ -256,6 +284,14 @@ def roofline_object(table, workload, blend_kernels_pmc, ref_flow=None):
                 roof["nearer_roof"] = "valu-issue"
             else:
                 roof["nearer_roof"] = "hbm"
+    # the VALU-issue fraction of every launch (group) the committed SQ profile of this workload covers
+    for k in table:
+        names = blend_kernels_pmc.get(k["kernel"])
+        if names:
+            insts, _src = pmc_lookup("sq", workload, names, "SQ_INSTS_VALU")
+            if insts:
+                k["valu_insts"] = insts
+                k["valu_issue_frac"] = insts / (k["ms"] * 1e-3) / 1e9 / VALU_PEAK_GINST
     roof["kernels"] = [{k2: (round(v, 5) if isinstance(v, float) else v) for k2, v in k.items()} for k in table]
     if ref_flow is not None:
         roof["vs_reference_dataflow"] = ref_flow
@@ -309,8 +345,10 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     cnt = base_C.last_counters()
     info["R"] = int(cnt["instances"])
     table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]))
-    pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess"],
-                 "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"]}
+    pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
+                 "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"],
+                 "forward blend group (reference K7): T-only walk x2 + alive + full walk + combine":
+                     [("lg::k_sf_render_forward<true>", 2), "lg::k_sf_alive", "lg::k_sf_render_forward<false>", "lg::k_sf_combine"]}
     out = {
         "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -876,7 +914,9 @@ def main():
                         "note": "SURVEY 8d formula on R_ref (16x1 instances the reference would bin) / our frame time: above the 8000 GB/s "
                                 "peak means the frame is faster than that data flow could be at HBM speed; NOT a roofline fraction"}
             pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
-                         "k_gaussian_backward": ["lg::k_gaussian_backward"]}
+                         "k_gaussian_backward": ["lg::k_gaussian_backward"],
+                         "forward blend group (reference K7): T-only walk x2 + alive + full walk + combine":
+                             [("lg::k_render_forward<true>", 2), "lg::k_render_alive", "lg::k_render_forward<false>", "lg::k_render_combine"]}
             out["roofline"] = roofline_object(table, args.workload, pmc_names, ref_flow)
             # the frame as a whole against the HBM roof, from the same per-launch units (+ what the table leaves out is small)
             own = sum(k["bytes"] for k in table)
