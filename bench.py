@@ -502,6 +502,21 @@ def bench_decode(args):
 
     t_hip, M = timed(lambda: generate_neural_gaussians(camera, pc, vmask, is_training=True), args.steps, args.warmup)
     n_vis = int(vis.sum())
+    # the backward alone (events on the current stream around .backward(): k_ng_backward_mfma + the partial-sum fold + glue)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    t_bwd = 0.0
+    for _ in range(10):
+        for t in leaves:
+            t.grad = None
+        xyz, color, opacity, scaling, rot = generate_neural_gaussians(camera, pc, vmask, is_training=True)[:5]
+        loss = xyz.sum() + color.sum() + opacity.sum() + scaling.sum() + rot.sum()
+        ev[0].record(); loss.backward(); ev[1].record()
+        torch.cuda.synchronize()
+        t_bwd += ev[0].elapsed_time(ev[1]) / 10 * 1e-3
+    # matrix-pipe side of the backward: 1064 v_mfma_f32_32x32x2_f32 per 64-anchor tile (counters: 11.08 M per launch at
+    # 666 k anchors), 4096 flop each, against the 157.3 TFLOP/s dense f32 MFMA peak (MI355X_MICROARCH.md)
+    mfma_insts = ((n_vis + 63) // 64) * 1064
+    mfma_flop = mfma_insts * 4096.0
     # algorithmic bytes: inputs once per visible anchor + the bool mask, outputs once, and the same again (+ upstream gradients,
     # dense input gradients) for the backward; the per-anchor activations the weight-gradient GEMMs read are NOT counted
     fwd_b = N + n_vis * (128 + 12 + 12 * k + 24) + n_vis * k * 5 + M * 52
@@ -513,7 +528,12 @@ def bench_decode(args):
                                   f"add_*_dist on (the reference's default model, arguments/__init__.py:51-79)"},
            "roofline": {"bound": "hbm", "kernel": "k_ng_opacity + k_ng_decode + k_ng_backward + weight-gradient GEMMs (whole step)",
                         "achieved": (fwd_b + bwd_b) / t_hip / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": (fwd_b + bwd_b) / t_hip / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                        "frac": (fwd_b + bwd_b) / t_hip / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "mfma": {"bound": "mfma", "kernel": "k_ng_backward_mfma (the backward call: kernel + partial-sum fold + autograd glue)",
+                                 "achieved": mfma_flop / t_bwd / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": mfma_flop / t_bwd / 1e12 / 157.3,
+                                 "mfma_instructions_per_launch": mfma_insts, "backward_ms": t_bwd * 1e3,
+                                 "note": "f32-in / f32-accumulate v_mfma_f32_32x32x2_f32, 4096 flop per instruction; the products are a third of "
+                                         "the launch, the per-anchor VALU stage and its LDS round trips the rest (DESIGN.md 6b)"}}}
     if not args.no_cpu_baseline:
         from oracle import neural_gaussians as ng
         from oracle import neural_gaussians_torch as ngt
