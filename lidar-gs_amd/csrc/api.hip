@@ -307,8 +307,9 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     LG_STAGE_CHECK("preprocess");
     g_prof.mark("preprocess", stream);
 
-    // 1. range sort of the Gaussians on the low 31 key bits, 3 passes of 11 + 10 + 10: ranges are positive floats (bit 31 clear), and a
-    //    culled Gaussian's key 0xFFFFFFFF still sorts behind every valid one (valid keys are < bits(lidar_far) < 0x7FFFFFFF)
+    // 1. range sort of the Gaussians on the low 31 key bits (8 + 8 + 8 + 7 by default; LIDARGS_RANGE_SORT_BITS=11 gives 11 + 10 + 10, slower
+    //    at 2 M keys): ranges are positive floats (bit 31 clear), and a culled Gaussian's key 0xFFFFFFFF still sorts behind every
+    //    valid one (valid keys are < bits(lidar_far) < 0x7FFFFFFF)
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
                                                  range_sort_bits());
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;

@@ -4,7 +4,10 @@
 
 Values of one dispatch are summed over counter instances (XCDs / SEs) first, then averaged over the dispatches of a kernel.
 Derived per launch where the inputs exist:
-  waves_per_simd_resident = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / (4 SIMDs)   (mean resident waves per SIMD while the SQ is busy)
+  waves_per_simd_resident = 4 * SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 32
+      (SQ_WAVE_CYCLES counts quad-cycles of resident waves, SQ_BUSY_CYCLES is summed over the 32 shader engines of 32 SIMDs each:
+       checked on k_gaussian_backward, a 256-thread streaming kernel, which comes out at 3.5 waves per SIMD; the first round-2
+       profiles (r02_a, r02_e) were written with a formula that gave twice this)
   wait_frac               = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES             (share of wave cycles spent in s_waitcnt)
 """
 import json
@@ -31,7 +34,7 @@ for k in sorted(acc):
     d = {c: round(sum(v) / len(v), 1) for c, v in acc[k].items()}
     d["launches_sampled"] = max(len(v) for v in acc[k].values())
     if d.get("SQ_BUSY_CYCLES") and d.get("SQ_WAVE_CYCLES"):
-        d["waves_per_simd_resident"] = round(d["SQ_WAVE_CYCLES"] / d["SQ_BUSY_CYCLES"] / 4.0, 3)
+        d["waves_per_simd_resident"] = round(4.0 * d["SQ_WAVE_CYCLES"] / d["SQ_BUSY_CYCLES"] / 32.0, 3)
     if d.get("SQ_WAIT_INST_ANY") and d.get("SQ_WAVE_CYCLES"):
         d["wait_frac"] = round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4)
     res["kernels"][k] = d
