@@ -112,7 +112,7 @@ thread_local HostRead t_host_read;
 //   Few nominal segments (R * waves_per_tile / 128 < 150 k: the 2 M-Gaussian 64x2650 frames, range shells of them) leave the
 //   blend latency-bound at ~2 waves per SIMD (SQ_WAVE_CYCLES), so the lists are cut finer: 64-entry segments, 45 slots, a first
 //   round of 5 segments (cfg3 0.99 -> 0.93 ms).  Frames with plenty of segments (8 M Gaussians at 128x4096) lose 10 % that way
-//   and keep 128 / 33 / 3.  The surfel blend does twice the arithmetic per entry and sits in between: 96 / 45 / 4.
+//   and keep 128 / 33 / 3.  The surfel blend does twice the arithmetic per entry and sits in between: 96 / 45 / 6.
 //   LIDARGS_SEG_LEN, LIDARGS_MAX_SEGMENTS, LIDARGS_ROUNDS ("3,9") override.
 SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
     static const int env_len = [] { const char* e = getenv("LIDARGS_SEG_LEN"); return e ? std::max(64, atoi(e)) : 0; }();
@@ -134,7 +134,7 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
     const bool fine = (unsigned long long)R * (unsigned)waves_per_tile / 128ull < 150000ull;
     p.seg_len = fine ? (surfel ? 96 : 64) : LG_SEG_LEN_DEFAULT;
     p.max_segments = fine ? 45 : 33;        // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
-    p.n_rounds = 1; p.rounds[0] = fine ? (surfel ? 4 : 5) : 3;    // one gated round: more rounds add launch tails
+    p.n_rounds = 1; p.rounds[0] = fine ? (surfel ? 6 : 5) : 3;    // one gated round: more rounds add launch tails (surfel: 6 beats 4, 5, 7+; r02)
     if (env_len) p.seg_len = env_len;
     if (env_max) p.max_segments = env_max;
     if (env_nrounds >= 0) { p.n_rounds = env_nrounds; for (int k = 0; k < env_nrounds; k++) p.rounds[k] = env_rounds[k]; }
