@@ -68,7 +68,7 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
              units=f"{pin} B in + 36 B (radii, radii_xy, key, id, spans) out per Gaussian, + record / row span / colours per visible one"),
         dict(kernel="radix sort of the range keys (hist + prefix + scatter) x4", stage="range_sort", launches=12, bound="hbm",
              bytes=4 * 20 * P, units="4 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per Gaussian"),
-        dict(kernel="forward blend group (reference K7): T-only walk x2 + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
+        dict(kernel="forward blend group (reference K7): T-only walks + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
              launches=5, bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
              bytes=rec * Rb + pix_f * N + acc * V, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on what the frame takes)"),
@@ -347,7 +347,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]))
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
                  "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"],
-                 "forward blend group (reference K7): T-only walk x2 + alive + full walk + combine":
+                 "forward blend group (reference K7): T-only walks + alive + full walk + combine":
                      [("lg::k_sf_render_forward<true>", 2), "lg::k_sf_alive", "lg::k_sf_render_forward<false>", "lg::k_sf_combine"]}
     out = {
         "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": 1,
@@ -935,7 +935,7 @@ def main():
                                 "peak means the frame is faster than that data flow could be at HBM speed; NOT a roofline fraction"}
             pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
                          "k_gaussian_backward": ["lg::k_gaussian_backward"],
-                         "forward blend group (reference K7): T-only walk x2 + alive + full walk + combine":
+                         "forward blend group (reference K7): T-only walks + alive + full walk + combine":
                              [("lg::k_render_forward<true>", 2), "lg::k_render_alive", "lg::k_render_forward<false>", "lg::k_render_combine"]}
             out["roofline"] = roofline_object(table, args.workload, pmc_names, ref_flow)
             # the frame as a whole against the HBM roof, from the same per-launch units (+ what the table leaves out is small)

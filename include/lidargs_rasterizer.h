@@ -106,7 +106,8 @@ int lidargs_forward(
  *   tile_rows          list-tile height 4, 8, 16 or 32 (what a previous lidargs_forward chose: 4 << (num_rendered & 3));
  *   status_host        NULL, or 16 words of PINNED host memory the stream fills behind the launches: [0] instances the frame
  *                      needed, [1] instances binned = min(needed, capacity), [2..7] 64-bit instance totals for tile heights
- *                      4 / 8 / 16, [8] = 1 if the capacity was too small, [9] capacity.  Valid once the stream has passed the copy.
+ *                      4 / 8 / 16, [8] = 1 if the capacity was too small, [9] capacity, [10..11] the total for tile height 32.  Valid once the
+ *                      stream has passed the copy.
  * Every count the later stages need stays on the device, so the call only enqueues work (it can be captured in a HIP graph, and
  * the host can run ahead).  If [8] comes back 1, instances were dropped: that frame's outputs are wrong and it must be redone
  * with a larger capacity (or with lidargs_forward).  The returned int and the three buffers go to lidargs_backward as usual. */

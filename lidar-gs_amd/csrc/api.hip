@@ -65,15 +65,22 @@ int forced_tile_rows() {
 }
 int tile_rows() { return forced_tile_rows() ? forced_tile_rows() : 4; }      // what non-adaptive callers (surfel variant) use
 
-// Tile height from the instance totals the preprocess accumulated for heights 4 / 8 / 16.  The blend costs the same for every
+// Tile height from the instance totals the preprocess accumulated for heights 4 / 8 / 16 / 32.  The blend costs the same for every
 // height (per-lane row test + contribution flags), the binning costs ~18 ns per 1000 instances, and a taller tile makes pass 1
 // visit entries that do not reach a patch's rows.  Measured: street scenes (instances shrink 1.27x / 1.46x at 8 / 16 rows) are
-// fastest at 4 rows, an 8 M-Gaussian shell scene with tall footprints (1.74x / 2.77x) at 16 (4.5 -> 3.0 ms).
-int choose_tile_rows(const unsigned long long (&inst)[3]) {
+// fastest at 4 rows, an 8 M-Gaussian shell scene with tall footprints (1.74x / 2.77x) at 16 (4.5 -> 3.0 ms) and, its instances
+// shrinking another 1.5x, at 32 (2.52 -> 2.33 ms: binning 0.53 -> 0.34 ms against 0.05 ms more in pass 1).
+int choose_tile_rows(const unsigned long long (&inst)[4], int height) {
     if (const int f = forced_tile_rows()) return f;
     const double r4 = (double)inst[0];
-    if (inst[2] > 0 && r4 / (double)inst[2] >= 2.2) return 16;
+    if (inst[2] > 0 && r4 / (double)inst[2] >= 2.2) {
+        if (height >= 64 && inst[3] > 0 && (double)inst[2] / (double)inst[3] >= 1.4) return 32;
+        return 16;
+    }
     if (inst[1] > 0 && r4 / (double)inst[1] >= 1.6) return 8;
+    // big frames: binning costs ~16 ns per 1000 instances (emit + two sort passes + ranges), so a smaller ratio already pays when
+    // it removes >= 12 M instances (8 M street Gaussians @ 128x4096: ratio 1.56, 47.5 -> 30.4 M instances, 2.62 -> 2.41 ms)
+    if (inst[1] > 0 && r4 / (double)inst[1] >= 1.4 && inst[0] - inst[1] >= 12000000ull) return 8;
     return 4;
 }
 
@@ -134,7 +141,11 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
     const bool fine = (unsigned long long)R * (unsigned)waves_per_tile / 128ull < 150000ull;
     p.seg_len = fine ? (surfel ? 96 : 64) : LG_SEG_LEN_DEFAULT;
     p.max_segments = fine ? 45 : 33;        // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
-    p.n_rounds = 1; p.rounds[0] = fine ? (surfel ? 6 : 5) : 3;    // one gated round: more rounds add launch tails (surfel: 6 beats 4, 5, 7+; r02)
+    // gated pass-1 rounds.  Fine plan: one round (5 segments; the surfel variant 6: beats 4, 5, 7-12 on cfg5; more rounds only add
+    // launch tails there).  Big frames (128-entry segments): the first segment alone, then segments [1, 4) of the patches still
+    // open, then the rest -- 8 M Gaussians @ 128x4096: shell scene 2.33 -> 2.17 ms, street scene 2.62 -> 2.50 ms against {3}.
+    if (fine) { p.n_rounds = 1; p.rounds[0] = surfel ? 6 : 5; }
+    else { p.n_rounds = 2; p.rounds[0] = 1; p.rounds[1] = 4; }
     if (env_len) p.seg_len = env_len;
     if (env_max) p.max_segments = env_max;
     if (env_nrounds >= 0) { p.n_rounds = env_nrounds; for (int k = 0; k < env_nrounds; k++) p.rounds[k] = env_rounds[k]; }
@@ -331,16 +342,16 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
         // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
         LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, LG_TOTALS_WORDS, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
-        unsigned long long inst[3] = {0, 0, 0};
+        unsigned long long inst[4] = {0, 0, 0, 0};
         for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
             unsigned long long v[4];
             memcpy(v, totals_h + LG_TOTALS_SLOT_WORD + 8 * slot, sizeof v);
-            inst[0] += v[0]; inst[1] += v[1]; inst[2] += v[2];
+            inst[0] += v[0]; inst[1] += v[1]; inst[2] += v[2]; inst[3] += v[3];
         }
         const uint32_t scan_total = totals_h[0];
-        const unsigned long long inst3[3] = {inst[0], inst[1], inst[2]};
-        TH = choose_tile_rows(inst3);
-        unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (unsigned long long)scan_total));
+        const unsigned long long inst4[4] = {inst[0], inst[1], inst[2], inst[3]};
+        TH = choose_tile_rows(inst4, height);
+        unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (TH == 32 ? inst[3] : (unsigned long long)scan_total)));
         if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
         R = (size_t)R64;
         if (TH != th_guess) {

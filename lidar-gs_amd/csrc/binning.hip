@@ -515,9 +515,9 @@ void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, in
 __global__ void __launch_bounds__(64) k_finish_totals(const uint32_t* __restrict__ totals, const unsigned long long* __restrict__ slots, uint32_t cap,
                                                       uint32_t* __restrict__ status) {
     const int lane = threadIdx.x;
-    unsigned long long v[3];
+    unsigned long long v[4];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
+    for (int q = 0; q < 4; q++) {
         v[q] = lane < LG_INST_SLOTS ? slots[4 * lane + q] : 0ull;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
@@ -527,6 +527,7 @@ __global__ void __launch_bounds__(64) k_finish_totals(const uint32_t* __restrict
         status[0] = need; status[1] = need < cap ? need : cap;
         for (int q = 0; q < 3; q++) { status[2 + 2 * q] = (uint32_t)v[q]; status[3 + 2 * q] = (uint32_t)(v[q] >> 32); }
         status[8] = need > cap ? 1u : 0u; status[9] = cap;
+        status[10] = (uint32_t)v[3]; status[11] = (uint32_t)(v[3] >> 32);       // ... and for tile height 32
     }
 }
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s) {

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     }
 
     int out_radius = 0, rx = 0, ry = 0;
-    uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0, t4 = 0, t8 = 0, t16 = 0;
+    uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0, t4 = 0, t8 = 0, t16 = 0, t32 = 0;
     float4 r0, r1, r2, r3;
     bool live = false;
 
@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
             t4 = tiles * (uint32_t)((ty_hi - 1) / 4 - ty_lo / 4 + 1);
             t8 = tiles * (uint32_t)((ty_hi - 1) / 8 - ty_lo / 8 + 1);
             t16 = tiles * (uint32_t)((ty_hi - 1) / 16 - ty_lo / 16 + 1);
+            t32 = tiles * (uint32_t)((ty_hi - 1) / 32 - ty_lo / 32 + 1);
         }
         rspan = (uint32_t)ty_lo | ((uint32_t)ty_hi << 16);
         xsp = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
@@ -315,16 +316,16 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;  // every row written: callers need not pre-zero
     }
     if (FILTER) return;
-    {   // instance totals for tile heights 4 / 8 / 16 (the host picks the height from them, api.hip choose_tile_rows): one block
+    {   // instance totals for tile heights 4 / 8 / 16 / 32 (the host picks the height from them, api.hip choose_tile_rows): one block
         // sum, added to one of LG_INST_SLOTS slots -- 31 k waves adding to the same three words cost a millisecond, 7.8 k blocks
         // spread over 64 lines do not show; the host adds the slots up after its one read
-        __shared__ uint32_t s_part[4][3];
-        uint32_t s4 = t4, s8 = t8, s16 = t16;
+        __shared__ uint32_t s_part[4][4];
+        uint32_t s4 = t4, s8 = t8, s16 = t16, s32 = t32;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s4 += __shfl_xor(s4, o); s8 += __shfl_xor(s8, o); s16 += __shfl_xor(s16, o); }
-        if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = s4; s_part[threadIdx.x >> 6][1] = s8; s_part[threadIdx.x >> 6][2] = s16; }
+        for (int o = 32; o > 0; o >>= 1) { s4 += __shfl_xor(s4, o); s8 += __shfl_xor(s8, o); s16 += __shfl_xor(s16, o); s32 += __shfl_xor(s32, o); }
+        if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = s4; s_part[threadIdx.x >> 6][1] = s8; s_part[threadIdx.x >> 6][2] = s16; s_part[threadIdx.x >> 6][3] = s32; }
         __syncthreads();
-        if (threadIdx.x < 3) {
+        if (threadIdx.x < 4) {
             const uint32_t sum = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
             if (sum) atomicAdd(a.inst_slots + (size_t)(blockIdx.x % LG_INST_SLOTS) * 4 + threadIdx.x, (unsigned long long)sum);
         }

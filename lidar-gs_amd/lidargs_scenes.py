@@ -15,6 +15,9 @@ BASELINE_CONFIGS = {
     "cfg3": ("street", 2_000_000, 64, 2650, 3),
     "cfg4": ("shell", 8_000_000, 128, 4096, 4),
     "cfg5": ("street", 2_000_000, 64, 2650, 5),     # surfel variant: scales[:, :2] are the two surfel axes
+    # not a BASELINE.json config: config 4's size with the street scene's statistics (long lists, early saturation), used to
+    # check that plan / tile-height choices tuned on cfg4's isotropic shell do not hurt the other kind of big frame
+    "cfg4_street": ("street", 8_000_000, 128, 4096, 6),
 }
 
 
