@@ -35,6 +35,7 @@
 // each hold one finished sum and issue ONE atomic instruction into a packed 64-byte accumulator line
 // of that Gaussian.  Entries no lane contributes to are skipped wholesale.
 #include "lidargs_common.h"
+#include <stdlib.h>
 
 namespace lg {
 
@@ -208,6 +209,113 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pass 2 over GROUPS of consecutive segments.  A (patch, segment) workgroup of pass 2 walks only the flagged entries of ~63 list
+// positions -- a few microseconds of work behind three dependent memory round trips (tile range -> ids + flags -> records).  Here a
+// workgroup takes `G` consecutive segments of its patch and walks them one after the other, exactly like the serial reference
+// walk: T is carried across the segment boundaries (only the group's first segment starts from the pass-1 products), the records
+// of the next segment's first chunk are gathered while the current segment's last chunk is composited, and every segment still
+// gets its own planes (partial sums, T_end, T_break, last), which is all the combine and the backward look at.
+__global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs a, const int G) {
+    __shared__ float4 s_rec[4 * LG_CHUNK];
+    __shared__ uint32_t s_span[LG_CHUNK];
+    const int lane = threadIdx.x;
+    const int S = a.S;
+    const int wpt = a.grid.waves_per_tile;
+    const int groups = ((S + G - 1) / G) | 1;                          // odd, like S: keeps the group index decorrelated from the XCD (b % 8)
+    int patch, grp;
+    if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), groups, patch, grp)) return;
+    patch = a.grid.global_patch(patch);
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    const int limit = a.alive ? min(St, (int)a.alive[patch]) : St;     // segments behind the limit were never walked by pass 1
+    const int s0 = grp * G;
+    if (s0 >= limit) return;
+    const int s1 = min(limit, s0 + G);
+    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
+    const size_t pstride = LG_SEG_PLANES * 64;
+    float* pbase = a.seg + (size_t)patch * S * pstride;
+
+    float T = 1.0f;
+    if (a.T_in && px.inside) T = a.T_in[px.pix];
+    for (int k = 0; k < s0; k++) T *= pbase[(size_t)k * pstride + LG_SEG_TPASS * 64 + lane];
+    bool done = !px.inside || T < 0.0001f;
+    const uint8_t* flp = a.flags ? a.flags + (size_t)sub * a.R : nullptr;
+
+    auto fetch = [&](uint2 sr, uint32_t n, uint32_t c, bool& have) {
+        const uint32_t k = c * LG_CHUNK + (uint32_t)lane;
+        const uint32_t g = k < n ? a.point_list[sr.x + k] : 0u;        // not waiting for the flag
+        have = k < n && (!flp || flp[sr.x + k] != 0);
+        return gather_record(a.rec, a.rowspan, g, have);
+    };
+    uint2 sr = segment_range(tr, St, s0);
+    bool have;
+    Staged st = fetch(sr, sr.y - sr.x, 0u, have);
+    bool all_done = false;
+    for (int sg = s0; sg < s1; sg++) {
+        sr = segment_range(tr, St, sg);
+        const uint32_t n = sr.y - sr.x;
+        const uint32_t nchunks = (n + LG_CHUNK - 1) / LG_CHUNK;
+        float T_break = T;
+        v2f C01 = v2f{0.f, 0.f};
+        float D = 0.f;
+        uint32_t last = 0;
+        if (!all_done) {
+            for (uint32_t c = 0; c < nchunks; c++) {
+                __syncthreads();
+                s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
+                s_span[lane] = st.span;
+                unsigned long long todo = __ballot(have);
+                __syncthreads();
+                if (c + 1 < nchunks) st = fetch(sr, n, c + 1, have);
+                else if (sg + 1 < s1) { const uint2 nsr = segment_range(tr, St, sg + 1); st = fetch(nsr, nsr.y - nsr.x, 0u, have); }
+                if (__ballot(!done) == 0ull) { all_done = true; break; }     // R3/cr/forward.cu:559-561 early-out
+                if (todo) {
+                    int j = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
+                    uint32_t span = s_span[j];
+                    while (true) {
+                        const bool more = todo != 0ull;
+                        const int jn = more ? __builtin_ctzll(todo) : j;
+                        todo &= todo - 1ull;
+                        const float4 n0 = s_rec[jn], n1 = s_rec[LG_CHUNK + jn], n2 = s_rec[2 * LG_CHUNK + jn], n3 = s_rec[3 * LG_CHUNK + jn];
+                        const uint32_t nspan = s_span[jn];
+
+                        const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
+                        const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
+                        const v2f d = ex * v2f{r1.x, r1.y} + ey * v2f{r1.z, r1.w} + ez * v2f{r2.x, r2.y};
+                        const v2f qd = v2f{r2.z, r2.w} * d * d;
+                        const float power = -0.5f * (qd.x + qd.y) - r3.x * d.x * d.y;
+                        const float alpha = fminf(0.99f, r3.y * __expf(fminf(power, 0.f)));
+                        const bool hit = !done && rows && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+                        const float test_T = T * (1.f - alpha);
+                        const bool trip = hit && (test_T < 0.0001f);
+                        const bool blend = hit && !trip;
+                        const float w = blend ? alpha * T : 0.f;
+                        C01 += v2f{r3.z, r3.w} * w; D += r0.w * w;
+                        T = blend ? test_T : T;
+                        T_break = hit ? test_T : T_break;
+                        last = blend ? (c * LG_CHUNK + (uint32_t)j + 1u) : last;
+                        done = done || trip;
+
+                        if (!more) break;
+                        r0 = n0; r1 = n1; r2 = n2; r3 = n3; span = nspan; j = jn;
+                    }
+                }
+            }
+        }
+        float* segbase = pbase + (size_t)sg * pstride;
+        segbase[LG_SEG_C0 * 64 + lane] = C01.x;
+        segbase[LG_SEG_C1 * 64 + lane] = C01.y;
+        segbase[LG_SEG_D * 64 + lane] = D;
+        segbase[LG_SEG_TEND * 64 + lane] = T;
+        segbase[LG_SEG_TBREAK * 64 + lane] = T_break;
+        reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = last;
+    }
+}
+
 // Pass 1 runs in rounds of growing depth; after the round that ends at segment `front`, a patch stays open (limit 255) if
 // some pixel's transmittance through those segments (product of the T-only walks, i.e. the hand-over value of a walk from
 // T = 1) is still >= 1e-4 and its list goes on; otherwise its limit becomes `front` and nothing behind is ever walked.
@@ -289,9 +397,23 @@ void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
     hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
 }
+// Segments a pass-2 workgroup walks in a row.  Measured (r02): on the 64-entry plan of the 64x2650 frames grouping LOSES (cfg3 pass 2
+// 0.069 ms at 1, 0.090 at 2, 0.146 at 4: the patches that never saturate set the launch's length, and their walk becomes G times as
+// long), so it stays at 1 = one workgroup per (patch, segment); on the 128-entry plan of the big frames 8 wins (cfg4 0.104 ->
+// 0.077 ms).  LIDARGS_P2_GROUP overrides.
+static int pass2_group(int seg_len) {
+    static const int env = [] { const char* e = getenv("LIDARGS_P2_GROUP"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    return env ? env : (seg_len >= LG_SEG_LEN_DEFAULT ? 8 : 1);
+}
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
-    hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
+    const int G = pass2_group(a.seg_len);
+    if (G <= 1 || a.seg_lo != 0 || a.seg_hi != a.S) {
+        const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
+        hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
+        return;
+    }
+    const unsigned blocks = segment_grid(a.grid.window_patches(), ((a.S + G - 1) / G) | 1);
+    hipLaunchKernelGGL(k_render_pass2_grouped, dim3(blocks), dim3(64), 0, s, a, G);
 }
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned patches = (unsigned)a.grid.window_patches();
