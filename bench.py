@@ -943,7 +943,15 @@ def main():
             out["roofline"]["frame"] = {"algorithmic_bytes_of_the_listed_launches": own, "GBs": own / (ms_per_step * 1e-3) / 1e9,
                                         "frac": own / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         else:
-            out["roofline"] = None
+            # sharded: rank 0's own launches on rank 0's own units (its selected Gaussians, the instances it binned, its columns);
+            # no PMC profile exists for a rank's sub-frame, so HBM fractions only
+            try:
+                n_own = N_pix // world if args.shard == "wedges" else N_pix
+                table = raster_kernel_table(int(cnt["P"]), int(cnt["V"]), int(cnt["instances"]), n_own, stages, taken=int(cnt["taken_instances"]))
+                out["roofline"] = roofline_object(table, "sharded-" + args.workload, {})
+                out["roofline"]["note"] = f"rank 0 of {world}: {int(cnt['P'])} Gaussians selected, {int(cnt['instances'])} instances binned"
+            except Exception as e:      # the headline number must not depend on the diagnostics
+                out["roofline"] = {"error": str(e)}
         out.update({
             "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
             "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",
