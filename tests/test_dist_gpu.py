@@ -376,3 +376,29 @@ def test_cfg4_column_wedges_over_8_virtual_ranks_at_full_size(hip_lib_built):
     full = _assemble(results, plain, P, world, grad_sync)
     for k in GRAD_KEYS_SR:
         parity(f"cfg4 wedges x8 {k} vs plain", full[k], plain[k])
+
+
+def test_wedge_with_no_gaussian_in_reach(hip_lib_built):
+    """A rank whose columns no Gaussian can reach (the scene covers half of the azimuth range): zero selected rows through
+    every stage (select, forward, backward, pack, all-to-all, unpack) -- its columns come out as background, nothing hangs."""
+    from util import hip_forward_backward
+    world, grad_sync = 4, "reduce_scatter"
+    P, H, W, seed = 12000, 16, 512, 91
+    scene = sc.make_scene("shell", P, H, seed)
+    az = np.arctan2(scene["means3D"][:, 1], scene["means3D"][:, 0])
+    keep = (az > 0.2) & (az < 2.9)                      # projected columns ~ [20, 240) of 512: the last two wedges stay empty
+    for k in ("means3D", "scales", "rotations", "opacities", "colors"):
+        scene[k] = np.ascontiguousarray(scene[k][keep])
+    P = int(keep.sum())
+    scene["bg"] = np.array([0.4, 0.1], np.float32)
+    grads = sc.upstream_grads(H, W, seed)
+    plain = hip_forward_backward(scene, W, H, grads)
+    results = _virtual_ranks(world, scene, W, H, grads, grad_sync, True, [0, 128, 256, 384, 512])
+    assert float(np.abs(plain["color"][0][:, 400:] - 0.4).max()) == 0.0     # really empty there
+    for r in range(world):
+        assert np.array_equal(results[r]["radii"], plain["radii"])
+        for k in ("color", "depth", "occ"):
+            assert np.array_equal(results[r][k], plain[k]), (k, r)
+    full = _assemble(results, plain, P, world, grad_sync)
+    for k in GRAD_KEYS_SR:
+        parity(f"{k} vs plain", full[k], plain[k], verbose=False)
