@@ -329,7 +329,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
 
     // 2. instance offsets in range order for the likeliest tile height (queued before the host wait, so that the device has work
     //    while the host decides), then the one host wait (R3/cr/rasterizer_impl.cu:292): the instance totals for tile heights
-    //    4 / 8 / 16 -> tile height, R.  Only if another height wins are the offsets recomputed.
+    //    4 / 8 / 16 / 32 -> tile height, R.  Only if another height wins are the offsets recomputed.
     // the likeliest tile height: the one the last frame on this thread chose (a training loop renders similar frames in a row)
     thread_local int t_last_th = 4;
     int TH;

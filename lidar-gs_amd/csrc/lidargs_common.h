@@ -75,7 +75,7 @@ inline size_t sort_scratch_words(size_t n, int max_bits = SORT_RADIX_BITS) {
 inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 
 // totals: word 0 = instance total of the scan; from word LG_TOTALS_SLOT_WORD on, LG_INST_SLOTS slots of four 64-bit sums (the
-// instance counts for tile heights 4 / 8 / 16 + pad), one 32-byte slot per group of preprocess blocks
+// instance counts for tile heights 4 / 8 / 16 / 32), one 32-byte slot per group of preprocess blocks
 #define LG_INST_SLOTS 64
 #define LG_TOTALS_SLOT_WORD 8
 // word 4 of the totals: 0 while the packed gradient lines (gacc) are all-zero as the forward left them, 1 once a backward has

@@ -69,6 +69,28 @@ __device__ __forceinline__ PixelSetup pixel_setup(const TileGrid& g, const float
 
 struct Staged { float4 a0, a1, a2, a3; uint32_t span; };
 
+// LDS reads that stay where they are written (see the walk below)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v3f __attribute__((ext_vector_type(3)));
+#define LG_LDS_VOLATILE(T) const volatile __attribute__((address_space(3))) T*
+__device__ __forceinline__ float4 lds_ahead(const float4* p) {
+    const v4f v = *(LG_LDS_VOLATILE(v4f))p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float lds_ahead(const float* p) { return *(LG_LDS_VOLATILE(float))p; }
+__device__ __forceinline__ uint32_t lds_ahead(const uint32_t* p) { return *(LG_LDS_VOLATILE(uint32_t))p; }
+
+// The entry's opacity for each of the four pixel rows [y0, y0 + 4) of a patch: 0 on the rows outside its row span [lo, hi).
+__device__ __forceinline__ float4 rows_opacity(uint32_t span, float opacity, int y0) {
+    const int lo = (int)(span & 0xFFFFu), hi = (int)(span >> 16);
+    float4 o;
+    o.x = (y0 >= lo && y0 < hi) ? opacity : 0.f;
+    o.y = (y0 + 1 >= lo && y0 + 1 < hi) ? opacity : 0.f;
+    o.z = (y0 + 2 >= lo && y0 + 2 < hi) ? opacity : 0.f;
+    o.w = (y0 + 3 >= lo && y0 + 3 < hi) ? opacity : 0.f;
+    return o;
+}
+
 // The list entry (a Gaussian id) is fetched for every entry of the chunk, in parallel with its contribution flag, and only the
 // 64-byte record waits for both: one round trip less on the critical path of every chunk.
 __device__ __forceinline__ Staged gather_record(const float4* __restrict__ rec, const uint32_t* __restrict__ rowspan, uint32_t g, bool valid) {
@@ -83,11 +105,97 @@ __device__ __forceinline__ Staged gather_record(const float4* __restrict__ rec, 
     return s;
 }
 // ------------------------------------------------------------------------------------------------
+// The walk over the flagged entries of one chunk parked in LDS, shared by the forward kernels.
+struct WalkState {
+    float T, T_break;                  // transmittance after the last blend | after the last hit (the hand-over value, R3/cr/forward.cu:613-618)
+    v2f C01; float D;                  // colour and range sums
+    uint32_t last;                     // 1-based segment position of the last entry blended
+    bool done;
+    unsigned long long took;           // T-only walk: entries of the chunk some pixel took
+};
+
+// Software-pipelined and branch-free: every per-pixel decision is a select (no exec-mask branching), and two register sets (a, b)
+// are used in turn -- while one entry is evaluated, the record of the next flagged entry is already on its way from LDS into the
+// other set.  The reads are volatile, which keeps each where it is written: a single set handed over at the loop's end costs 13
+// register moves per entry, and plain loads get folded into the top of the next iteration, where every entry waits out the LDS
+// latency.  Only what the pass uses is read (the T-only walk needs neither depth nor colours, nobody the record's opacity): a register
+// that is loaded but never used gets reused as a temporary, and the walk would wait for the load to land first.
+template <bool T_ONLY>
+__device__ __forceinline__ void walk_flagged(unsigned long long todo, const float4* s_rec, const float* oprow, const v2f qxy, const float qz,
+                                             const uint32_t chunk_base, WalkState& w) {
+    struct Rec { float4 r0, r1, r2, r3; float op; };
+    auto read = [&](int jj) {
+        Rec r;
+        const float* f0 = reinterpret_cast<const float*>(&s_rec[jj]);
+        const float* f3 = reinterpret_cast<const float*>(&s_rec[3 * LG_CHUNK + jj]);
+        if (T_ONLY) {
+            const v3f p = *(LG_LDS_VOLATILE(v3f))f0;
+            r.r0 = make_float4(p.x, p.y, p.z, 0.f);
+            r.r3 = make_float4(lds_ahead(f3), 0.f, 0.f, 0.f);
+        } else {
+            r.r0 = lds_ahead(&s_rec[jj]);
+            const v2f col = *(LG_LDS_VOLATILE(v2f))(f3 + 2);
+            r.r3 = make_float4(lds_ahead(f3), 0.f, col.x, col.y);
+        }
+        r.r1 = lds_ahead(&s_rec[LG_CHUNK + jj]); r.r2 = lds_ahead(&s_rec[2 * LG_CHUNK + jj]);
+        r.op = lds_ahead(&oprow[4 * jj]);
+        return r;
+    };
+    auto evaluate = [&](const Rec& r, int jj) {
+        const v2f exy = v2f{r.r0.x, r.r0.y} - qxy;
+        const float ez = r.r0.z - qz;
+        const v2f d = exy.x * v2f{r.r1.x, r.r1.y} + exy.y * v2f{r.r1.z, r.r1.w} + ez * v2f{r.r2.x, r.r2.y};   // (d.x, d.y) = delta . (u1', u2')
+        const v2f qd = v2f{r.r2.z, r.r2.w} * d * d;                                          // (A dx^2, C dy^2)
+        const float power = -0.5f * (qd.x + qd.y) - r.r3.x * d.x * d.y;                       // :601
+        // `op` is the entry's opacity on this pixel's row, 0 outside its row span: alpha = 0 there fails the 1/255 test, which is the
+        // row test of the rect (R3/cr/forward.cu:580-583 via the tile lists) without two compares per pair.  A lane that is done,
+        // or has power > 0 (:602), gets exp(-inf) = 0 the same way, so that `hit` is ONE compare whose lane mask is the ballot itself.
+        const float pw = (!w.done && power <= 0.0f) ? power : -INFINITY;
+        const float alpha = fminf(0.99f, r.op * __expf(pw));
+        const bool hit = alpha >= 1.0f / 255.0f;
+        const float test_T = w.T * (1.f - alpha);
+        const bool trip = hit && (test_T < 0.0001f);
+        if (T_ONLY) {
+            // only the hand-over value is kept: T takes the tripping value too, and the lane is done from there on
+            w.T = hit ? test_T : w.T;
+            w.took |= (__ballot(hit) != 0ull) ? (1ull << jj) : 0ull;
+        } else {
+            const bool blend = hit != trip;
+            const float wt = blend ? alpha * w.T : 0.f;
+            w.C01 += v2f{r.r3.z, r.r3.w} * wt; w.D += r.r0.w * wt;
+            w.T = blend ? test_T : w.T;
+            w.T_break = hit ? test_T : w.T_break;
+            w.last = blend ? (chunk_base + (uint32_t)jj + 1u) : w.last;
+        }
+        w.done = w.done || trip;
+    };
+    int ja = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    Rec ra = read(ja), rb;
+    while (true) {
+        // (the read is not conditional on there being a next entry -- the last one is simply read again: behind a branch, the
+        //  compiler's wait counts have to cover the path without new reads in flight, and the walk waits for every read at once)
+        const bool more_b = todo != 0ull;
+        const int jb = more_b ? __builtin_ctzll(todo) : ja;
+        todo &= todo - 1ull;
+        rb = read(jb);
+        evaluate(ra, ja);
+        if (!more_b) break;
+        const bool more_a = todo != 0ull;
+        ja = more_a ? __builtin_ctzll(todo) : jb;
+        todo &= todo - 1ull;
+        ra = read(ja);
+        evaluate(rb, jb);
+        if (!more_a) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One workgroup = (patch, segment).  T_ONLY: pass 1.  Otherwise pass 2.
 template <bool T_ONLY>
 __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ uint32_t s_span[LG_CHUNK];
+    __shared__ float4 s_oprow[LG_CHUNK];                               // the entry's opacity per pixel row of this patch, 0 outside its row span
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -105,18 +213,18 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     const uint32_t n = sr.y - sr.x;
     float* segbase = a.seg + ((size_t)patch * S + seg) * (LG_SEG_PLANES * 64);
 
+    const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
+    const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
+    const v2f qxy = v2f{px.q.x, px.q.y};
+
     float T = 1.0f;
     if (!T_ONLY) {
         if (a.T_in && px.inside) T = a.T_in[px.pix];
         const float* tp = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + LG_SEG_TPASS * 64 + lane;
         for (int k = 0; k < seg; k++) T *= tp[(size_t)k * (LG_SEG_PLANES * 64)];
     }
-    float T_break = T;
-    v2f C01 = v2f{0.f, 0.f};
-    float D = 0.f;
-    uint32_t last = 0;
     // a lane that starts below the threshold can never blend again: every contributing entry trips T < 1e-4
-    bool done = !px.inside || (!T_ONLY && T < 0.0001f);
+    WalkState w{T, T, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || (!T_ONLY && T < 0.0001f), 0ull};
 
     const uint32_t nchunks = (n + LG_CHUNK - 1) / LG_CHUNK;
     // Contribution flags: pass 1 records, per (sub-patch, entry), whether ANY pixel took the entry; pass 2 (and the
@@ -125,7 +233,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     // pass 2: the flagged set is a superset of what pass 2 / backward can ever blend.
     uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
     uint32_t c_done = 0;                                               // chunks whose flags pass 1 has written
-    if (__ballot(!done) != 0ull && n > 0) {
+    if (__ballot(!w.done) != 0ull && n > 0) {
         auto entry_valid = [&](uint32_t k) { return k < n && (T_ONLY || !fl || fl[k] != 0); };
         auto fetch = [&](uint32_t k, bool& have) {
             const uint32_t g = k < n ? a.point_list[sr.x + k] : 0u;    // not waiting for the flag
@@ -137,55 +245,20 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
         for (uint32_t c = 0; c < nchunks; c++) {
             __syncthreads();
             s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
-            s_span[lane] = st.span;
+            s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
             unsigned long long todo = __ballot(have);                  // entries of this chunk worth visiting
             __syncthreads();
             if (c + 1 < nchunks) {
                 st = fetch((c + 1) * LG_CHUNK + lane, have);
             }
-            if (__ballot(!done) == 0ull) break;                       // R3/cr/forward.cu:559-561 early-out
-            unsigned long long took = 0ull;
+            if (__ballot(!w.done) == 0ull) break;                       // R3/cr/forward.cu:559-561 early-out
+            w.took = 0ull;
             if (todo) {
-                // Software-pipelined, branch-free walk: the LDS reads of the NEXT flagged entry are issued before the
-                // current one is evaluated, and every per-pixel decision is a select (no exec-mask branching).
-                int j = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
-                uint32_t span = s_span[j];
-                while (true) {
-                    const bool more = todo != 0ull;
-                    const int jn = more ? __builtin_ctzll(todo) : j;
-                    todo &= todo - 1ull;
-                    const float4 n0 = s_rec[jn], n1 = s_rec[LG_CHUNK + jn], n2 = s_rec[2 * LG_CHUNK + jn], n3 = s_rec[3 * LG_CHUNK + jn];
-                    const uint32_t nspan = s_span[jn];
-
-                    const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-                    const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-                    const v2f d = ex * v2f{r1.x, r1.y} + ey * v2f{r1.z, r1.w} + ez * v2f{r2.x, r2.y};     // (d.x, d.y) = delta . (u1', u2')
-                    const v2f qd = v2f{r2.z, r2.w} * d * d;                                              // (A dx^2, C dy^2)
-                    const float power = -0.5f * (qd.x + qd.y) - r3.x * d.x * d.y;                         // :601
-                    const float alpha = fminf(0.99f, r3.y * __expf(fminf(power, 0.f)));
-                    const bool hit = !done && rows && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-                    const float test_T = T * (1.f - alpha);
-                    const bool trip = hit && (test_T < 0.0001f);
-                    const bool blend = hit && !trip;
-                    if (!T_ONLY) {
-                        const float w = blend ? alpha * T : 0.f;
-                        C01 += v2f{r3.z, r3.w} * w; D += r0.w * w;
-                    }
-                    T = blend ? test_T : T;
-                    T_break = hit ? test_T : T_break;
-                    last = blend ? (c * LG_CHUNK + (uint32_t)j + 1u) : last;
-                    done = done || trip;
-                    if (T_ONLY) took |= (__ballot(hit) != 0ull) ? (1ull << j) : 0ull;
-
-                    if (!more) break;
-                    r0 = n0; r1 = n1; r2 = n2; r3 = n3; span = nspan; j = jn;
-                }
+                walk_flagged<T_ONLY>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
             }
             if (T_ONLY && fl) {
                 const uint32_t k = c * LG_CHUNK + lane;
-                if (k < n) fl[k] = (uint8_t)((took >> lane) & 1ull);
+                if (k < n) fl[k] = (uint8_t)((w.took >> lane) & 1ull);
                 c_done = c + 1;
             }
         }
@@ -198,14 +271,14 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     }
 
     if (T_ONLY) {
-        segbase[LG_SEG_TPASS * 64 + lane] = T_break;
+        segbase[LG_SEG_TPASS * 64 + lane] = w.T;
     } else {
-        segbase[LG_SEG_C0 * 64 + lane] = C01.x;
-        segbase[LG_SEG_C1 * 64 + lane] = C01.y;
-        segbase[LG_SEG_D * 64 + lane] = D;
-        segbase[LG_SEG_TEND * 64 + lane] = T;
-        segbase[LG_SEG_TBREAK * 64 + lane] = T_break;
-        reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = last;
+        segbase[LG_SEG_C0 * 64 + lane] = w.C01.x;
+        segbase[LG_SEG_C1 * 64 + lane] = w.C01.y;
+        segbase[LG_SEG_D * 64 + lane] = w.D;
+        segbase[LG_SEG_TEND * 64 + lane] = w.T;
+        segbase[LG_SEG_TBREAK * 64 + lane] = w.T_break;
+        reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = w.last;
     }
 }
 
@@ -218,7 +291,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
 // gets its own planes (partial sums, T_end, T_break, last), which is all the combine and the backward look at.
 __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs a, const int G) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ uint32_t s_span[LG_CHUNK];
+    __shared__ float4 s_oprow[LG_CHUNK];
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -240,7 +313,10 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
     float T = 1.0f;
     if (a.T_in && px.inside) T = a.T_in[px.pix];
     for (int k = 0; k < s0; k++) T *= pbase[(size_t)k * pstride + LG_SEG_TPASS * 64 + lane];
-    bool done = !px.inside || T < 0.0001f;
+    WalkState w{T, T, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || T < 0.0001f, 0ull};
+    const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
+    const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
+    const v2f qxy = v2f{px.q.x, px.q.y};
     const uint8_t* flp = a.flags ? a.flags + (size_t)sub * a.R : nullptr;
 
     auto fetch = [&](uint2 sr, uint32_t n, uint32_t c, bool& have) {
@@ -257,62 +333,27 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
         sr = segment_range(tr, St, sg);
         const uint32_t n = sr.y - sr.x;
         const uint32_t nchunks = (n + LG_CHUNK - 1) / LG_CHUNK;
-        float T_break = T;
-        v2f C01 = v2f{0.f, 0.f};
-        float D = 0.f;
-        uint32_t last = 0;
+        w.T_break = w.T; w.C01 = v2f{0.f, 0.f}; w.D = 0.f; w.last = 0u;
         if (!all_done) {
             for (uint32_t c = 0; c < nchunks; c++) {
                 __syncthreads();
                 s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
-                s_span[lane] = st.span;
-                unsigned long long todo = __ballot(have);
+                s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
+                const unsigned long long todo = __ballot(have);
                 __syncthreads();
                 if (c + 1 < nchunks) st = fetch(sr, n, c + 1, have);
                 else if (sg + 1 < s1) { const uint2 nsr = segment_range(tr, St, sg + 1); st = fetch(nsr, nsr.y - nsr.x, 0u, have); }
-                if (__ballot(!done) == 0ull) { all_done = true; break; }     // R3/cr/forward.cu:559-561 early-out
-                if (todo) {
-                    int j = __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
-                    uint32_t span = s_span[j];
-                    while (true) {
-                        const bool more = todo != 0ull;
-                        const int jn = more ? __builtin_ctzll(todo) : j;
-                        todo &= todo - 1ull;
-                        const float4 n0 = s_rec[jn], n1 = s_rec[LG_CHUNK + jn], n2 = s_rec[2 * LG_CHUNK + jn], n3 = s_rec[3 * LG_CHUNK + jn];
-                        const uint32_t nspan = s_span[jn];
-
-                        const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-                        const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-                        const v2f d = ex * v2f{r1.x, r1.y} + ey * v2f{r1.z, r1.w} + ez * v2f{r2.x, r2.y};
-                        const v2f qd = v2f{r2.z, r2.w} * d * d;
-                        const float power = -0.5f * (qd.x + qd.y) - r3.x * d.x * d.y;
-                        const float alpha = fminf(0.99f, r3.y * __expf(fminf(power, 0.f)));
-                        const bool hit = !done && rows && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-                        const float test_T = T * (1.f - alpha);
-                        const bool trip = hit && (test_T < 0.0001f);
-                        const bool blend = hit && !trip;
-                        const float w = blend ? alpha * T : 0.f;
-                        C01 += v2f{r3.z, r3.w} * w; D += r0.w * w;
-                        T = blend ? test_T : T;
-                        T_break = hit ? test_T : T_break;
-                        last = blend ? (c * LG_CHUNK + (uint32_t)j + 1u) : last;
-                        done = done || trip;
-
-                        if (!more) break;
-                        r0 = n0; r1 = n1; r2 = n2; r3 = n3; span = nspan; j = jn;
-                    }
-                }
+                if (__ballot(!w.done) == 0ull) { all_done = true; break; }   // R3/cr/forward.cu:559-561 early-out
+                if (todo) walk_flagged<false>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
             }
         }
         float* segbase = pbase + (size_t)sg * pstride;
-        segbase[LG_SEG_C0 * 64 + lane] = C01.x;
-        segbase[LG_SEG_C1 * 64 + lane] = C01.y;
-        segbase[LG_SEG_D * 64 + lane] = D;
-        segbase[LG_SEG_TEND * 64 + lane] = T;
-        segbase[LG_SEG_TBREAK * 64 + lane] = T_break;
-        reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = last;
+        segbase[LG_SEG_C0 * 64 + lane] = w.C01.x;
+        segbase[LG_SEG_C1 * 64 + lane] = w.C01.y;
+        segbase[LG_SEG_D * 64 + lane] = w.D;
+        segbase[LG_SEG_TEND * 64 + lane] = w.T;
+        segbase[LG_SEG_TBREAK * 64 + lane] = w.T_break;
+        reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = w.last;
     }
 }
 
