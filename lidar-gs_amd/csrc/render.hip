@@ -517,7 +517,7 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
 
 __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ uint32_t s_span[LG_CHUNK];
+    __shared__ float4 s_oprow[LG_CHUNK];                               // opacity per pixel row of the patch, 0 outside the entry's row span
     __shared__ uint32_t s_gid[LG_CHUNK];
     const int lane = threadIdx.x;
     const int S = a.S;
@@ -575,6 +575,9 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     v2f lc01 = v2f{0.f, 0.f}, ldo = v2f{0.f, 1.f};                    // last entry's (colour0, colour1) | (range, 1)
 
     const int c_last = (int)((n_max - 1) / LG_CHUNK);
+    const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
+    const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
+    const v2f qxy = v2f{px.q.x, px.q.y};
     const uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
     auto gather = [&](int c, Staged& st, uint32_t& gid, bool& have) {
         const uint32_t k = (uint32_t)c * LG_CHUNK + lane;
@@ -589,35 +592,38 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     for (int c = c_last; c >= 0; c--) {
         __syncthreads();
         s_rec[lane] = st.a0; s_rec[LG_CHUNK + lane] = st.a1; s_rec[2 * LG_CHUNK + lane] = st.a2; s_rec[3 * LG_CHUNK + lane] = st.a3;
-        s_span[lane] = st.span; s_gid[lane] = gid;
+        s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0); s_gid[lane] = gid;
         unsigned long long todo = __ballot(have);
         __syncthreads();
         if (c > 0) gather(c - 1, st, gid, have);
         if (todo == 0ull) continue;
-        // back to front, software-pipelined: the next flagged entry's LDS reads are in flight while this one is evaluated
-        int j = 63 - __builtin_clzll(todo);
-        todo &= ~(1ull << j);
-        float4 r0 = s_rec[j], r1 = s_rec[LG_CHUNK + j], r2 = s_rec[2 * LG_CHUNK + j], r3 = s_rec[3 * LG_CHUNK + j];
-        uint32_t span = s_span[j];
-        while (true) {
-            const bool more = todo != 0ull;
-            const int jn = more ? 63 - __builtin_clzll(todo) : j;
-            todo &= ~(1ull << jn);
-            const float4 n0 = s_rec[jn], n1 = s_rec[LG_CHUNK + jn], n2 = s_rec[2 * LG_CHUNK + jn], n3 = s_rec[3 * LG_CHUNK + jn];
-            const uint32_t nspan = s_span[jn];
-
+        // back to front, software-pipelined like the forward walk (walk_flagged): two register sets, unconditional look-ahead reads
+        struct Rec { float4 r0, r1, r2, r3; float op; };
+        auto read = [&](int jj) {
+            Rec r;
+            const float* f3 = reinterpret_cast<const float*>(&s_rec[3 * LG_CHUNK + jj]);
+            r.r0 = lds_ahead(&s_rec[jj]); r.r1 = lds_ahead(&s_rec[LG_CHUNK + jj]); r.r2 = lds_ahead(&s_rec[2 * LG_CHUNK + jj]);
+            const v2f col = *(LG_LDS_VOLATILE(v2f))(f3 + 2);
+            r.r3 = make_float4(lds_ahead(f3), 0.f, col.x, col.y);
+            r.op = lds_ahead(&oprow[4 * jj]);
+            return r;
+        };
+        auto evaluate = [&](const Rec& r, int j) {
             const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based position inside the segment
-            const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-            const float ex = r0.x - px.q.x, ey = r0.y - px.q.y, ez = r0.z - px.q.z;
-            const v2f ux = v2f{r1.x, r1.y}, uy = v2f{r1.z, r1.w}, uz = v2f{r2.x, r2.y};        // (u1', u2') by component
+            const v2f exy = v2f{r.r0.x, r.r0.y} - qxy;
+            const float ex = exy.x, ey = exy.y, ez = r.r0.z - px.q.z;
+            const v2f ux = v2f{r.r1.x, r.r1.y}, uy = v2f{r.r1.z, r.r1.w}, uz = v2f{r.r2.x, r.r2.y};        // (u1', u2') by component
             const v2f d = ex * ux + ey * uy + ez * uz;
             const float dx = d.x, dy = d.y;
-            const float A = r2.z, B = r3.x, Cc = r2.w, op = r3.y;
+            const float A = r.r2.z, B = r.r3.x, Cc = r.r2.w;
+            const float op = r.op;                                    // the entry's opacity on this pixel's row, 0 outside its row span
             const float power = -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy;
-            const float G = __expf(fminf(power, 0.f));
+            // :650 skip entries behind the last contributor; :673-679 the forward's skips.  As in the forward walk the tests are folded
+            // into the exponent (exp(-inf) = 0 -> alpha 0) and the row test into `op`, so that `contrib` is one compare = the ballot.
+            const float pw = ((e < n_lane) && (power <= 0.0f)) ? power : -INFINITY;
+            const float G = __expf(pw);
             const float alpha_raw = fminf(0.99f, op * G);
-            // :650 skip entries behind the last contributor; :673-679 the forward's skips
-            const bool contrib = rows && (e < n_lane) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+            const bool contrib = alpha_raw >= 1.0f / 255.0f;
             if (__ballot(contrib) != 0ull) {                           // wave-uniform
                 // A pixel that does not blend this entry treats it as an alpha = 0 entry: T / (1 - 0) = T, the "colour
                 // behind" recurrences commit the previous entry (the same operation, just earlier) and then carry
@@ -630,7 +636,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 const float keep = 1.f - last_alpha;
                 const v2f a01 = last_alpha * lc01 + keep * acc01;      // :694-714
                 const v2f ado = last_alpha * ldo + keep * accdo;
-                const v2f c01 = v2f{r3.z, r3.w}, cdo = v2f{r0.w, 1.f};
+                const v2f c01 = v2f{r.r3.z, r.r3.w}, cdo = v2f{r.r0.w, 1.f};
                 const v2f t4 = (c01 - a01) * g01 + (cdo - ado) * gdo;
                 float dL_dalpha = (t4.x + t4.y) * Tn;
                 dL_dalpha -= T_final * inv * bgdot;                    // :727
@@ -675,8 +681,23 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                     atomicAdd(a.gacc + 16 * (size_t)s_gid[j] + slot, mine);
                 }
             }
-            if (!more) break;
-            r0 = n0; r1 = n1; r2 = n2; r3 = n3; span = nspan; j = jn;
+        };
+        auto top = [&](unsigned long long& m) { const int jj = 63 - __builtin_clzll(m); m &= ~(1ull << jj); return jj; };
+        int ja = top(todo);
+        Rec ra = read(ja), rb;
+        while (true) {
+            const bool more_b = todo != 0ull;
+            int jb = ja;
+            if (more_b) jb = top(todo);
+            rb = read(jb);
+            evaluate(ra, ja);
+            if (!more_b) break;
+            const bool more_a = todo != 0ull;
+            ja = jb;
+            if (more_a) ja = top(todo);
+            ra = read(ja);
+            evaluate(rb, jb);
+            if (!more_a) break;
         }
     }
 }
