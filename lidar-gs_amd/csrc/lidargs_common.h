@@ -357,4 +357,29 @@ struct GaussBwdArgs {
 };
 void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s);
 
+// ---- device-side helpers shared by the blend kernels (render.hip, surfel.hip) ----------------------------------------
+#ifdef __HIPCC__
+// LDS reads that stay where they are written (see walk_flagged in render.hip)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v3f __attribute__((ext_vector_type(3)));
+#define LG_LDS_VOLATILE(T) const volatile __attribute__((address_space(3))) T*
+__device__ __forceinline__ float4 lds_ahead(const float4* p) {
+    const v4f v = *(LG_LDS_VOLATILE(v4f))p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float lds_ahead(const float* p) { return *(LG_LDS_VOLATILE(float))p; }
+__device__ __forceinline__ uint32_t lds_ahead(const uint32_t* p) { return *(LG_LDS_VOLATILE(uint32_t))p; }
+
+// The entry's opacity for each of the four pixel rows [y0, y0 + 4) of a patch: 0 on the rows outside its row span [lo, hi).
+__device__ __forceinline__ float4 rows_opacity(uint32_t span, float opacity, int y0) {
+    const int lo = (int)(span & 0xFFFFu), hi = (int)(span >> 16);
+    float4 o;
+    o.x = (y0 >= lo && y0 < hi) ? opacity : 0.f;
+    o.y = (y0 + 1 >= lo && y0 + 1 < hi) ? opacity : 0.f;
+    o.z = (y0 + 2 >= lo && y0 + 2 < hi) ? opacity : 0.f;
+    o.w = (y0 + 3 >= lo && y0 + 3 < hi) ? opacity : 0.f;
+    return o;
+}
+#endif
+
 }  // namespace lg

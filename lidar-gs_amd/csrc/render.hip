@@ -69,28 +69,6 @@ __device__ __forceinline__ PixelSetup pixel_setup(const TileGrid& g, const float
 
 struct Staged { float4 a0, a1, a2, a3; uint32_t span; };
 
-// LDS reads that stay where they are written (see the walk below)
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v3f __attribute__((ext_vector_type(3)));
-#define LG_LDS_VOLATILE(T) const volatile __attribute__((address_space(3))) T*
-__device__ __forceinline__ float4 lds_ahead(const float4* p) {
-    const v4f v = *(LG_LDS_VOLATILE(v4f))p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float lds_ahead(const float* p) { return *(LG_LDS_VOLATILE(float))p; }
-__device__ __forceinline__ uint32_t lds_ahead(const uint32_t* p) { return *(LG_LDS_VOLATILE(uint32_t))p; }
-
-// The entry's opacity for each of the four pixel rows [y0, y0 + 4) of a patch: 0 on the rows outside its row span [lo, hi).
-__device__ __forceinline__ float4 rows_opacity(uint32_t span, float opacity, int y0) {
-    const int lo = (int)(span & 0xFFFFu), hi = (int)(span >> 16);
-    float4 o;
-    o.x = (y0 >= lo && y0 < hi) ? opacity : 0.f;
-    o.y = (y0 + 1 >= lo && y0 + 1 < hi) ? opacity : 0.f;
-    o.z = (y0 + 2 >= lo && y0 + 2 < hi) ? opacity : 0.f;
-    o.w = (y0 + 3 >= lo && y0 + 3 < hi) ? opacity : 0.f;
-    return o;
-}
-
 // The list entry (a Gaussian id) is fetched for every entry of the chunk, in parallel with its contribution flag, and only the
 // 64-byte record waits for both: one round trip less on the critical path of every chunk.
 __device__ __forceinline__ Staged gather_record(const float4* __restrict__ rec, const uint32_t* __restrict__ rowspan, uint32_t g, bool valid) {
@@ -104,6 +82,7 @@ __device__ __forceinline__ Staged gather_record(const float4* __restrict__ rec, 
     }
     return s;
 }
+
 // ------------------------------------------------------------------------------------------------
 // The walk over the flagged entries of one chunk parked in LDS, shared by the forward kernels.
 struct WalkState {

@@ -223,9 +223,13 @@ __device__ __forceinline__ SfStaged sf_gather(const uint32_t* __restrict__ point
 }
 
 // Everything up to alpha for one (pixel, surfel) pair: R2/cr/forward.cu:426-490 == R2/cr/backward.cu:283-340.
+// `op` is the surfel's opacity on this pixel's row, 0 outside its row span (rows_opacity): alpha = 0 there fails the 1/255 test,
+// which is the row test of the rect without two compares per pair.  `gate` (the lane still walks | the entry is not behind the
+// pixel's last contributor) and the reference's other skips (:459 cos2 == 0, :476 depth < near, :483 power > 0) go into the
+// exponent the same way -- exp(-inf) = 0 -- so that `ok` is ONE compare whose lane mask is the ballot itself.
 struct SfPair { bool ok, in3d; float sx, sy, dxp, dyp, lam2, cos2, depth, G, alpha; float3 dp; };
 
-__device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r1, float4 r2, float4 r3, float4 r4) {
+__device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, float op, bool gate) {
     SfPair o;
     const float3 n = sf3(r3.x, r3.y, r3.z);
     o.cos2 = sdot(px.p, n);
@@ -242,9 +246,10 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
     o.in3d = front && (rho3d <= rho2d);
     o.depth = o.in3d ? o.lam2 : r4.z;
     const float power = -0.5f * rho;
-    o.G = __expf(fminf(power, 0.f));
-    o.alpha = fminf(0.99f, r1.z * o.G);
-    o.ok = (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N) && !(power > 0.f) && !(o.alpha < 1.0f / 255.0f);
+    const bool pass = gate && (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N) && !(power > 0.f);
+    o.G = __expf(pass ? power : -INFINITY);
+    o.alpha = fminf(0.99f, op * o.G);
+    o.ok = o.alpha >= 1.0f / 255.0f;
     return o;
 }
 
@@ -271,7 +276,7 @@ struct SfFwdArgs {
 template <bool T_ONLY>
 __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
     __shared__ float4 s_rec[5 * SF_CHUNK];
-    __shared__ uint32_t s_span[SF_CHUNK];
+    __shared__ float4 s_oprow[SF_CHUNK];                               // opacity per pixel row of the patch, 0 outside the surfel's row span
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -298,6 +303,8 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
     uint32_t last = 0, med_c = 0;
     bool done = !px.inside || (!T_ONLY && T < 0.0001f);
     uint8_t* fl = a.flags + (size_t)sub * a.R + sr.x;
+    const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
+    const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
     const uint32_t nchunks = (n + SF_CHUNK - 1) / SF_CHUNK;
     uint32_t c_done = 0;
     if (__ballot(!done) != 0ull && n > 0) {
@@ -307,43 +314,84 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
         for (uint32_t c = 0; c < nchunks; c++) {
             __syncthreads();
             s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
-            s_rec[4 * SF_CHUNK + lane] = st.a4; s_span[lane] = st.span;
+            s_rec[4 * SF_CHUNK + lane] = st.a4; s_oprow[lane] = rows_opacity(st.span, st.a1.z, y0);
             unsigned long long todo = __ballot(have);
             __syncthreads();
             if (c + 1 < nchunks) { const uint32_t k = (c + 1) * SF_CHUNK + lane; have = entry_valid(k); st = sf_gather(a.point_list, a.rec, a.rowspan, sr.x + k, have); }
             if (__ballot(!done) == 0ull) break;
             unsigned long long took = 0ull;
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
+            if (todo) {
+                // Two register sets used in turn, look-ahead reads that stay where they are written, only the fields the pass uses:
+                // see walk_flagged (render.hip), which this follows.
+                struct Rec { float4 r0, r1, r2, r3, r4; float op; };
+                auto read = [&](int jj) {
+                    Rec r;
+                    const float* f1 = reinterpret_cast<const float*>(&s_rec[SF_CHUNK + jj]);
+                    const float* f2 = reinterpret_cast<const float*>(&s_rec[2 * SF_CHUNK + jj]);
+                    const float* f4 = reinterpret_cast<const float*>(&s_rec[4 * SF_CHUNK + jj]);
+                    r.r0 = lds_ahead(&s_rec[jj]);
+                    const sf2 tz = *(LG_LDS_VOLATILE(sf2))f1;
+                    r.r3 = lds_ahead(&s_rec[3 * SF_CHUNK + jj]);
+                    const v3f c4 = *(LG_LDS_VOLATILE(v3f))f4;
+                    r.r4 = make_float4(c4.x, c4.y, c4.z, 0.f);
+                    if (T_ONLY) {
+                        const v3f tw = *(LG_LDS_VOLATILE(v3f))f2;
+                        r.r1 = make_float4(tz.x, tz.y, 0.f, 0.f);
+                        r.r2 = make_float4(tw.x, tw.y, tw.z, 0.f);
+                    } else {
+                        r.r1 = make_float4(tz.x, tz.y, 0.f, lds_ahead(f1 + 3));
+                        r.r2 = lds_ahead(&s_rec[2 * SF_CHUNK + jj]);
+                    }
+                    r.op = lds_ahead(&oprow[4 * jj]);
+                    return r;
+                };
+                auto evaluate = [&](const Rec& r, int j) {
+                    const SfPair q = sf_pair(px, r.r0, r.r1, r.r2, r.r3, r.r4, r.op, !done);
+                    const bool hit = q.ok;
+                    const float test_T = T * (1.f - q.alpha);
+                    const bool trip = hit && test_T < 0.0001f;
+                    if (T_ONLY) {
+                        // only the hand-over value is kept: T takes the tripping value too, and the lane is done from there on
+                        T = hit ? test_T : T;
+                        took |= (__ballot(hit) != 0ull) ? (1ull << j) : 0ull;
+                    } else {
+                        const bool blend = hit != trip;
+                        const float w = blend ? q.alpha * T : 0.f;
+                        const float m = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / q.depth);
+                        // distortion with the segment-local prefix sums; the combine adds the terms in the sums of the segments
+                        // in front (the expression is linear in them), R2/cr/forward.cu:497-499
+                        dist += blend ? (m * m * (1.f - T) + M2 - 2.f * m * M1) * w : 0.f;
+                        D += blend ? q.depth * w : 0.f;
+                        M1 += blend ? m * w : 0.f;
+                        M2 += blend ? m * m * w : 0.f;
+                        const bool is_med = blend && T > 0.5f;                             // :503-507
+                        med = is_med ? q.depth : med;
+                        med_c = is_med ? (sr.x - tr.x + c * SF_CHUNK + (uint32_t)j + 1u) : med_c;
+                        N0 += r.r3.x * w; N1 += r.r3.y * w; N2 += r.r3.z * w;
+                        C0 += r.r1.w * w; C1 += r.r2.w * w;
+                        T = blend ? test_T : T;
+                        T_break = hit ? test_T : T_break;
+                        last = blend ? (c * SF_CHUNK + (uint32_t)j + 1u) : last;
+                    }
+                    done = done || trip;
+                };
+                int ja = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const float4 r0 = s_rec[j], r1 = s_rec[SF_CHUNK + j], r2 = s_rec[2 * SF_CHUNK + j], r3 = s_rec[3 * SF_CHUNK + j], r4 = s_rec[4 * SF_CHUNK + j];
-                const uint32_t span = s_span[j];
-                const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-                const SfPair q = sf_pair(px, r0, r1, r2, r3, r4);
-                const bool hit = !done && rows && q.ok;
-                const float test_T = T * (1.f - q.alpha);
-                const bool trip = hit && test_T < 0.0001f;
-                const bool blend = hit && !trip;
-                if (!T_ONLY) {
-                    const float w = blend ? q.alpha * T : 0.f;
-                    const float m = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / q.depth);
-                    // distortion with the segment-local prefix sums; the combine adds the terms in the sums of the segments
-                    // in front (the expression is linear in them), R2/cr/forward.cu:497-499
-                    dist += blend ? (m * m * (1.f - T) + M2 - 2.f * m * M1) * w : 0.f;
-                    D += blend ? q.depth * w : 0.f;
-                    M1 += blend ? m * w : 0.f;
-                    M2 += blend ? m * m * w : 0.f;
-                    const bool is_med = blend && T > 0.5f;                             // :503-507
-                    med = is_med ? q.depth : med;
-                    med_c = is_med ? (sr.x - tr.x + c * SF_CHUNK + (uint32_t)j + 1u) : med_c;
-                    N0 += r3.x * w; N1 += r3.y * w; N2 += r3.z * w;
-                    C0 += r1.w * w; C1 += r2.w * w;
+                Rec ra = read(ja), rb;
+                while (true) {
+                    const bool more_b = todo != 0ull;
+                    const int jb = more_b ? __builtin_ctzll(todo) : ja;
+                    todo &= todo - 1ull;
+                    rb = read(jb);
+                    evaluate(ra, ja);
+                    if (!more_b) break;
+                    const bool more_a = todo != 0ull;
+                    ja = more_a ? __builtin_ctzll(todo) : jb;
+                    todo &= todo - 1ull;
+                    ra = read(ja);
+                    evaluate(rb, jb);
+                    if (!more_a) break;
                 }
-                T = blend ? test_T : T;
-                T_break = hit ? test_T : T_break;
-                last = blend ? (c * SF_CHUNK + (uint32_t)j + 1u) : last;
-                done = done || trip;
-                if (T_ONLY) took |= (__ballot(hit) != 0ull) ? (1ull << j) : 0ull;
             }
             if (T_ONLY) {
                 const uint32_t k = c * SF_CHUNK + lane;
@@ -354,7 +402,7 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
     }
     if (T_ONLY) {
         for (uint32_t c = c_done; c < nchunks; c++) { const uint32_t k = c * SF_CHUNK + lane; if (k < n) fl[k] = 0; }
-        segbase[SF_SEG_TPASS * 64 + lane] = T_break;
+        segbase[SF_SEG_TPASS * 64 + lane] = T;
     } else {
         segbase[SF_SEG_C0 * 64 + lane] = C0; segbase[SF_SEG_C1 * 64 + lane] = C1; segbase[SF_SEG_D * 64 + lane] = D;
         segbase[SF_SEG_N0 * 64 + lane] = N0; segbase[SF_SEG_N1 * 64 + lane] = N1; segbase[SF_SEG_N2 * 64 + lane] = N2;
@@ -488,7 +536,7 @@ struct SfBwdArgs {
 // value; the "what lies behind" recurrences are seeded with the partial sums of the segments behind it, as seen from there.
 __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     __shared__ float4 s_rec[5 * SF_CHUNK];
-    __shared__ uint32_t s_span[SF_CHUNK];
+    __shared__ float4 s_oprow[SF_CHUNK];                               // opacity per pixel row of the patch, 0 outside the surfel's row span
     __shared__ uint32_t s_gid[SF_CHUNK];
     const int lane = threadIdx.x;
     const int S = a.S;
@@ -543,6 +591,8 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     float last_alpha = 0.f, l_c0 = 0.f, l_d = 0.f, l_n0 = 0.f, l_n1 = 0.f, l_n2 = 0.f;
 
     const int c_last = (int)((n_max - 1) / SF_CHUNK);
+    const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
+    const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
     const uint8_t* fl = a.flags + (size_t)sub * a.R + sr.x;
     bool have;
     auto gather = [&](int c) {
@@ -554,7 +604,7 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     for (int c = c_last; c >= 0; c--) {
         __syncthreads();
         s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
-        s_rec[4 * SF_CHUNK + lane] = st.a4; s_span[lane] = st.span; s_gid[lane] = st.gid;
+        s_rec[4 * SF_CHUNK + lane] = st.a4; s_oprow[lane] = rows_opacity(st.span, st.a1.z, y0); s_gid[lane] = st.gid;
         unsigned long long todo = __ballot(have);
         __syncthreads();
         if (c > 0) st = gather(c - 1);
@@ -564,10 +614,9 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             const uint32_t e_loc = (uint32_t)c * SF_CHUNK + j;       // position inside the segment
             const uint32_t e = seg_off + e_loc;                       // 0-based list position == the reference's `contributor`
             const float4 r0 = s_rec[j], r1 = s_rec[SF_CHUNK + j], r2 = s_rec[2 * SF_CHUNK + j], r3 = s_rec[3 * SF_CHUNK + j], r4 = s_rec[4 * SF_CHUNK + j];
-            const uint32_t span = s_span[j];
-            const bool rows = ((uint32_t)px.y >= (span & 0xFFFFu)) && ((uint32_t)px.y < (span >> 16));
-            const SfPair q = sf_pair(px, r0, r1, r2, r3, r4);
-            const bool contrib = rows && (e_loc < n_lane) && q.ok;
+            const float op = oprow[4 * j];                              // the surfel's opacity on this pixel's row, 0 outside its row span
+            const SfPair q = sf_pair(px, r0, r1, r2, r3, r4, op, e_loc < n_lane);
+            const bool contrib = q.ok;
             if (__ballot(contrib) == 0ull) continue;
             // A pixel that does not blend this entry treats it as an alpha = 0 entry (as in render.hip): T / (1 - 0) = T, the
             // recurrences commit the previous entry and then carry (alpha 0, this entry), which the next step folds away
@@ -597,7 +646,7 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             dL_dalpha *= Tn;
             dL_dalpha -= T_final * inv * bgdot;
             dL_dalpha = contrib ? dL_dalpha : 0.f;
-            const float dL_dG = r1.z * dL_dalpha;
+            const float dL_dG = op * dL_dalpha;
             dL_dz += w * g_depth;                                       // :420
             // 3-D branch: gradient through s = (dp.Tu', dp.Tv'), dp = lam2 p - Tw, lam2 = (Tw.n)/(p.n)   (:427-563); its three
             // roots are zeroed for a 2-D-branch pair, the 2-D branch's two for a 3-D one
