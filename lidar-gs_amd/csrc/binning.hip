@@ -105,7 +105,7 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 // LSD radix sort pass on (u32 key, u32 value) pairs.  A block = 4 waves = 4096 consecutive keys, wave w
 // owning the w-th 1024-key slice so that the order (wave, round, lane) IS the key order (stability).
 //   k_radix_hist          per-block digit histogram -> hist[digit][block]
-//   k_radix_digit_prefix  one wave per digit: exclusive prefix over the blocks in place, digit totals -> tot[digit]
+//   k_radix_digit_prefix  one workgroup per digit: exclusive prefix over the blocks in place, digit totals -> tot[digit]
 //   k_radix_scatter       ranks its keys (ballot match-any per round, per-wave LDS counters), sorts the block into
 //                         LDS, then streams it out: consecutive threads write consecutive addresses inside each digit
 //                         run, so the pass writes whole lines instead of 4-byte crumbs (measured 5x write
@@ -137,34 +137,41 @@ __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__
     for (int d = tid; d < BINS; d += 256) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
 }
 
-// One wave per (digit, chunk of `chunk` blocks): exclusive prefix of the block histograms inside the chunk, in place, and the
-// chunk's sum -> part[digit][chunk].  With a single chunk (chunk >= nblocks) the sum is the digit total itself.
-template <int MAXG>
+// One workgroup (4 waves) per (digit, chunk of `chunk` blocks): exclusive prefix of the block histograms inside the chunk, in place,
+// and the chunk's sum -> part[digit][chunk].  With a single chunk (chunk >= nblocks) the sum is the digit total itself.
+// Each wave takes a quarter of the chunk (WG groups of 64 blocks, WG = 2, 4 or 8 picked at launch): every load is issued before
+// the first scan and the groups' scans are independent chains; only the carries are sequential, and the quarters meet through LDS.
+// (One wave per row walked 22 groups one after the other at 1381 blocks: 12 us of a 50-us sort pass on 64 waves.)
+template <int WG>
 __global__ void __launch_bounds__(256) k_radix_digit_prefix(uint32_t* __restrict__ hist, unsigned nblocks, int bins, unsigned chunk,
                                                             unsigned chunks, uint32_t* __restrict__ part) {
-    const int lane = threadIdx.x & 63;
-    const unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const unsigned d = w / chunks, c = w - d * chunks;
-    if (d >= (unsigned)bins) return;
+    __shared__ uint32_t wtot[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned d = blockIdx.x / chunks, c = blockIdx.x - d * chunks;
     uint32_t* row = hist + (size_t)d * nblocks;
     const unsigned lo = c * chunk, hi = min(nblocks, lo + chunk);
-    // A chunk is at most 2 * SORT_PREFIX_CHUNK blocks = 32 groups of 64 (MAXG: 8, 16 or 32, picked at launch): every load is issued before the first scan and the
-    // groups' scans are independent chains (walking the groups one after the other, load -> six dependent cross-lane steps
-    // -> store, made this ~9 us launch the slowest part of a sort pass on small inputs); only the carries are sequential.
-    uint32_t v[MAXG], inc[MAXG];
-    const unsigned groups = (hi - lo + 63u) / 64u;                     // wave-uniform
+    const unsigned wlo = lo + (unsigned)w * (WG * 64);                 // this wave's quarter
+    uint32_t v[WG], inc[WG];
 #pragma unroll
-    for (int g = 0; g < MAXG; g++) { const unsigned b = lo + (unsigned)g * 64 + lane; v[g] = b < hi ? row[b] : 0u; }
+    for (int g = 0; g < WG; g++) { const unsigned b = wlo + (unsigned)g * 64 + lane; v[g] = b < hi ? row[b] : 0u; }
 #pragma unroll
-    for (int g = 0; g < MAXG; g++) inc[g] = (unsigned)g < groups ? wave_incl_scan(v[g], lane) : 0u;
-    uint32_t carry = 0;
+    for (int g = 0; g < WG; g++) inc[g] = wave_incl_scan(v[g], lane);
+    uint32_t carry = 0, excl[WG];
 #pragma unroll
-    for (int g = 0; g < MAXG; g++) {
-        const unsigned b = lo + (unsigned)g * 64 + lane;
-        if (b < hi) row[b] = carry + inc[g] - v[g];
+    for (int g = 0; g < WG; g++) {
+        excl[g] = carry + inc[g] - v[g];
         carry += __shfl(inc[g], 63);
     }
-    if (lane == 0) part[(size_t)d * chunks + c] = carry;
+    if (lane == 0) wtot[w] = carry;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int q = 0; q < w; q++) off += wtot[q];
+#pragma unroll
+    for (int g = 0; g < WG; g++) {
+        const unsigned b = wlo + (unsigned)g * 64 + lane;
+        if (b < hi) row[b] = off + excl[g];
+    }
+    if (threadIdx.x == 0) part[(size_t)d * chunks + c] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
 }
 // Second level (only when there is more than one chunk): exclusive prefix of the chunk sums per digit, in place; digit total.
 // A single wave used to walk all the blocks of a digit: 33 k blocks at 138 M keys = 0.3 ms per pass on 128 waves.
@@ -324,11 +331,11 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
     hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb);
     // single level: the chunk sums ARE the digit totals, written straight to `tot`
-    const dim3 pgrid((BINS * chunks + 3) / 4);
+    const dim3 pgrid(BINS * chunks);
     uint32_t* const pout = two_level ? part : tot;
-    if (chunk <= 8 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
-    else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<16>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
-    else hipLaunchKernelGGL(k_radix_digit_prefix<32>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    if (chunk <= 8 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<2>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<4>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    else hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
     hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
                        two_level ? part : (const uint32_t*)nullptr, chunk, chunks);
