@@ -322,7 +322,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     //    at 2 M keys): ranges are positive floats (bit 31 clear), and a culled Gaussian's key 0xFFFFFFFF still sorts behind every
     //    valid one (valid keys are < bits(lidar_far) < 0x7FFFFFFF)
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
-                                                 range_sort_bits());
+                                                 range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS);   // (the scratch is carved for 11-bit digits)
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
     LG_STAGE_CHECK("range sort");
     g_prof.mark("range_sort", stream);

@@ -14,6 +14,7 @@
 // Ranks inside a wave come from ballot-matching the digit bits (wave-wide match-any), so every pass is
 // stable by construction; blocks sort locally in LDS and write whole digit runs.
 #include "lidargs_common.h"
+#include <stdlib.h>
 
 namespace lg {
 
@@ -112,24 +113,24 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 //                         amplification with direct per-key scatter).
 // `n_dev` (nullable): the pair count lives on the device (enqueue-only forward: the host never learns it); the launch then covers the
 // capacity `n` and the blocks behind *n_dev see no keys (their histograms are zero, their scatter retires).
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev, int shift,
                                                     uint32_t* __restrict__ hist, unsigned nblocks) {
     constexpr int BINS = 1 << BITS;
     if (n_dev) n = min(n, (size_t)*n_dev);
     __shared__ uint32_t cnt[BINS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t base = (size_t)blockIdx.x * SORT_CHUNK + (size_t)w * (64 * SORT_ITEMS);
-    uint32_t k[SORT_ITEMS];
+    const size_t base = (size_t)blockIdx.x * (256 * ITEMS) + (size_t)w * (64 * ITEMS);
+    uint32_t k[ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
         k[r] = i < n ? keys[i] : 0u;
     }
     for (int d = tid; d < BINS; d += 256) cnt[d] = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
         if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (BINS - 1)], 1u);
     }
@@ -191,28 +192,29 @@ __global__ void __launch_bounds__(256) k_radix_chunk_prefix(uint32_t* __restrict
     if (lane == 0) tot[d] = carry;
 }
 
-template <int BITS>
+template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        size_t n, const uint32_t* __restrict__ n_dev, int shift, const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
                                                        const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks) {
     constexpr int BINS = 1 << BITS;
+    constexpr int CHUNK = 256 * ITEMS;                    // keys per block
     constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
     if (n_dev) n = min(n, (size_t)*n_dev);
-    if ((size_t)blockIdx.x * SORT_CHUNK >= n) return;     // wave-uniform, before any barrier
+    if ((size_t)blockIdx.x * CHUNK >= n) return;     // wave-uniform, before any barrier
     __shared__ uint32_t run[SORT_WAVES][BINS];   // per-wave running digit counts, then wave bases
     __shared__ uint32_t dbase[BINS];             // block-local start of each digit run
     __shared__ uint32_t gbase[BINS];             // global start of this block's run of each digit
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t s_key[SORT_CHUNK];
-    __shared__ uint32_t s_val[SORT_CHUNK];
+    __shared__ uint32_t s_key[CHUNK];
+    __shared__ uint32_t s_val[CHUNK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t blk_base = (size_t)blockIdx.x * SORT_CHUNK;
-    const size_t base = blk_base + (size_t)w * (64 * SORT_ITEMS);
-    uint32_t k[SORT_ITEMS], v[SORT_ITEMS], pos[SORT_ITEMS];
+    const size_t blk_base = (size_t)blockIdx.x * CHUNK;
+    const size_t base = blk_base + (size_t)w * (64 * ITEMS);
+    uint32_t k[ITEMS], v[ITEMS], pos[ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
         const bool valid = i < n;
         k[r] = valid ? keys_in[i] : 0u;
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     // A. wave-local stable ranks
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const bool valid = base + (size_t)r * 64 + lane < n;
         const uint32_t d = (k[r] >> shift) & (BINS - 1);
         unsigned long long peers = __ballot(valid);
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 
     // C. park the block in LDS in sorted order
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         if (base + (size_t)r * 64 + lane < n) {
             const uint32_t d = (k[r] >> shift) & (BINS - 1);
             const uint32_t p = run[w][d] + pos[r];
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     __syncthreads();
 
     // D. stream out: thread i writes element i of the sorted block to its digit run
-    const uint32_t count = (uint32_t)(n - blk_base < (size_t)SORT_CHUNK ? n - blk_base : (size_t)SORT_CHUNK);
+    const uint32_t count = (uint32_t)(n - blk_base < (size_t)CHUNK ? n - blk_base : (size_t)CHUNK);
     for (uint32_t i = tid; i < count; i += 256) {
         const uint32_t kk = s_key[i];
         const uint32_t d = (kk >> shift) & (BINS - 1);
@@ -317,19 +319,23 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     }
 }
 
-template <int BITS>
-static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
-                       uint32_t* scratch, hipStream_t s, int max_bits) {
-    const size_t SORT_MAX_BINS = (size_t)1 << max_bits;          // the scratch layout of sort_scratch_words(n, max_bits)
-    const unsigned nb = (unsigned)sort_blocks(n);
+// Keys per sort block: 4096 (16 per lane), or 2048 for inputs up to 4 M pairs when the scratch has room for twice the blocks -- at
+// 2 M keys 489 blocks of 4 waves leave half of the 1024 SIMDs without a wave, and each block's load -> rank -> park -> stream-out
+// chain is the launch's length.
+template <int BITS, int ITEMS>
+static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
+                             uint32_t* scratch, hipStream_t s, int scratch_bits) {
+    const size_t cap_bins = (size_t)1 << scratch_bits;           // the scratch layout of sort_scratch_words(n, scratch_bits)
+    constexpr size_t CHUNK = 256 * ITEMS;
+    const unsigned nb = (unsigned)((n + CHUNK - 1) / CHUNK);
     constexpr int BINS = 1 << BITS;
     uint32_t* hist = scratch;
-    uint32_t* tot = scratch + (size_t)SORT_MAX_BINS * nb;
-    uint32_t* part = tot + SORT_MAX_BINS;
+    uint32_t* tot = scratch + cap_bins * sort_blocks(n);
+    uint32_t* part = tot + cap_bins;
     const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
     const bool two_level = chunks_all > 2;
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
-    hipLaunchKernelGGL(k_radix_hist<BITS>, dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb);
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb);
     // single level: the chunk sums ARE the digit totals, written straight to `tot`
     const dim3 pgrid(BINS * chunks);
     uint32_t* const pout = two_level ? part : tot;
@@ -337,14 +343,26 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
     else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<4>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     else hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
-    hipLaunchKernelGGL(k_radix_scatter<BITS>, dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
                        two_level ? part : (const uint32_t*)nullptr, chunk, chunks);
+}
+template <int BITS>
+static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
+                       uint32_t* scratch, hipStream_t s, int scratch_bits) {
+    static const int env = [] { const char* e = getenv("LIDARGS_SORT_ITEMS"); return e ? atoi(e) : 0; }();   // 8 / 16 forces the block size
+    const bool room = BITS + 1 <= scratch_bits;                  // twice the blocks x BINS <= the histogram area (and the chunk sums likewise)
+    const bool half = room && (env ? env == 8 : n <= ((size_t)4 << 20));
+    if constexpr (BITS <= 10) {
+        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); return; }
+    }
+    radix_pass_items<BITS, SORT_ITEMS>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits);
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev) {
+                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits) {
     if (n == 0 || end_bit <= 0) return 0;
     if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
+    if (scratch_bits < max_bits) scratch_bits = max_bits;
     int cur = 0;
     int shift = 0;
     while (shift < end_bit) {
@@ -355,17 +373,17 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
         const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
         switch (bits) {
-            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
-            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, max_bits); break;
+            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
         }
         shift += bits;
         cur ^= 1;
