@@ -204,6 +204,18 @@ int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* 
     if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
     return (int)e;
 }
+// The same read in two halves: the copy is queued at `begin`, more work is queued behind it, and `end` waits for the copy only.
+int api_read_words_begin(const uint32_t* dev, int n, hipStream_t s) {
+    if (n > HostRead::WORDS || !t_host_read.ready()) return (int)hipErrorOutOfMemory;
+    hipError_t e = hipMemcpyAsync(t_host_read.words, dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(t_host_read.copied, s);
+    return (int)e;
+}
+int api_read_words_end(int n, uint32_t* out) {
+    const hipError_t e = hipEventSynchronize(t_host_read.copied);
+    if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
+    return (int)e;
+}
 void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans, const uint8_t* flags, size_t flags_stride,
                       int flags_planes) {   // diagnostics only (lidargs_last_counters)
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = R; g_counters[3] = -1; g_counters[4] = TH; g_counters[5] = tiles;
@@ -321,49 +333,43 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 1. range sort of the Gaussians on the low 31 key bits (8 + 8 + 8 + 7 by default; LIDARGS_RANGE_SORT_BITS=11 gives 11 + 10 + 10, slower
     //    at 2 M keys): ranges are positive floats (bit 31 clear), and a culled Gaussian's key 0xFFFFFFFF still sorts behind every
     //    valid one (valid keys are < bits(lidar_far) < 0x7FFFFFFF)
+    //    Everything the host decides on -- the instance totals per tile height -- is known once the preprocess has run: their copy
+    //    (2 KB into pinned memory) is queued here, the sort behind it, and the host waits for the copy while the sort runs.
+    if (!enqueue_only) LG_HIP((hipError_t)lg::api_read_words_begin(geom.totals, LG_TOTALS_WORDS, stream));
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
                                                  range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS);   // (the scratch is carved for 11-bit digits)
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
     LG_STAGE_CHECK("range sort");
     g_prof.mark("range_sort", stream);
 
-    // 2. instance offsets in range order for the likeliest tile height (queued before the host wait, so that the device has work
-    //    while the host decides), then the one host wait (R3/cr/rasterizer_impl.cu:292): the instance totals for tile heights
-    //    4 / 8 / 16 / 32 -> tile height, R.  Only if another height wins are the offsets recomputed.
-    // the likeliest tile height: the one the last frame on this thread chose (a training loop renders similar frames in a row)
-    thread_local int t_last_th = 4;
+    // 2. the one host wait (R3/cr/rasterizer_impl.cu:292), for a copy that was queued before the sort: the instance totals for tile
+    //    heights 4 / 8 / 16 / 32 -> tile height, R; then the instance offsets in range order for that height.  The device is still
+    //    sorting while the host decides and queues what follows (the packed gradient lines are zeroed by the preprocess itself, so
+    //    there is no fill to queue behind the copy any more, and no guess of the tile height).
     int TH;
     size_t R;
     uint32_t* status_dev = geom.totals + LG_TOTALS_STATUS_WORD;
     if (!enqueue_only) {
-        const int th_guess = forced_tile_rows() ? forced_tile_rows() : t_last_th;
-        lg::launch_instance_offsets(ids_sorted, geom.spans, th_guess, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
-        LG_STAGE_CHECK("instance scan");
-        uint32_t totals_h[LG_TOTALS_WORDS];                                // [0] scan total, then the slots of 64-bit instance totals
-        // behind the copy, so that the device is busy while the host decides: the backward's zero-fill of the gradient lines
-        LG_HIP((hipError_t)lg::api_read_words_zero_behind(geom.totals, LG_TOTALS_WORDS, totals_h, geom.gacc, sizeof(float) * 16 * (size_t)P, stream));
+        uint32_t totals_h[LG_TOTALS_WORDS];                                // the slots of 64-bit instance totals the preprocess filled
+        LG_HIP((hipError_t)lg::api_read_words_end(LG_TOTALS_WORDS, totals_h));
         unsigned long long inst[4] = {0, 0, 0, 0};
         for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
             unsigned long long v[4];
             memcpy(v, totals_h + LG_TOTALS_SLOT_WORD + 8 * slot, sizeof v);
             inst[0] += v[0]; inst[1] += v[1]; inst[2] += v[2]; inst[3] += v[3];
         }
-        const uint32_t scan_total = totals_h[0];
         const unsigned long long inst4[4] = {inst[0], inst[1], inst[2], inst[3]};
-        TH = choose_tile_rows(inst4, height);
-        unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : (TH == 32 ? inst[3] : (unsigned long long)scan_total)));
+        TH = choose_tile_rows(inst4, height);                              // 4, 8, 16 or 32
+        const unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : inst[3]));
         if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
         R = (size_t)R64;
-        if (TH != th_guess) {
-            lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
-        }
-        t_last_th = TH;
+        lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        LG_STAGE_CHECK("instance scan");
     } else {
         TH = fixed_tile_rows;
         R = (size_t)instance_capacity;                                     // the capacity stands in for the count everywhere on the host
         lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
         LG_STAGE_CHECK("instance scan");
-        LG_HIP(hipMemsetAsync(geom.gacc, 0, sizeof(float) * 16 * (size_t)P, stream));
         lg::launch_finish_totals(geom.totals, reinterpret_cast<const unsigned long long*>(geom.totals + LG_TOTALS_SLOT_WORD),
                                  (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);
         if (status_host) LG_HIP(hipMemcpyAsync(status_host, status_dev, LG_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

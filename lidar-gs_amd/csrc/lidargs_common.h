@@ -225,6 +225,8 @@ SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel);
 // Device -> host read of `n` (<= 1024) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
 // for the copy only.  Returns a hipError_t.
 int api_read_words_zero_behind(const uint32_t* dev, int n, uint32_t* out, void* zero, size_t zero_bytes, hipStream_t s);
+int api_read_words_begin(const uint32_t* dev, int n, hipStream_t s);    // the same read in two halves: queue the copy ...
+int api_read_words_end(int n, uint32_t* out);                           // ... and, with more work queued behind it, wait for it
 // num_rendered = instance capacity (multiple of 4) | tile-height code: all a later call on the forward's buffers needs (api.hip)
 // per-stage HIP-event timing (lidargs_profile_*): kind 0 = forward-like call, 1 = backward
 void api_prof_begin(hipStream_t s, int kind);

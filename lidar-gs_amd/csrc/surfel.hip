@@ -24,6 +24,7 @@
 // are reconstructed in the per-surfel epilogue instead (the 3-D branch's dL/dmean2D statistics from the |dL/dTw|
 // sums; the 2-D branch's dL/dTw from its dL/dmean2D sums and one dL/dz sum).
 #include "lidargs_common.h"
+#include <string.h>
 
 namespace lg {
 
@@ -90,6 +91,8 @@ struct SfPreArgs {
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
     uint32_t* dirty;       // the geometry buffer's "gradient lines hold sums" word (LG_TOTALS_DIRTY_WORD): cleared here
+    unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: word 0 of each slot = part of the instance total (zeroed by the caller)
+    float4* gacc;          // [8P] packed gradient lines of the backward: zeroed here for every surfel with radii > 0
 };
 
 template <bool FILTER>
@@ -105,12 +108,13 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         __syncthreads();
     }
     const float* __restrict__ beams_tab = lds_beams ? s_beams : a.beams;
-    if (idx >= a.P) return;
+    const bool in_range = idx < a.P;                                   // no early return: the whole wave takes part in the sum at the end
     int out_radius = 0, rx = 0, ry = 0;
     uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0;
     float4 r0, r1, r2, r3, r4;
     bool live = false;
     do {
+        if (!in_range) break;
         const float* vm = a.view;
         const float3 pw = sf3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         const float3 pv = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
@@ -172,9 +176,35 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         r4 = make_float4(pim.x, pim.y, dist, pv.x * n.x + pv.y * n.y + pv.z * n.z);
     } while (false);
 
-    a.radii[idx] = out_radius;
-    a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;
+    if (in_range) {
+        a.radii[idx] = out_radius;
+        a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;
+    }
     if (FILTER) return;
+    {   // the instance total (what the host sizes the binning buffer with), known before anything is sorted: one sum per wave, added
+        // to one of LG_INST_SLOTS slots (k_preprocess has the same, per tile height); the host adds the slots up after its one read
+        uint32_t sum = tiles;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if ((threadIdx.x & 63) == 0 && sum)
+            atomicAdd(a.inst_slots + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % LG_INST_SLOTS) * 4, (unsigned long long)sum);
+    }
+    // the packed 128-byte gradient lines the backward adds into are zeroed here, not by a 128 B x P fill launch per frame: the wave
+    // writes the 8 KB of its 64 surfels as eight contiguous 1-KB stores
+    {
+        const int lane = threadIdx.x & 63, wbase = idx - lane;
+        if (wbase < a.P) {
+            float4* z = a.gacc + 8 * (size_t)wbase;
+            const size_t room = 8 * (size_t)(a.P - wbase);
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const size_t o = (size_t)k * 64 + lane;
+                if (o < room) z[o] = zero;
+            }
+        }
+    }
+    if (!in_range) return;
     a.dkey[idx] = key; a.ids[idx] = (uint32_t)idx;
     a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, tiles, reftiles);   // lidargs_common.h: one gather per Gaussian when the lists are built
     if (live) {
