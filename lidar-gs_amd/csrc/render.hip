@@ -390,14 +390,24 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     float C0 = 0.f, C1 = 0.f, D = 0.f;
     float T_final = a.T_in ? a.T_in[pix] : 1.f, T_hand = T_final;
     bool stopped = false;
-    for (int k = 0; k < St; k++) {
-        if (stopped) break;
-        C0 += sb[k * stride + LG_SEG_C0 * 64];
-        C1 += sb[k * stride + LG_SEG_C1 * 64];
-        D += sb[k * stride + LG_SEG_D * 64];
-        T_final = sb[k * stride + LG_SEG_TEND * 64];
-        T_hand = sb[k * stride + LG_SEG_TBREAK * 64];
-        stopped = T_hand < 0.0001f;                                    // the walk ended inside segment k
+    // four segments per step: their twenty loads are issued together (every plane below St was written by pass 2), and a pixel
+    // whose walk has ended simply stops taking them; the patch leaves once all of its pixels have
+    for (int k0 = 0; k0 < St; k0 += 4) {
+        float c0[4], c1[4], dd[4], te[4], tb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = min(k0 + i, St - 1);
+            c0[i] = sb[k * stride + LG_SEG_C0 * 64]; c1[i] = sb[k * stride + LG_SEG_C1 * 64]; dd[i] = sb[k * stride + LG_SEG_D * 64];
+            te[i] = sb[k * stride + LG_SEG_TEND * 64]; tb[i] = sb[k * stride + LG_SEG_TBREAK * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool use = !stopped && (k0 + i < St);
+            C0 += use ? c0[i] : 0.f; C1 += use ? c1[i] : 0.f; D += use ? dd[i] : 0.f;
+            T_final = use ? te[i] : T_final; T_hand = use ? tb[i] : T_hand;
+            stopped = stopped || (use && tb[i] < 0.0001f);             // the walk ended inside segment k
+        }
+        if (__ballot(!stopped) == 0ull) break;
     }
     const size_t N = (size_t)g.W * g.H;
     a.final_T[pix] = T_final;

@@ -480,21 +480,37 @@ __global__ void __launch_bounds__(64) k_sf_combine(const SfFwdArgs a) {
     float T_final = 1.f, T_start = 1.f;
     uint32_t last = 0, med_c = 0;
     bool stopped = false;
-    for (int k = 0; k < St; k++) {
-        if (stopped) break;
+    // two segments per step: their thirty loads are issued together (every plane below St was written by pass 2), and a pixel whose
+    // walk has ended simply stops taking them; the patch leaves once all of its pixels have
+    struct Seg { float tend, m1, m2, dist, c0, c1, d, n0, n1, n2, med, tpass, tbreak; uint32_t l, mc; };
+    auto load = [&](int k) {
+        Seg g;
         const float* p = sb + (size_t)k * stride;
-        const float tend = p[SF_SEG_TEND * 64], m1 = p[SF_SEG_M1 * 64], m2 = p[SF_SEG_M2 * 64];
-        const float wsum = T_start - tend;                                 // sum of the blend weights of this segment
-        dist += p[SF_SEG_DIST * 64] + M2 * wsum - 2.f * M1 * m1;           // cross terms with the segments in front
-        C0 += p[SF_SEG_C0 * 64]; C1 += p[SF_SEG_C1 * 64]; D += p[SF_SEG_D * 64];
-        N0 += p[SF_SEG_N0 * 64]; N1 += p[SF_SEG_N1 * 64]; N2 += p[SF_SEG_N2 * 64];
-        M1 += m1; M2 += m2;
-        const uint32_t l = su[(size_t)k * stride + SF_SEG_LAST * 64], mc = su[(size_t)k * stride + SF_SEG_MEDC * 64];
-        if (l) last = segment_range(tr, Sfull, k).x - tr.x + l;
-        if (mc) { med_c = mc; med = p[SF_SEG_MED * 64]; }
-        T_final = tend;
-        T_start *= p[SF_SEG_TPASS * 64];                                    // what pass 2 started the next segment from
-        stopped = p[SF_SEG_TBREAK * 64] < 0.0001f;
+        g.tend = p[SF_SEG_TEND * 64]; g.m1 = p[SF_SEG_M1 * 64]; g.m2 = p[SF_SEG_M2 * 64]; g.dist = p[SF_SEG_DIST * 64];
+        g.c0 = p[SF_SEG_C0 * 64]; g.c1 = p[SF_SEG_C1 * 64]; g.d = p[SF_SEG_D * 64];
+        g.n0 = p[SF_SEG_N0 * 64]; g.n1 = p[SF_SEG_N1 * 64]; g.n2 = p[SF_SEG_N2 * 64];
+        g.med = p[SF_SEG_MED * 64]; g.tpass = p[SF_SEG_TPASS * 64]; g.tbreak = p[SF_SEG_TBREAK * 64];
+        g.l = su[(size_t)k * stride + SF_SEG_LAST * 64]; g.mc = su[(size_t)k * stride + SF_SEG_MEDC * 64];
+        return g;
+    };
+    auto fold = [&](const Seg& g, int k, bool in) {
+        const bool use = in && !stopped;
+        const float wsum = T_start - g.tend;                               // sum of the blend weights of this segment
+        dist += use ? g.dist + M2 * wsum - 2.f * M1 * g.m1 : 0.f;          // cross terms with the segments in front
+        C0 += use ? g.c0 : 0.f; C1 += use ? g.c1 : 0.f; D += use ? g.d : 0.f;
+        N0 += use ? g.n0 : 0.f; N1 += use ? g.n1 : 0.f; N2 += use ? g.n2 : 0.f;
+        M1 += use ? g.m1 : 0.f; M2 += use ? g.m2 : 0.f;
+        if (use && g.l) last = segment_range(tr, Sfull, k).x - tr.x + g.l;
+        if (use && g.mc) { med_c = g.mc; med = g.med; }
+        T_final = use ? g.tend : T_final;
+        T_start = use ? T_start * g.tpass : T_start;                       // what pass 2 started the next segment from
+        stopped = stopped || (use && g.tbreak < 0.0001f);
+    };
+    for (int k0 = 0; k0 < St; k0 += 2) {
+        const Seg g0 = load(k0), g1 = load(min(k0 + 1, St - 1));
+        fold(g0, k0, true);
+        fold(g1, k0 + 1, k0 + 1 < St);
+        if (__ballot(!stopped) == 0ull) break;
     }
     const size_t N = (size_t)a.grid.W * a.grid.H;
     a.accum[px.pix] = T_final; a.accum[N + px.pix] = M1; a.accum[2 * N + px.pix] = M2;
