@@ -146,6 +146,12 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
     // open, then the rest -- 8 M Gaussians @ 128x4096: shell scene 2.33 -> 2.17 ms, street scene 2.62 -> 2.50 ms against {3}.
     if (fine) { p.n_rounds = 1; p.rounds[0] = surfel ? 6 : 5; }
     else { p.n_rounds = 2; p.rounds[0] = 1; p.rounds[1] = 4; }
+    // Round 1 as the complete walk of the list heads (k_render_pass2_grouped<true>) instead of a T-only walk that pass 2 repeats: on
+    // the big frames, whose first round is the first 128-entry segment alone (8 M Gaussians @ 128x4096: blends 0.233 -> 0.205 ms).  On
+    // the 64x2650 frames a workgroup per patch walking 5 segments in a row is 2.6 waves per SIMD of serial work: 2 M Gaussians lose
+    // 0.09 ms, 0.5 M are even; heads of 1 or 2 segments there lose 0.03-0.04 ms to the extra launches (r02 measurements).
+    p.head = (fine || surfel) ? 0 : 1;
+    { static const int env_head = [] { const char* e = getenv("LIDARGS_HEAD"); return e ? atoi(e) : -1; }(); if (env_head >= 0 && !surfel) p.head = env_head ? 1 : 0; }
     if (env_len) p.seg_len = env_len;
     if (env_max) p.max_segments = env_max;
     if (env_nrounds >= 0) { p.n_rounds = env_nrounds; for (int k = 0; k < env_nrounds; k++) p.rounds[k] = env_rounds[k]; }
@@ -157,15 +163,24 @@ bool pass1_gated(const SegPlan& p, int S) { return p.n_rounds > 0 && p.rounds[0]
 // still unsaturated -- the next ones, and so on.  In a street scene most patches saturate within a few hundred entries,
 // and pass 1 (which restarts from T = 1 in every segment) would otherwise walk every entry behind that point for nothing.
 // Leaves `ra` covering all segments with the gate armed, which is what pass 2 and the combine expect.
-void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive, hipStream_t stream) {
+// `head` (out, nullable): when the caller goes on to pass 2 and the walk starts from T = 1, the first round is not a T-only walk but
+// the head of every list walked once, completely (render.hip k_render_pass2_grouped<true>); *head = its segments, which pass 2 then
+// skips.  0 = no head (plans without one, transmittance-only passes, walks that start from a T_in plane).
+void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive, hipStream_t stream, int* head = nullptr) {
     const int S = ra.S;
     const int* r = plan.rounds;
     const int n = plan.n_rounds;
     ra.alive = nullptr; ra.front = 0;
     int lo = 0;
+    if (head) *head = 0;
     for (int i = 0; i < n && r[i] < S; i++) {
         ra.seg_lo = lo; ra.seg_hi = r[i];
-        lg::launch_render_pass1(ra, stream);       // gated on the limits the previous rounds left (none in the first)
+        if (i == 0 && head && plan.head && !ra.T_in && !ra.transmittance_only && ra.flags) {
+            lg::launch_render_head(ra, r[0], stream);
+            *head = r[0];
+        } else {
+            lg::launch_render_pass1(ra, stream);   // gated on the limits the previous rounds left (none in the first)
+        }
         ra.alive = alive; ra.front = r[i];
         lg::launch_render_alive(ra, stream);
         lo = r[i];
@@ -419,12 +434,13 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = Rp;
     ra.transmittance_only = transmittance_pass;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
+    int head = 0;                                                      // segments at the head of every list that round 1 walked completely
     if (ra.run_pass1) {
-        run_pass1_rounds(ra, plan, bin.alive, stream);
+        run_pass1_rounds(ra, plan, bin.alive, stream, transmittance_pass ? nullptr : &head);
         LG_STAGE_CHECK("render pass 1");
         g_prof.mark("render_pass1", stream);
     }
-    ra.seg_lo = 0; ra.seg_hi = S;
+    ra.seg_lo = head; ra.seg_hi = S;
     if (!transmittance_pass) {
         lg::launch_render_pass2(ra, stream);
         LG_STAGE_CHECK("render pass 2");

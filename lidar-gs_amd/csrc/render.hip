@@ -99,7 +99,7 @@ struct WalkState {
 // register moves per entry, and plain loads get folded into the top of the next iteration, where every entry waits out the LDS
 // latency.  Only what the pass uses is read (the T-only walk needs neither depth nor colours, nobody the record's opacity): a register
 // that is loaded but never used gets reused as a temporary, and the walk would wait for the load to land first.
-template <bool T_ONLY>
+template <bool T_ONLY, bool TRACK = T_ONLY>
 __device__ __forceinline__ void walk_flagged(unsigned long long todo, const float4* s_rec, const float* oprow, const v2f qxy, const float qz,
                                              const uint32_t chunk_base, WalkState& w) {
     struct Rec { float4 r0, r1, r2, r3; float op; };
@@ -137,7 +137,6 @@ __device__ __forceinline__ void walk_flagged(unsigned long long todo, const floa
         if (T_ONLY) {
             // only the hand-over value is kept: T takes the tripping value too, and the lane is done from there on
             w.T = hit ? test_T : w.T;
-            w.took |= (__ballot(hit) != 0ull) ? (1ull << jj) : 0ull;
         } else {
             const bool blend = hit != trip;
             const float wt = blend ? alpha * w.T : 0.f;
@@ -146,6 +145,7 @@ __device__ __forceinline__ void walk_flagged(unsigned long long todo, const floa
             w.T_break = hit ? test_T : w.T_break;
             w.last = blend ? (chunk_base + (uint32_t)jj + 1u) : w.last;
         }
+        if (TRACK) w.took |= (__ballot(hit) != 0ull) ? (1ull << jj) : 0ull;
         w.done = w.done || trip;
     };
     int ja = __builtin_ctzll(todo);
@@ -268,21 +268,28 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
 // walk: T is carried across the segment boundaries (only the group's first segment starts from the pass-1 products), the records
 // of the next segment's first chunk are gathered while the current segment's last chunk is composited, and every segment still
 // gets its own planes (partial sums, T_end, T_break, last), which is all the combine and the backward look at.
+//
+// FIRST: the head of every list -- its first G segments -- walked ONCE, instead of a T-only walk per segment followed by pass 2 over
+// what was flagged.  The head starts from the true transmittance (1, or T_in), so this walk IS the serial reference walk: it visits
+// every entry, records the contribution flags itself (exact ones: a subset of what the T-only walks, which restart from T = 1 in
+// every segment, would flag), and leaves in the head's T_pass planes the hand-over value (in segment 0's; 1 in the others), so that
+// the product pass 2 and k_render_alive form over the segments in front of the tail is the transmittance the tail starts from.
+template <bool FIRST>
 __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs a, const int G) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
     __shared__ float4 s_oprow[LG_CHUNK];
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
-    const int groups = ((S + G - 1) / G) | 1;                          // odd, like S: keeps the group index decorrelated from the XCD (b % 8)
+    const int groups = FIRST ? 1 : (((S - a.seg_lo + G - 1) / G) | 1); // odd, like S: keeps the group index decorrelated from the XCD (b % 8)
     int patch, grp;
     if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), groups, patch, grp)) return;
     patch = a.grid.global_patch(patch);
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const uint2 tr = a.ranges[tile];
     const int St = segment_count(tr, S, a.seg_len);
-    const int limit = a.alive ? min(St, (int)a.alive[patch]) : St;     // segments behind the limit were never walked by pass 1
-    const int s0 = grp * G;
+    const int limit = (!FIRST && a.alive) ? min(St, (int)a.alive[patch]) : St;   // segments behind the limit were never walked by pass 1
+    const int s0 = (FIRST ? 0 : a.seg_lo) + grp * G;                   // (pass 2 may start behind a head that was walked once)
     if (s0 >= limit) return;
     const int s1 = min(limit, s0 + G);
     const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
@@ -291,28 +298,31 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
 
     float T = 1.0f;
     if (a.T_in && px.inside) T = a.T_in[px.pix];
+    const float T_start = T;
     for (int k = 0; k < s0; k++) T *= pbase[(size_t)k * pstride + LG_SEG_TPASS * 64 + lane];
     WalkState w{T, T, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || T < 0.0001f, 0ull};
     const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
     const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
     const v2f qxy = v2f{px.q.x, px.q.y};
-    const uint8_t* flp = a.flags ? a.flags + (size_t)sub * a.R : nullptr;
+    uint8_t* flp = a.flags ? a.flags + (size_t)sub * a.R : nullptr;
 
     auto fetch = [&](uint2 sr, uint32_t n, uint32_t c, bool& have) {
         const uint32_t k = c * LG_CHUNK + (uint32_t)lane;
         const uint32_t g = k < n ? a.point_list[sr.x + k] : 0u;        // not waiting for the flag
-        have = k < n && (!flp || flp[sr.x + k] != 0);
+        have = k < n && (FIRST || !flp || flp[sr.x + k] != 0);
         return gather_record(a.rec, a.rowspan, g, have);
     };
     uint2 sr = segment_range(tr, St, s0);
     bool have;
     Staged st = fetch(sr, sr.y - sr.x, 0u, have);
     bool all_done = false;
+    float hand = T;                                                    // FIRST: what a walk behind this group starts from (< 1e-4: stopped)
     for (int sg = s0; sg < s1; sg++) {
         sr = segment_range(tr, St, sg);
         const uint32_t n = sr.y - sr.x;
         const uint32_t nchunks = (n + LG_CHUNK - 1) / LG_CHUNK;
         w.T_break = w.T; w.C01 = v2f{0.f, 0.f}; w.D = 0.f; w.last = 0u;
+        uint32_t c_done = 0;                                           // FIRST: chunks of this segment whose flags are written
         if (!all_done) {
             for (uint32_t c = 0; c < nchunks; c++) {
                 __syncthreads();
@@ -323,7 +333,19 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
                 if (c + 1 < nchunks) st = fetch(sr, n, c + 1, have);
                 else if (sg + 1 < s1) { const uint2 nsr = segment_range(tr, St, sg + 1); st = fetch(nsr, nsr.y - nsr.x, 0u, have); }
                 if (__ballot(!w.done) == 0ull) { all_done = true; break; }   // R3/cr/forward.cu:559-561 early-out
-                if (todo) walk_flagged<false>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
+                w.took = 0ull;
+                if (todo) walk_flagged<false, FIRST>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
+                if (FIRST && flp) {
+                    const uint32_t k = c * LG_CHUNK + lane;
+                    if (k < n) flp[sr.x + k] = (uint8_t)((w.took >> lane) & 1ull);
+                    c_done = c + 1;
+                }
+            }
+        }
+        if (FIRST && flp) {                                            // entries the walk never reached: nobody takes them
+            for (uint32_t c = c_done; c < nchunks; c++) {
+                const uint32_t k = c * LG_CHUNK + lane;
+                if (k < n) flp[sr.x + k] = 0;
             }
         }
         float* segbase = pbase + (size_t)sg * pstride;
@@ -333,6 +355,14 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
         segbase[LG_SEG_TEND * 64 + lane] = w.T;
         segbase[LG_SEG_TBREAK * 64 + lane] = w.T_break;
         reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = w.last;
+        if (FIRST) {
+            hand = hand < 0.0001f ? hand : w.T_break;                  // T after the segment's last hit: the tripping value if it stopped here
+            segbase[LG_SEG_TPASS * 64 + lane] = 1.0f;
+        }
+    }
+    if (FIRST) {
+        // the consumers multiply T_in by the product of the planes in front of them: this plane carries the head's factor
+        pbase[LG_SEG_TPASS * 64 + lane] = (T_start > 0.f) ? hand / T_start : 0.f;
     }
 }
 
@@ -437,13 +467,18 @@ static int pass2_group(int seg_len) {
 }
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
     const int G = pass2_group(a.seg_len);
-    if (G <= 1 || a.seg_lo != 0 || a.seg_hi != a.S) {
+    if (G <= 1 || a.seg_hi != a.S) {
         const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
         hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
         return;
     }
-    const unsigned blocks = segment_grid(a.grid.window_patches(), ((a.S + G - 1) / G) | 1);
-    hipLaunchKernelGGL(k_render_pass2_grouped, dim3(blocks), dim3(64), 0, s, a, G);
+    const unsigned blocks = segment_grid(a.grid.window_patches(), ((a.S - a.seg_lo + G - 1) / G) | 1);
+    hipLaunchKernelGGL(k_render_pass2_grouped<false>, dim3(blocks), dim3(64), 0, s, a, G);
+}
+// the first `head` segments of every list, walked once from the true transmittance (see k_render_pass2_grouped<true>)
+void launch_render_head(const RenderFwdArgs& a, int head, hipStream_t s) {
+    const unsigned blocks = segment_grid(a.grid.window_patches(), 1);
+    hipLaunchKernelGGL(k_render_pass2_grouped<true>, dim3(blocks), dim3(64), 0, s, a, head);
 }
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned patches = (unsigned)a.grid.window_patches();
