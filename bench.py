@@ -64,12 +64,12 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
     pin = 40 if surfel else 44
     t = [
         dict(kernel="k_sf_preprocess" if surfel else "k_preprocess", stage="preprocess", launches=1, bound="hbm",
-             bytes=(pin + 36) * P + (88 if surfel else 76) * V,
-             units=f"{pin} B in + 36 B (radii, radii_xy, key, id, spans) out per Gaussian, + record / row span / colours per visible one"),
+             bytes=(pin + 36 + (128 if surfel else 64)) * P + (88 if surfel else 76) * V,
+             units=f"{pin} B in + 36 B (radii, radii_xy, key, id, spans) out + the {128 if surfel else 64}-B gradient line it zeroes per Gaussian, + record / row span / colours per visible one"),
         dict(kernel="radix sort of the range keys (hist + prefix + scatter) x4", stage="range_sort", launches=12, bound="hbm",
              bytes=4 * 20 * P, units="4 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per Gaussian"),
         dict(kernel="forward blend group (reference K7): T-only walks + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
-             launches=5, bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
+             launches="4-7 by plan", bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
              bytes=rec * Rb + pix_f * N + acc * V, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on what the frame takes)"),
         dict(kernel="k_sf_gaussian_backward" if surfel else "k_gaussian_backward", stage="gaussian_bwd", launches=1, bound="hbm",
@@ -127,6 +127,20 @@ def pmc_lookup(kind, workload, kernel_names, field):
         return None, None
     f, j = prof
     tot = 0
+    if isinstance(kernel_names, dict):
+        # a launch GROUP whose members depend on the frame's segment plan: every kernel of the profile whose name starts with one of
+        # `any_of`, each weighted by its launches per frame = launches sampled / launches sampled of `per_frame` (one per frame)
+        ref = [v for k, v in j["kernels"].items() if kernel_names["per_frame"] in k]
+        if not ref or not ref[0].get("launches_sampled"):
+            return None, os.path.basename(f)
+        frames = ref[0]["launches_sampled"]
+        found = False
+        for k, v in j["kernels"].items():
+            base = k[5:] if k.startswith("void ") else k
+            if any(base.startswith(pre) for pre in kernel_names["any_of"]) and field in v:
+                tot += v[field] * v.get("launches_sampled", frames) / frames
+                found = True
+        return (tot if found else None), os.path.basename(f)
     for name in kernel_names:
         name, times = name if isinstance(name, tuple) else (name, 1)
         hit = [v for k, v in j["kernels"].items() if k == name or k.startswith(name + "<") or k == "void " + name]
@@ -348,7 +362,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
                  "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"],
                  "forward blend group (reference K7): T-only walks + alive + full walk + combine":
-                     [("lg::k_sf_render_forward<true>", 2), "lg::k_sf_alive", "lg::k_sf_render_forward<false>", "lg::k_sf_combine"]}
+                     {"any_of": ["lg::k_sf_render_forward<", "lg::k_sf_alive", "lg::k_sf_combine"], "per_frame": "k_sf_combine"}}
     out = {
         "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -936,7 +950,8 @@ def main():
             pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
                          "k_gaussian_backward": ["lg::k_gaussian_backward"],
                          "forward blend group (reference K7): T-only walks + alive + full walk + combine":
-                             [("lg::k_render_forward<true>", 2), "lg::k_render_alive", "lg::k_render_forward<false>", "lg::k_render_combine"]}
+                             {"any_of": ["lg::k_render_forward<", "lg::k_render_pass2_grouped", "lg::k_render_alive", "lg::k_render_combine"],
+                              "per_frame": "k_render_combine"}}
             out["roofline"] = roofline_object(table, args.workload, pmc_names, ref_flow)
             # the frame as a whole against the HBM roof, from the same per-launch units (+ what the table leaves out is small)
             own = sum(k["bytes"] for k in table)
