@@ -13,7 +13,8 @@
  * Conventions shared by all entry points
  *   - all array arguments are DEVICE pointers (gfx950 HBM), float32 / int32, contiguous;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are only
- *     enqueued on it, the single host wait is the 4-byte instance-count read in forward;
+ *     enqueued on it, the single host wait is the 2-KB read of the instance totals in forward (queued right behind
+ *     the preprocess, waited for while the range sort runs);
  *   - return value: >= 0 on success, one of LIDARGS_ERR_* (< 0) on failure, with a message
  *     available from lidargs_last_error() (thread-local);
  *   - argument order and meaning mirror the reference signatures line by line; arguments the
