@@ -375,6 +375,18 @@ __device__ __forceinline__ float4 lds_ahead(const float4* p) {
 __device__ __forceinline__ float lds_ahead(const float* p) { return *(LG_LDS_VOLATILE(float))p; }
 __device__ __forceinline__ uint32_t lds_ahead(const uint32_t* p) { return *(LG_LDS_VOLATILE(uint32_t))p; }
 
+// gfx950 lane swaps: {a', b'} with a' = (a's lower half | b's lower half), b' = (a's upper half | b's upper half) for halves of
+// 32 lanes (v_permlane32_swap) or, row pair by row pair, of 16 (v_permlane16_swap).  a' + b' is then one reduce-scatter step
+// with no select: the lower half of the lanes owns the sum of a, the upper half the sum of b.
+__device__ __forceinline__ float fold_halves32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold_halves16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // The entry's opacity for each of the four pixel rows [y0, y0 + 4) of a patch: 0 on the rows outside its row span [lo, hi).
 __device__ __forceinline__ float4 rows_opacity(uint32_t span, float opacity, int y0) {
     const int lo = (int)(span & 0xFFFFu), hi = (int)(span >> 16);

@@ -509,18 +509,6 @@ __device__ __forceinline__ float xchg_swz(float x) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (XORMASK << 10) | 0x1F));
 }
 
-// gfx950 lane swaps: {a', b'} with a' = (a's lower half | b's lower half), b' = (a's upper half | b's upper half) for halves of
-// 32 lanes (v_permlane32_swap) or, row pair by row pair, of 16 (v_permlane16_swap).  a' + b' is then one reduce-scatter step
-// with no select: the lower half of the lanes owns the sum of a, the upper half the sum of b.
-__device__ __forceinline__ float fold_halves32(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float fold_halves16(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // Reduce-scatter of 16 per-lane values over the 64 lanes of a wave.  On return lane L owns, in v[0], the wave-wide sum of value slot
 //   id(L) = 8*bit5(L) + 4*bit4(L) + 2*bit0(L) + bit1(L)          (lanes that differ only in bits 2, 3 hold the same)
 // The two wide steps come first, when there are most values to fold: a lane swap + an add each, instead of two selects + a

@@ -538,33 +538,44 @@ void launch_sf_combine(const SfFwdArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 32-slot butterfly reduce-scatter: lane L (< 32) ends with the wave-wide sum of slot bitrev5(L).
+// 32-slot reduce-scatter over the 64 lanes of a wave.
 __device__ __forceinline__ float sf_x1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float sf_x2(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)); }
 template <int M> __device__ __forceinline__ float sf_xs(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (M << 10) | 0x1F)); }
 
+// The two wide steps (most values to fold) are a gfx950 lane swap + an add each (fold_halves32 / fold_halves16: no selects); the
+// lane ^ 1, ^ 2, ^ 4 steps exchange through DPP quad permutes / the swizzle crossbar; lanes that differ in bit 3 end with the same
+// sum (one row rotation).  On return lane L holds, in v[0], the wave-wide sum of slot
+//   16*bit5(L) + 8*bit4(L) + 4*bit0(L) + 2*bit1(L) + bit2(L).
+// Only 23 of the 32 slots carry a sum.  The nine unused ones (SFA_DEAD) sit where the folds pair them with each other -- a pair of
+// unused slots is not folded at all: 12 + 6 + 3 + 2 + 1 folds instead of 16 + 8 + 4 + 2 + 1.
+constexpr uint32_t SFA_DEAD = (1u << 3) | (1u << 7) | (1u << 11) | (1u << 14) | (1u << 15) | (1u << 19) | (1u << 23) | (1u << 27) | (1u << 31);
+__device__ __forceinline__ constexpr bool sfa_dead(uint32_t mask, int k) { return (mask >> k) & 1u; }
+// slots still unused after folding pairs (k, k + half): both halves unused
+__device__ __forceinline__ constexpr uint32_t sfa_fold_mask(uint32_t mask, int half) { return mask & (mask >> half) & ((1u << half) - 1u); }
+
 __device__ __forceinline__ float sf_reduce_scatter32(float (&v)[32], int lane) {
+    constexpr uint32_t D32 = SFA_DEAD, D16 = sfa_fold_mask(D32, 16), D8 = sfa_fold_mask(D16, 8), D4 = sfa_fold_mask(D8, 4), D2 = sfa_fold_mask(D4, 2);
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (!sfa_dead(D16, k)) v[k] = fold_halves32(v[k], v[k + 16]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (!sfa_dead(D8, k)) v[k] = fold_halves16(v[k], v[k + 8]);
     { const bool hi = lane & 1;
 #pragma unroll
-      for (int k = 0; k < 16; k++) { const float keep = hi ? v[k + 16] : v[k], send = hi ? v[k] : v[k + 16]; v[k] = keep + sf_x1(send); } }
+      for (int k = 0; k < 4; k++) if (!sfa_dead(D4, k)) { const float keep = hi ? v[k + 4] : v[k], send = hi ? v[k] : v[k + 4]; v[k] = keep + sf_x1(send); } }
     { const bool hi = lane & 2;
 #pragma unroll
-      for (int k = 0; k < 8; k++) { const float keep = hi ? v[k + 8] : v[k], send = hi ? v[k] : v[k + 8]; v[k] = keep + sf_x2(send); } }
+      for (int k = 0; k < 2; k++) if (!sfa_dead(D2, k)) { const float keep = hi ? v[k + 2] : v[k], send = hi ? v[k] : v[k + 2]; v[k] = keep + sf_x2(send); } }
     { const bool hi = lane & 4;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const float keep = hi ? v[k + 4] : v[k], send = hi ? v[k] : v[k + 4]; v[k] = keep + sf_xs<4>(send); } }
-    { const bool hi = lane & 8;
-#pragma unroll
-      for (int k = 0; k < 2; k++) { const float keep = hi ? v[k + 2] : v[k], send = hi ? v[k] : v[k + 2]; v[k] = keep + sf_xs<8>(send); } }
-    { const bool hi = lane & 16;
-      const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1]; v[0] = keep + sf_xs<16>(send); }
-    v[0] += __shfl_xor(v[0], 32);
+      const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1]; v[0] = keep + sf_xs<4>(send); }
+    v[0] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x128, 0xF, 0xF, true));   // row_ror:8 = lane ^ 8
     return v[0];
 }
 
-// packed accumulator slots (32 floats = 128 B per surfel)
-enum { SFA_COL0 = 0, SFA_COL1, SFA_OPA, SFA_N0, SFA_N1, SFA_N2, SFA_TU0, SFA_TU1, SFA_TU2, SFA_TV0, SFA_TV1, SFA_TV2,
-       SFA_TW0, SFA_TW1, SFA_TW2, SFA_AW0, SFA_AW1, SFA_AW2, SFA_M2X, SFA_M2Y, SFA_M2AX, SFA_M2AY, SFA_Z2D, SFA_COUNT };
+// packed accumulator slots (32 floats = 128 B per surfel; the indices skip SFA_DEAD)
+enum { SFA_COL0 = 0, SFA_COL1 = 1, SFA_OPA = 2, SFA_N0 = 4, SFA_N1 = 5, SFA_N2 = 6, SFA_TU0 = 8, SFA_TU1 = 9, SFA_TU2 = 10,
+       SFA_TV0 = 12, SFA_TV1 = 13, SFA_TV2 = 16, SFA_TW0 = 17, SFA_TW1 = 18, SFA_TW2 = 20, SFA_AW0 = 21, SFA_AW1 = 22, SFA_AW2 = 24,
+       SFA_M2X = 25, SFA_M2Y = 26, SFA_M2AX = 28, SFA_M2AY = 29, SFA_Z2D = 30 };
 
 struct SfBwdArgs {
     TileGrid grid;
@@ -734,9 +745,9 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             l_c0 = r1.w; l_d = c_d; l_n0 = r3.x; l_n1 = r3.y; l_n2 = r3.z;
             last_alpha = alpha;
             const float mine = sf_reduce_scatter32(v, lane);
-            if (lane < 32) {
-                const int slot = 16 * (lane & 1) + 8 * ((lane >> 1) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 4) & 1);
-                if (slot < SFA_COUNT) atomicAdd(a.gacc + 32 * (size_t)s_gid[j] + slot, mine);
+            if ((lane & 8) == 0) {                                      // one owner per slot
+                const int slot = 16 * ((lane >> 5) & 1) + 8 * ((lane >> 4) & 1) + 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+                if (!((SFA_DEAD >> slot) & 1u)) atomicAdd(a.gacc + 32 * (size_t)s_gid[j] + slot, mine);
             }
         }
     }
