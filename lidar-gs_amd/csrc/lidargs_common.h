@@ -387,6 +387,44 @@ __device__ __forceinline__ float fold_halves16(float a, float b) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Product / sum over a run of per-segment planes with EIGHT loads in flight: the plain loops (`for k: T *= plane[k]`) compile to a
+// load, a wait and a multiply per iteration, i.e. one memory round trip per segment in front of (or behind) the workgroup, before
+// its walk can start.  Same operations in the same order as the plain loop.
+__device__ __forceinline__ float plane_product(float T, const float* first, size_t stride, int n) {
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = first[(size_t)(k + i) * stride];
+#pragma unroll
+        for (int i = 0; i < 8; i++) T *= x[i];
+    }
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = (k + i < n) ? first[(size_t)(k + i) * stride] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (k + i < n) T *= x[i];
+    return T;
+}
+template <int NP>
+__device__ __forceinline__ void plane_sums(float (&acc)[NP], const float* first, size_t stride, const int (&plane)[NP], int n) {
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        float x[4][NP];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) x[i][p] = first[(size_t)(k + i) * stride + (size_t)plane[p] * 64];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) acc[p] += x[i][p];
+    }
+    for (; k < n; k++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc[p] += first[(size_t)k * stride + (size_t)plane[p] * 64];
+}
+
 // The entry's opacity for each of the four pixel rows [y0, y0 + 4) of a patch: 0 on the rows outside its row span [lo, hi).
 __device__ __forceinline__ float4 rows_opacity(uint32_t span, float opacity, int y0) {
     const int lo = (int)(span & 0xFFFFu), hi = (int)(span >> 16);

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     if (!T_ONLY) {
         if (a.T_in && px.inside) T = a.T_in[px.pix];
         const float* tp = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + LG_SEG_TPASS * 64 + lane;
-        for (int k = 0; k < seg; k++) T *= tp[(size_t)k * (LG_SEG_PLANES * 64)];
+        T = plane_product(T, tp, LG_SEG_PLANES * 64, seg);
     }
     // a lane that starts below the threshold can never blend again: every contributing entry trips T < 1e-4
     WalkState w{T, T, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || (!T_ONLY && T < 0.0001f), 0ull};
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
     float T = 1.0f;
     if (a.T_in && px.inside) T = a.T_in[px.pix];
     const float T_start = T;
-    for (int k = 0; k < s0; k++) T *= pbase[(size_t)k * pstride + LG_SEG_TPASS * 64 + lane];
+    T = plane_product(T, pbase + LG_SEG_TPASS * 64 + lane, pstride, s0);
     WalkState w{T, T, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || T < 0.0001f, 0ull};
     const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
     const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
@@ -582,10 +582,11 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     {
         float b0 = 0.f, b1 = 0.f, bd = 0.f;
         const int Send = a.alive ? min(St, (int)a.alive[patch]) : St;  // nothing was walked behind the patch's limit
-        for (int k = seg + 1; k < Send; k++) {
-            b0 += sb[(size_t)k * stride + LG_SEG_C0 * 64];
-            b1 += sb[(size_t)k * stride + LG_SEG_C1 * 64];
-            bd += sb[(size_t)k * stride + LG_SEG_D * 64];
+        {
+            float acc[3] = {0.f, 0.f, 0.f};
+            const int planes[3] = {LG_SEG_C0, LG_SEG_C1, LG_SEG_D};
+            plane_sums<3>(acc, sb + (size_t)(seg + 1) * stride, stride, planes, Send - (seg + 1));
+            b0 = acc[0]; b1 = acc[1]; bd = acc[2];
         }
         if (a.behind && px.inside) { b0 += a.behind[px.pix]; b1 += a.behind[N + px.pix]; bd += a.behind[2 * N + px.pix]; }
         if (T > 0.f) {

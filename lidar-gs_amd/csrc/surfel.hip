@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
     float T = 1.f;
     if (!T_ONLY) {
         const float* tp = a.seg + (size_t)patch * S * (SF_SEG_PLANES * 64) + SF_SEG_TPASS * 64 + lane;
-        for (int k = 0; k < seg; k++) T *= tp[(size_t)k * (SF_SEG_PLANES * 64)];
+        T = plane_product(T, tp, SF_SEG_PLANES * 64, seg);
     }
     float T_break = T;
     float C0 = 0.f, C1 = 0.f, D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
@@ -634,10 +634,11 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     {
         float b0 = 0.f, bd = 0.f, bn0 = 0.f, bn1 = 0.f, bn2 = 0.f;
         const int Send = a.alive ? min(St, (int)a.alive[patch]) : St;
-        for (int k = seg + 1; k < Send; k++) {
-            const float* p = sb + (size_t)k * stride;
-            b0 += p[SF_SEG_C0 * 64]; bd += p[SF_SEG_D * 64];
-            bn0 += p[SF_SEG_N0 * 64]; bn1 += p[SF_SEG_N1 * 64]; bn2 += p[SF_SEG_N2 * 64];
+        {
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            const int planes[5] = {SF_SEG_C0, SF_SEG_D, SF_SEG_N0, SF_SEG_N1, SF_SEG_N2};
+            plane_sums<5>(acc, sb + (size_t)(seg + 1) * stride, stride, planes, Send - (seg + 1));
+            b0 = acc[0]; bd = acc[1]; bn0 = acc[2]; bn1 = acc[3]; bn2 = acc[4];
         }
         if (T > 0.f) {
             const float inv = 1.f / T;
