@@ -73,8 +73,8 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
              bytes=rec * Rb + pix_f * N + acc * V, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on what the frame takes)"),
         dict(kernel="k_sf_gaussian_backward" if surfel else "k_gaussian_backward", stage="gaussian_bwd", launches=1, bound="hbm",
-             bytes=(pin + 4 + (108 if surfel else 92)) * P + (128 if surfel else 64) * V,
-             units="inputs + radii in, every returned gradient row out per Gaussian, + the packed gradient line per visible one"),
+             bytes=(pin + 4 + 68) * P + (128 if surfel else 64) * V,
+             units="inputs + radii in, every gradient row somebody receives out per Gaussian (68 B: the covariance / transMat intermediates are not materialised), + the packed gradient line per visible one"),
     ]
     ms = lambda st: sum(stages.get(x, (0.0, 0))[0] for x in (st if isinstance(st, tuple) else (st,)))
     out = []

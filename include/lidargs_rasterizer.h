@@ -154,7 +154,8 @@ int lidargs_forward_enqueue(
  * dL_dbasis_u2 f32[3P], dL_dcov3D f32[6P], dL_dsh (untouched), dL_dscale f32[3P], dL_drot f32[4P].
  * dL_dconic, dL_ddepths, dL_dsphere_means3D, dL_dbasis_u1 and dL_dbasis_u2 are scratch of the reference's two-kernel
  * backward that its binding never returns (R3/rasterize_points.cu:219); each of them may be NULL, in which case it is
- * not materialised (56 of 148 bytes per Gaussian less to write). */
+ * not materialised (56 of 148 bytes per Gaussian less to write).  dL_dcov3D may be NULL as well when the covariance comes
+ * from scales + rotations (cov3D_precomp == NULL): it is then only an intermediate of the scale / rotation gradients. */
 int lidargs_backward(
     int P, int D, int M, int R,
     const float* background,
@@ -379,7 +380,9 @@ int lidargs_shell_scatter_radii(int M, const int* idx, const int* radii_shell, i
  * backward rejects it, R2/cr/backward.cu:655-658).  Backward outputs (written for all P rows): dL_dmean2D f32[4P],
  * dL_dnormal f32[3P], dL_dopacity f32[P], dL_dcolor f32[2P], dL_dmean3D f32[3P], dL_dtransMat f32[9P],
  * dL_dtransMat_2dtemp f32[3P], dL_dscale f32[2P], dL_drot f32[4P], depth f32[P]; dL_depths is the gradient of
- * all 7 planes of out_others. */
+ * all 7 planes of out_others.  dL_dnormal, dL_dtransMat and dL_dtransMat_2dtemp are intermediates of the reference's
+ * two-kernel backward (transMat_precomp being rejected, nobody receives dL_dtransMat): each may be NULL, in which case it
+ * is not materialised (60 bytes per surfel less to write). */
 int lidargs_surfel_forward(
     lidargs_alloc_fn geometry_alloc, void* geometry_user,
     lidargs_alloc_fn binning_alloc, void* binning_user,

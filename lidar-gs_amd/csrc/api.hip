@@ -472,7 +472,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(LIDARGS_ERR_STATE, "backward: missing forward buffers%s");
     // dL_dconic, dL_ddepths, dL_dsphere_means3D, dL_dbasis_u1/u2 are the reference's scratch gradients: optional here
     if (!means3D || !viewmatrix || !radii || !dL_dpix || !dL_dout_depth || !dL_dout_occ || !dL_dmean2D ||
-        !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dscale || !dL_drot || (cov3D_precomp && !dL_dcov3D))
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward: NULL required pointer%s");
 
     lg::GeomView geom; lg::geom_carve(geom_buffer, (size_t)P, &geom);

@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
             if (a.dL_dbasis_u1) a.dL_dbasis_u1[3 * idx + k] = 0.f;
             if (a.dL_dbasis_u2) a.dL_dbasis_u2[3 * idx + k] = 0.f;
         }
-        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0.f;
+        if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0.f;
         a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f;
         a.dL_dopacity[idx] = 0.f; if (a.dL_ddepths) a.dL_ddepths[idx] = 0.f;
         return;
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float S01 = 2.f * t1.x * t1.y * da + (t1.x * t2.y + t1.y * t2.x) * db + 2.f * t2.x * t2.y * dc;
     const float S02 = 2.f * t1.x * t1.z * da + (t1.x * t2.z + t1.z * t2.x) * db + 2.f * t2.x * t2.z * dc;
     const float S12 = 2.f * t1.z * t1.y * da + (t1.y * t2.z + t1.z * t2.y) * db + 2.f * t2.y * t2.z * dc;
-    gS[0] = S00; gS[1] = S01; gS[2] = S02; gS[3] = S11; gS[4] = S12; gS[5] = S22;
+    if (a.dL_dcov3D) { gS[0] = S00; gS[1] = S01; gS[2] = S02; gS[3] = S11; gS[4] = S12; gS[5] = S22; }   // NULL: only the scale / rotation path wants it
 
     // dL/dt_i = 2 (Sigma t_i) d{a,c} + (Sigma t_j) db ; dL/du_i = A^T dL/dt_i + direct part (:281-307)
     const float3 gt1 = add3(scale3(St1, 2.f * da), scale3(St2, db));

@@ -773,8 +773,12 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     if (idx >= a.P) return;
     if (!(a.radii[idx] > 0)) {                                         // every output row is written (zeros here)
         for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; }
-        for (int k = 0; k < 3; k++) { a.dL_dnormal[3 * idx + k] = 0.f; a.dL_dmean3D[3 * idx + k] = 0.f; a.dL_dtransMat_2dtemp[3 * idx + k] = 0.f; }
-        for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
+        for (int k = 0; k < 3; k++) {
+            a.dL_dmean3D[3 * idx + k] = 0.f;
+            if (a.dL_dnormal) a.dL_dnormal[3 * idx + k] = 0.f;
+            if (a.dL_dtransMat_2dtemp) a.dL_dtransMat_2dtemp[3 * idx + k] = 0.f;
+        }
+        if (a.dL_dtransMat) for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
         a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f; a.dL_dopacity[idx] = 0.f;
         a.dL_dscale[2 * idx] = 0.f; a.dL_dscale[2 * idx + 1] = 0.f; a.depth[idx] = 0.f;
         return;
@@ -792,9 +796,9 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     a.dL_dcolor[2 * idx] = g[SFA_COL0]; a.dL_dcolor[2 * idx + 1] = g[SFA_COL1];
     a.dL_dopacity[idx] = g[SFA_OPA];
     const float3 gn = sf3(g[SFA_N0], g[SFA_N1], g[SFA_N2]);
-    a.dL_dnormal[3 * idx] = gn.x; a.dL_dnormal[3 * idx + 1] = gn.y; a.dL_dnormal[3 * idx + 2] = gn.z;
+    if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = gn.x; a.dL_dnormal[3 * idx + 1] = gn.y; a.dL_dnormal[3 * idx + 2] = gn.z; }   // the three intermediates are optional
     const float3 aw = sf3(g[SFA_AW0], g[SFA_AW1], g[SFA_AW2]);
-    a.dL_dtransMat_2dtemp[3 * idx] = aw.x; a.dL_dtransMat_2dtemp[3 * idx + 1] = aw.y; a.dL_dtransMat_2dtemp[3 * idx + 2] = aw.z;
+    if (a.dL_dtransMat_2dtemp) { a.dL_dtransMat_2dtemp[3 * idx] = aw.x; a.dL_dtransMat_2dtemp[3 * idx + 1] = aw.y; a.dL_dtransMat_2dtemp[3 * idx + 2] = aw.z; }
 
     // dL/dmean2D: 3-D branch statistics are abs-linear in |dL/dTw| with per-surfel coefficients (:564-577);
     // |sin(beta_t) cos(alpha_t)| = |Tw.y|/rho_r, |cos(beta_t) cos(alpha_t)| = |Tw.x|/rho_r, ...
@@ -819,9 +823,11 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
         gTw.y += z2 * Tw.y * irho + m2x * ddelx.y + m2y * ddely.y;
         gTw.z += z2 * Tw.z * irho + m2y * ddely.z;
     }
-    float* gT = a.dL_dtransMat + 9 * (size_t)idx;
     const float3 gTu = sf3(g[SFA_TU0], g[SFA_TU1], g[SFA_TU2]), gTv = sf3(g[SFA_TV0], g[SFA_TV1], g[SFA_TV2]);
-    gT[0] = gTu.x; gT[1] = gTu.y; gT[2] = gTu.z; gT[3] = gTv.x; gT[4] = gTv.y; gT[5] = gTv.z; gT[6] = gTw.x; gT[7] = gTw.y; gT[8] = gTw.z;
+    if (a.dL_dtransMat) {
+        float* gT = a.dL_dtransMat + 9 * (size_t)idx;
+        gT[0] = gTu.x; gT[1] = gTu.y; gT[2] = gTu.z; gT[3] = gTv.x; gT[4] = gTv.y; gT[5] = gTv.z; gT[6] = gTw.x; gT[7] = gTw.y; gT[8] = gTw.z;
+    }
 
     // K10': T rows are (Rv L0, Rv L1, p_view)  =>  dL/dL0 = Rv^T dL/dTu, dL/dL1 = Rv^T dL/dTv, dL/dp = Rv^T dL/dTw
     const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);

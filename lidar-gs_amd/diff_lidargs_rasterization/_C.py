@@ -184,11 +184,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, beam_inclinations, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_depth, dL_dout_occ, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 debug):
+                                 debug, want_cov3D_grad=True):
     """RasterizeGaussiansBackwardCUDA (R3/rasterize_points.cu:126-219).
 
     Returns (dL_dmeans2D[P,4], dL_dcolors[P,2], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6],
-    dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])."""
+    dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4]).  want_cov3D_grad=False (only with scales + rotations, where the
+    reference's dL_dcov3D is an intermediate nobody receives): dL_dcov3D is not materialised and None is returned for it."""
     _require_device(means3D, "means3D")
     dev = means3D.device
     P = int(means3D.size(0))
@@ -197,12 +198,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # the reference makes 13 torch::zeros tensors (:163-175), five of which are scratch it never returns.  Here: one slab for
     # the returned ones, NOT pre-zeroed (the native backward writes every row of every output, zeros for culled
     # Gaussians), and NULL for the scratch ones, which the library then does not materialise.
-    widths = (3, 4, NUM_CHANNELS, 1, 6, 3, 4)
+    skip_cov = (not want_cov3D_grad) and cov3D_precomp.numel() == 0
+    widths = (3, 4, NUM_CHANNELS, 1, 0 if skip_cov else 6, 3, 4)
     slab = torch.empty(P * sum(widths), dtype=torch.float32, device=dev)
     parts, o = [], 0
     for w in widths:
         parts.append(slab[o:o + P * w].view(P, w)); o += P * w
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, dL_dscales, dL_drotations = parts
+    if skip_cov:
+        dL_dcov3D = None
     dL_ddepths = dL_dconic = dL_dsphere = dL_du1 = dL_du2 = None
     dL_dsh = torch.zeros((P, M, 3), dtype=torch.float32, device=dev)
     if P != 0:

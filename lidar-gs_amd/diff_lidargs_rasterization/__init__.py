@@ -146,16 +146,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.beam_inclinations, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, grad_out_occ,
                 sh, rs.sh_degree, rs.campos, geom_buffer, ctx.num_rendered, binning_buffer, img_buffer, rs.debug)
+        # dL/dcov3D is an output only when the covariance was an input; with scales + rotations nobody receives it
+        want_cov = cov3Ds_precomp.numel() != 0
         if rs.debug:
             saved = _snapshot(args)
             try:
-                grads = _C.rasterize_gaussians_backward(*args)
+                grads = _C.rasterize_gaussians_backward(*args, want_cov3D_grad=want_cov)
             except Exception:
                 torch.save(saved, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise
         else:
-            grads = _C.rasterize_gaussians_backward(*args)
+            grads = _C.rasterize_gaussians_backward(*args, want_cov3D_grad=want_cov)
         grad_means2D, grad_colors, grad_opacities, grad_means3D, grad_cov3Ds, grad_sh, grad_scales, grad_rotations = grads
         # one slot per forward input, in forward's order (R3/.../__init__.py:150-160)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors, grad_opacities, grad_scales, grad_rotations,

@@ -69,17 +69,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, beam_inclinations, dL_dout_color, dL_dout_others, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_intermediates=True):
     """RasterizeGaussiansBackwardCUDA (R2/rasterize_points.cu:143-242).
 
     Returns (dL_dmeans2D[P,4], dL_dcolors[P,2], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dtransMat[P,9],
-    dL_dsh[P,M,3], dL_dscales[P,2], dL_drotations[P,4], depth[P,1])."""
+    dL_dsh[P,M,3], dL_dscales[P,2], dL_drotations[P,4], depth[P,1]).  want_intermediates=False: dL_dtransMat and the two
+    scratch gradients of the reference's kernel pair are not materialised (None is returned for dL_dtransMat)."""
     _require_device(means3D, "means3D")
     dev = means3D.device
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 and sh.ndim > 1 else 0
-    widths = (3, 4, NUM_CHANNELS, 3, 1, 9, 3, 2, 4, 1)       # the reference's torch::zeros list (:193-203), one slab here
+    skip = not want_intermediates
+    widths = (3, 4, NUM_CHANNELS, 0 if skip else 3, 1, 0 if skip else 9, 0 if skip else 3, 2, 4, 1)   # the reference's torch::zeros list (:193-203), one slab here
     slab = torch.empty(P * sum(widths), dtype=torch.float32, device=dev)   # every row is written by the library
     parts, o = [], 0
     for w in widths:
@@ -101,7 +103,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 C.c_int(int(bool(debug))), _stream(dev))
         if rc < 0:
             _raise(rc, "rasterize_gaussians_backward (surfel)")
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations, depth
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, (None if skip else dL_dtransMat), dL_dsh, dL_dscales, dL_drotations, depth
 
 
 def rasterize_aussians_filter(means3D, scales, rotations, scale_modifier, transMat_precomp, viewmatrix, projmatrix,

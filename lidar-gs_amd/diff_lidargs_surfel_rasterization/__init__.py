@@ -57,7 +57,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          _depth) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.beam_inclinations, grad_out_color, grad_others, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, rs.debug)
+            ctx.num_rendered, binning, img, rs.debug, want_intermediates=bool(cov3Ds_precomp.numel()))
         return (grad_means3D, grad_means2D, grad_sh if sh.numel() else None, grad_colors, grad_opacities, grad_scales,
                 grad_rotations, grad_transMat if cov3Ds_precomp.numel() else None, None)
 
