@@ -68,7 +68,8 @@ const char* lidargs_last_error(void);
 
 /* Rasterizer::forward -- R3/cr/rasterizer.h:31-58, R3/cr/rasterizer_impl.cu:202-359.
  * Outputs (caller-allocated, R3/rasterize_points.cu:71-75): out_color f32[2*H*W],
- * out_depth f32[H*W], out_occ f32[H*W], radii i32[P], radii_xy i32[2P].
+ * out_depth f32[H*W], out_occ f32[H*W], radii i32[P], radii_xy i32[2P] (may be NULL: the reference's binding never
+ * returns it, R3/rasterize_points.cu:75).
  * Returns num_rendered (>= 0) to be passed back to lidargs_backward as R. */
 int lidargs_forward(
     lidargs_alloc_fn geometry_alloc, void* geometry_user,

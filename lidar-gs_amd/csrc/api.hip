@@ -308,7 +308,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (height < 2) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: need at least 2 beams%s");
     if (height > 65535 || width > 65535 * 16) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: image too large%s");
     if (colors_precomp == nullptr) return fail(LIDARGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!%s");
-    if (!means3D || !opacities || !viewmatrix || !beams || !out_color || !out_depth || !out_occ || !radii || !radii_xy)
+    if (!means3D || !opacities || !viewmatrix || !beams || !out_color || !out_depth || !out_occ || !radii)   // radii_xy: optional
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: NULL required pointer%s");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: need scales+rotations or cov3D_precomp%s");
     if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: NULL allocator%s");
@@ -587,7 +587,7 @@ int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user,
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height < 2) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "visible_filter: bad sizes%s");
     if (P == 0) return 0;
-    if (!means3D || !viewmatrix || !beam_inclinations || !radii || !radii_xy)
+    if (!means3D || !viewmatrix || !beam_inclinations || !radii)   // radii_xy: optional
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "visible_filter: NULL required pointer%s");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "visible_filter: need scales+rotations or cov3D_precomp%s");
     const lg::TileGrid grid = lg::make_grid(width, height, tile_rows());

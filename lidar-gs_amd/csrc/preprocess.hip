@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
 
     if (in_range) {
         a.radii[idx] = out_radius;
-        a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0;  // every row written: callers need not pre-zero
+        if (a.radii_xy) { a.radii_xy[2 * idx] = live ? rx : 0; a.radii_xy[2 * idx + 1] = live ? ry : 0; }  // every row written: callers need not pre-zero; NULL: not wanted
     }
     if (FILTER) return;
     {   // instance totals for tile heights 4 / 8 / 16 / 32 (the host picks the height from them, api.hip choose_tile_rows): one block

@@ -147,7 +147,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     out_depth = mk((1, H, W), dtype=torch.float32, device=dev)
     out_occ = mk((1, H, W), dtype=torch.float32, device=dev)
     radii = mk((P,), dtype=torch.int32, device=dev)
-    radii_xy = mk((2 * P,), dtype=torch.int32, device=dev)
+    radii_xy = None           # the reference's binding makes this [2P] tensor and never returns it (R3/rasterize_points.cu:75): NULL = not written
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     rendered = 0
     if P != 0:
@@ -241,8 +241,8 @@ def rasterize_aussians_filter(means3D, scales, rotations, scale_modifier, cov3D_
     _require_device(means3D, "means3D")
     dev = means3D.device
     P = int(means3D.size(0))
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    radii_xy = torch.zeros((2 * P,), dtype=torch.int32, device=dev)
+    radii = (torch.empty if P != 0 else torch.zeros)((P,), dtype=torch.int32, device=dev)   # every row is written by the library
+    radii_xy = None           # (as in the forward: the reference never returns it, R3/rasterize_points.cu:278)
     if P != 0:
         m3, sc, rot = _f32(means3D, "means3D"), _f32(scales, "scales"), _f32(rotations, "rotations")
         cov, vm, beams = _f32(cov3D_precomp, "cov3D_precomp"), _f32(viewmatrix, "viewmatrix"), _f32(beam_inclinations, "beam_inclinations")
