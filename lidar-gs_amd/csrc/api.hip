@@ -352,7 +352,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     //    (2 KB into pinned memory) is queued here, the sort behind it, and the host waits for the copy while the sort runs.
     if (!enqueue_only) LG_HIP((hipError_t)lg::api_read_words_begin(geom.totals, LG_TOTALS_WORDS, stream));
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
-                                                 range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS);   // (the scratch is carved for 11-bit digits)
+                                                 range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true);   // (the scratch is carved for 11-bit digits; ids = positions)
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
     LG_STAGE_CHECK("range sort");
     g_prof.mark("range_sort", stream);

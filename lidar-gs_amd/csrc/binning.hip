@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
         const size_t i = base + (size_t)r * 64 + lane;
         const bool valid = i < n;
         k[r] = valid ? keys_in[i] : 0u;
-        v[r] = valid ? vals_in[i] : 0u;
+        v[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;    // vals_in == nullptr: the values are the positions (first pass of an id sort)
     }
     // global digit bases: exclusive scan of the digit totals (every block repeats this tiny scan)
     {
@@ -359,7 +359,7 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits) {
+                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions) {
     if (n == 0 || end_bit <= 0) return 0;
     if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
     if (scratch_bits < max_bits) scratch_bits = max_bits;
@@ -368,6 +368,7 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
     while (shift < end_bit) {
         const int left = end_bit - shift;
         uint32_t* kin = cur ? key_b : key_a; uint32_t* vin = cur ? val_b : val_a;
+        if (shift == 0 && vals_are_positions) vin = nullptr;              // val_a is not read (and need not have been written)
         uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
         // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4; 31 bits at 11 -> 11+10+10)
         const int passes_left = (left + max_bits - 1) / max_bits;

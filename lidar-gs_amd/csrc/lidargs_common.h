@@ -271,7 +271,8 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 // scratch_bits: the scratch holds sort_scratch_words(n, scratch_bits) words (0 = max_bits); room beyond the digit width lets small
 // inputs be sorted in half-size blocks (binning.hip radix_pass)
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr, int scratch_bits = 0);
+                            uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr, int scratch_bits = 0,
+                            bool vals_are_positions = false);   // true: the values are 0..n-1 and val_a is never read
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
 void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
                              size_t P, hipStream_t s);

@@ -349,7 +349,6 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     }
     if (!in_range) return;
     a.dkey[idx] = key;
-    a.ids[idx] = (uint32_t)idx;
     a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, t4, reftiles);   // an empty column span = no instances, whatever the row span holds
     if (live) {
         a.rowspan[idx] = rspan;

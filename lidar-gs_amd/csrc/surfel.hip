@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         }
     }
     if (!in_range) return;
-    a.dkey[idx] = key; a.ids[idx] = (uint32_t)idx;
+    a.dkey[idx] = key;                                                 // (the ids of the range sort are the positions: not written)
     a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, tiles, reftiles);   // lidargs_common.h: one gather per Gaussian when the lists are built
     if (live) {
         a.rowspan[idx] = rspan;
