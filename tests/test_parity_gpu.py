@@ -163,6 +163,36 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout
 
 
+@pytest.mark.parametrize("env", [{"LIDARGS_HEAD": "1"}, {"LIDARGS_HEAD": "1", "LIDARGS_ROUNDS": "2,6"}, {"LIDARGS_HEAD": "0", "LIDARGS_SEG_LEN": "128"},
+                                 {"LIDARGS_P2_GROUP": "3"}, {"LIDARGS_SORT_ITEMS": "16"}, {"LIDARGS_RANGE_SORT_BITS": "11"}],
+                         ids=["head5", "head2_rounds26", "nohead_seg128", "pass2_groups_of_3", "sort_blocks_4096", "sort_digits_11"])
+def test_plan_variants_are_invisible(env, hip_lib_built):
+    """The segment plan is an internal choice too: round 1 as the complete walk of the list heads (what the big frames take by default:
+    k_render_pass2_grouped<true>, here forced onto the 64-entry plan with heads of 5 and 2 segments), pass 2 over groups of segments
+    behind a head, no head on 128-entry segments, the sort's block size and digit width -- the image and the gradients must not
+    depend on any of it."""
+    import os, subprocess, sys
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import lidargs_scenes as sc
+from util import hip_forward_backward, oracle_forward_backward, parity, GRAD_KEYS_SR
+for kind, P, H, W, seed in (("street", 60000, 32, 800, 11), ("shell", 20000, 16, 512, 12)):
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    hip = hip_forward_backward(scene, W, H, grads)
+    for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+        parity(kind + "." + k, hip[k], ref[k])
+print("OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "lidar-gs_amd"), os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "OK" in r.stdout
+
+
 def test_adaptive_tile_height_is_chosen_and_invisible(hip_lib_built):
     """Tall footprints (scale_modifier 6 on a 64-beam view) make the adaptive choice leave the default 4-row tiles;
     the results must still match the oracle, which knows nothing about tile heights."""
