@@ -255,6 +255,35 @@ def test_backward_twice_on_one_forward(hip_lib_built):
         parity("other forward's backward", c.cpu().numpy(), a.cpu().numpy(), verbose=False)
 
 
+def test_intermediate_gradients_are_optional(hip_lib_built):
+    """dL_dcov3D is an output only when the covariance was an input: with scales + rotations the module asks the binding not to
+    materialise it (want_cov3D_grad=False).  The binding's own surface still returns it by default, it still matches the oracle, and
+    leaving it out changes no other gradient."""
+    import torch
+    from diff_lidargs_rasterization import _C
+    from util import to_torch, oracle_forward_backward
+    H, W, P = 32, 600, 20000
+    scene = sc.make_scene("street", P, H, 33, random_view=True)
+    grads = sc.upstream_grads(H, W, 33)
+    st = to_torch(scene)
+    empty = torch.empty(0, device="cuda")
+    fwd = _C.rasterize_gaussians(st["bg"], st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"], 1.0, empty,
+                                 st["viewmatrix"], st["viewmatrix"], H, W, st["beams"], empty, 1, empty, False, 80, 0, False)
+    R, radii, geom, binning, img = fwd[0], fwd[4], fwd[5], fwd[6], fwd[7]
+    gc, gd, go = (torch.from_numpy(g).cuda() for g in grads)
+    bw = lambda **kw: _C.rasterize_gaussians_backward(st["bg"], st["means3D"], radii, st["colors"], st["scales"], st["rotations"], 1.0, empty,
+                                                      st["viewmatrix"], st["viewmatrix"], st["beams"], 1.0, 1.0, gc, gd, go, empty, 1, empty,
+                                                      geom, R, binning, img, False, **kw)
+    full, lean = bw(), bw(want_cov3D_grad=False)
+    assert full[4] is not None and tuple(full[4].shape) == (P, 6) and lean[4] is None
+    ref = oracle_forward_backward(scene, W, H, grads)
+    if "dL_dcov3D" in ref:
+        parity("dL_dcov3D (scales + rotations path)", full[4].cpu().numpy(), ref["dL_dcov3D"])
+    for i, (a, b) in enumerate(zip(full, lean)):
+        if i != 4:
+            parity(f"output {i} without dL_dcov3D", b.cpu().numpy(), a.cpu().numpy(), verbose=False)   # (float atomics: two launches)
+
+
 def test_unused_outputs_have_no_gradient(hip_lib_built):
     """A loss that reads only `color`: autograd hands no gradient for depth / occ (none is materialised), which must equal
     passing zeros for them."""
