@@ -26,7 +26,7 @@ thread_local char g_err[512] = "";
 // diagnostics of the last forward ON THIS THREAD (lidargs_last_counters); never read by the compute path
 thread_local long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 thread_local const uint8_t* g_last_flags = nullptr; thread_local size_t g_last_flags_R = 0, g_last_flags_stride = 0; thread_local int g_last_flags_planes = 0;
-thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's spans
+thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals (geometry buffer)
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -231,12 +231,12 @@ int api_read_words_end(int n, uint32_t* out) {
     if (e == hipSuccess) memcpy(out, t_host_read.words, (size_t)n * sizeof(uint32_t));
     return (int)e;
 }
-void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans, const uint8_t* flags, size_t flags_stride,
+void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* totals, const uint8_t* flags, size_t flags_stride,
                       int flags_planes) {   // diagnostics only (lidargs_last_counters)
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = R; g_counters[3] = -1; g_counters[4] = TH; g_counters[5] = tiles;
     g_counters[6] = flags ? -1 : 0; g_counters[7] = S;
     g_last_flags = flags; g_last_flags_R = (size_t)R; g_last_flags_stride = flags_stride; g_last_flags_planes = flags_planes;
-    g_last_totals_dev = (uint32_t*)spans;
+    g_last_totals_dev = (uint32_t*)totals;
 }
 int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }
 size_t api_rendered_capacity(int nr) { return rendered_capacity(nr); }
@@ -330,6 +330,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     pp.scale_modifier = scale_modifier;
     pp.near_f = near_f; pp.far_f = far_f; pp.shell_lo = shell_lo; pp.shell_hi = shell_hi;
     pp.tile_x_lo = 0; pp.tile_x_hi = grid4.tiles_x;
+    pp.compact = lg::compact_spans(grid4.tiles_x, height) ? 1 : 0;
     if (col_lo >= 0) {                                                   // column wedge: whole 16-pixel tile columns
         if (col_lo % LG_TILE_W || (col_hi % LG_TILE_W && col_hi != width) || col_hi <= col_lo || col_hi > width)
             return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: a column wedge must be [multiple of 16, multiple of 16 or width)%s");
@@ -350,7 +351,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     //    valid one (valid keys are < bits(lidar_far) < 0x7FFFFFFF)
     //    Everything the host decides on -- the instance totals per tile height -- is known once the preprocess has run: their copy
     //    (2 KB into pinned memory) is queued here, the sort behind it, and the host waits for the copy while the sort runs.
-    if (!enqueue_only) LG_HIP((hipError_t)lg::api_read_words_begin(geom.totals, LG_TOTALS_WORDS, stream));
+    if (!enqueue_only) LG_HIP((hipError_t)lg::api_read_words_begin(geom.totals, LG_TOTALS_READ_WORDS, stream));
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
                                                  range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true);   // (the scratch is carved for 11-bit digits; ids = positions)
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
@@ -365,8 +366,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     size_t R;
     uint32_t* status_dev = geom.totals + LG_TOTALS_STATUS_WORD;
     if (!enqueue_only) {
-        uint32_t totals_h[LG_TOTALS_WORDS];                                // the slots of 64-bit instance totals the preprocess filled
-        LG_HIP((hipError_t)lg::api_read_words_end(LG_TOTALS_WORDS, totals_h));
+        uint32_t totals_h[LG_TOTALS_READ_WORDS];                           // the slots of 64-bit instance totals the preprocess filled
+        LG_HIP((hipError_t)lg::api_read_words_end(LG_TOTALS_READ_WORDS, totals_h));
         unsigned long long inst[4] = {0, 0, 0, 0};
         for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
             unsigned long long v[4];
@@ -378,12 +379,12 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         const unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : inst[3]));
         if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
         R = (size_t)R64;
-        lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
         LG_STAGE_CHECK("instance scan");
     } else {
         TH = fixed_tile_rows;
         R = (size_t)instance_capacity;                                     // the capacity stands in for the count everywhere on the host
-        lg::launch_instance_offsets(ids_sorted, geom.spans, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
         LG_STAGE_CHECK("instance scan");
         lg::launch_finish_totals(geom.totals, reinterpret_cast<const unsigned long long*>(geom.totals + LG_TOTALS_SLOT_WORD),
                                  (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);
@@ -407,7 +408,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // 3. emit instances in range order, bin them by tile (stable)
     const uint32_t* point_list = bin.val_a;
     if (R) {
-        lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, (size_t)P, grid,
+        lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, pp.compact != 0, (size_t)P, grid,
                                   bin.tile_a, bin.val_a, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
@@ -454,7 +455,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_counters[5] = grid.num_tiles();
     g_counters[6] = -1; g_counters[7] = S;
     g_last_flags = ra.flags; g_last_flags_R = R; g_last_flags_stride = Rp; g_last_flags_planes = grid.waves_per_tile;
-    g_last_totals_dev = (uint32_t*)geom.spans;   // R_ref / V are reduced lazily in lidargs_last_counters (word 3 of each span)
+    g_last_totals_dev = geom.totals;             // R_ref / V are summed lazily in lidargs_last_counters (the diagnostic slots)
     return rendered;
 }
 
@@ -596,7 +597,7 @@ int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user,
     pp.scale_modifier = scale_modifier;
     pp.near_f = (float)lidar_near; pp.far_f = (float)lidar_far;
     pp.shell_lo = -std::numeric_limits<float>::infinity(); pp.shell_hi = std::numeric_limits<float>::infinity();
-    pp.tile_x_lo = 0; pp.tile_x_hi = grid.tiles_x;
+    pp.tile_x_lo = 0; pp.tile_x_hi = grid.tiles_x; pp.compact = 0;
     const float pi_f = 3.14159265358979323846f;
     pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;
     pp.tan_col_step = tanf(2 * pi_f / width);
@@ -821,15 +822,13 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
 
 int lidargs_last_counters(long long* out, int n) {
     if (g_counters[1] < 0 && g_last_totals_dev && g_counters[0] > 0) {
-        // reduce ref_tiles on the host (diagnostics path, not on any timed path)
-        const size_t P = (size_t)g_counters[0];
-        uint32_t* h = (uint32_t*)malloc(4 * P * sizeof(uint32_t));
-        if (h && hipMemcpy(h, g_last_totals_dev, 4 * P * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+        // the preprocess summed the visible Gaussians and the reference's tiles_touched into LG_INST_SLOTS slots (diagnostics path)
+        unsigned long long h[2 * LG_INST_SLOTS];
+        if (hipMemcpy(h, g_last_totals_dev + LG_TOTALS_DIAG_WORD, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
             long long v = 0, r = 0;
-            for (size_t i = 0; i < P; i++) { if (h[4 * i + 3]) v++; r += h[4 * i + 3]; }
+            for (int i = 0; i < LG_INST_SLOTS; i++) { v += (long long)h[2 * i]; r += (long long)h[2 * i + 1]; }
             g_counters[1] = v; g_counters[3] = r;
         }
-        free(h);
     }
     if (g_counters[6] < 0 && g_last_flags && g_last_flags_R) {
         const size_t nbytes = g_last_flags_stride * (size_t)g_last_flags_planes;

@@ -404,22 +404,41 @@ __device__ __forceinline__ uint32_t span_tiles(uint32_t xs, uint32_t rs, int th_
 //   k_gather_spans   one 16-byte gather per Gaussian -> its spans in range order + the block's instance count -> block_sum[block]
 //   k_scan_partials  exclusive prefix of the block sums, grand total (= R) -> what the host reads
 //   k_emit_instances re-derives the counts from the range-ordered spans and scans them inside the block
-__global__ void __launch_bounds__(256) k_gather_spans(const uint32_t* __restrict__ ids_sorted, const uint4* __restrict__ spans, int th_shift,
-                                                      uint2* __restrict__ span_sorted, uint32_t* __restrict__ block_sum, size_t P) {
+// COMPACT: 4-byte span records (lidargs_common.h span_pack) in and out instead of 16 / 8 bytes.
+template <bool COMPACT>
+__global__ void __launch_bounds__(256) k_gather_spans(const uint32_t* __restrict__ ids_sorted, const void* __restrict__ spans_, int th_shift,
+                                                      void* __restrict__ span_sorted_, uint32_t* __restrict__ block_sum, size_t P) {
     __shared__ uint32_t ws[4];
     const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     uint32_t id[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) { const size_t i = base + (size_t)r * 256; id[r] = i < P ? ids_sorted[i] : 0xFFFFFFFFu; }
-    uint4 sp[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) sp[r] = id[r] != 0xFFFFFFFFu ? spans[id[r]] : make_uint4(0u, 0u, 0u, 0u);     // four gathers in flight
     uint32_t sum = 0;
+    if (COMPACT) {
+        const uint32_t* spans = static_cast<const uint32_t*>(spans_);
+        uint32_t* span_sorted = static_cast<uint32_t*>(span_sorted_);
+        uint32_t w[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const size_t i = base + (size_t)r * 256;
-        if (i < P) span_sorted[i] = make_uint2(sp[r].y, sp[r].x);
-        sum += span_tiles(sp[r].y, sp[r].x, th_shift);
+        for (int r = 0; r < 4; r++) w[r] = id[r] != 0xFFFFFFFFu ? spans[id[r]] : 0xFFFFFFFFu;                 // four gathers in flight
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t i = base + (size_t)r * 256;
+            if (i < P) span_sorted[i] = w[r];
+            const uint2 xr = span_unpack(w[r]);
+            sum += span_tiles(xr.x, xr.y, th_shift);
+        }
+    } else {
+        const uint4* spans = static_cast<const uint4*>(spans_);
+        uint2* span_sorted = static_cast<uint2*>(span_sorted_);
+        uint4 sp[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) sp[r] = id[r] != 0xFFFFFFFFu ? spans[id[r]] : make_uint4(0u, 0u, 0u, 0u); // four gathers in flight
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t i = base + (size_t)r * 256;
+            if (i < P) span_sorted[i] = make_uint2(sp[r].y, sp[r].x);
+            sum += span_tiles(sp[r].y, sp[r].x, th_shift);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -428,12 +447,13 @@ __global__ void __launch_bounds__(256) k_gather_spans(const uint32_t* __restrict
     if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 // spans in range order + exclusive block offsets in `block_off` (scan_blocks(P) words) + the instance total in *total_out
-void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
-                             size_t P, hipStream_t s) {
+void launch_instance_offsets(const uint32_t* ids_sorted, const void* spans, bool compact, int TH, void* span_sorted, uint32_t* block_off,
+                             uint32_t* total_out, size_t P, hipStream_t s) {
     int sh = 0;
     while ((1 << sh) < TH) sh++;
     const size_t nb = scan_blocks(P);
-    hipLaunchKernelGGL(k_gather_spans, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
+    if (compact) hipLaunchKernelGGL(k_gather_spans<true>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
+    else hipLaunchKernelGGL(k_gather_spans<false>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, block_off, nb, total_out);
 }
 
@@ -441,14 +461,16 @@ void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int
 // instances cooperatively, 64 consecutive output slots per step (coalesced 256-B stores),
 // instead of one thread looping over its own rect (the reference's duplicateWithKeys,
 // R3/cr/rasterizer_impl.cu:70-112, whose per-thread trip count varies 1..100s).
+template <bool COMPACT>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ block_off,
-                                                               const uint2* __restrict__ span_sorted, size_t P, int th_shift, int tiles_x,
+                                                               const void* __restrict__ span_sorted_, size_t P, int th_shift, int tiles_x,
                                                                uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap) {
     __shared__ uint32_t s_tot[SCAN_BLOCK / 64];                        // instance count of each wave's 64 Gaussians
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const bool valid = i < P;
-    const uint2 sp = valid ? span_sorted[i] : make_uint2(0u, 0u);      // (xspan, rowspan); an empty column span = no instances
+    uint2 sp = make_uint2(0u, 0u);                                     // (xspan, rowspan); an empty column span = no instances
+    if (valid) sp = COMPACT ? span_unpack(static_cast<const uint32_t*>(span_sorted_)[i]) : static_cast<const uint2*>(span_sorted_)[i];
     const uint32_t cnt = span_tiles(sp.x, sp.y, th_shift);
     const uint32_t inc = wave_incl_scan(cnt, lane);
     if (lane == 63) s_tot[w] = inc;
@@ -493,12 +515,14 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
     }
 }
 
-void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap) {
     int sh = 0;
     while ((1 << sh) < grid.TH) sh++;
-    hipLaunchKernelGGL(k_emit_instances, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted, P, sh,
-                       grid.tiles_x, inst_tile, inst_val, cap);
+    if (compact) hipLaunchKernelGGL(k_emit_instances<true>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
+                                    P, sh, grid.tiles_x, inst_tile, inst_val, cap);
+    else hipLaunchKernelGGL(k_emit_instances<false>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
+                            P, sh, grid.tiles_x, inst_tile, inst_val, cap);
 }
 
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles

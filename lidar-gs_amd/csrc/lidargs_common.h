@@ -74,6 +74,26 @@ inline size_t sort_scratch_words(size_t n, int max_bits = SORT_RADIX_BITS) {
 }
 inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 
+// Per-Gaussian span record the instance offsets and the emit are built from.  Full form: u32x4 (rowspan = lo | hi << 16 in pixel
+// rows, xspan = x0 | x1 << 16 in 16-pixel tile columns, 0 = no instances, -, -).  COMPACT form, whenever the image has at most 256
+// tile columns and 256 pixel rows (64x2650 and 128x4096 do): ONE u32 = x0 | (nx - 1) << 8 | lo << 16 | (hi - 1) << 24, 0xFFFFFFFF =
+// no instances.  The spans are gathered at random in range order (k_gather_spans): with 16-byte records every 128-byte line of a
+// 32-MB table is fetched for one record (measured 243 MB of fabric traffic for 2 M Gaussians); the 8-MB table of compact records
+// stays in the L2s / MALL.
+inline bool compact_spans(int tiles_x, int H) { return tiles_x <= 256 && H <= 256; }
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t span_pack(uint32_t rs, uint32_t xs) {
+    if (!xs) return 0xFFFFFFFFu;
+    const uint32_t x0 = xs & 0xFFFFu, x1 = xs >> 16, lo = rs & 0xFFFFu, hi = rs >> 16;
+    return x0 | ((x1 - x0 - 1u) << 8) | (lo << 16) | ((hi - 1u) << 24);
+}
+__device__ __forceinline__ uint2 span_unpack(uint32_t w) {            // -> (xspan, rowspan)
+    if (w == 0xFFFFFFFFu) return make_uint2(0u, 0u);
+    const uint32_t x0 = w & 255u, nx = ((w >> 8) & 255u) + 1u, lo = (w >> 16) & 255u, hi = (w >> 24) + 1u;
+    return make_uint2(x0 | ((x0 + nx) << 16), lo | (hi << 16));
+}
+#endif
+
 // totals: word 0 = instance total of the scan; from word LG_TOTALS_SLOT_WORD on, LG_INST_SLOTS slots of four 64-bit sums (the
 // instance counts for tile heights 4 / 8 / 16 / 32), one 32-byte slot per group of preprocess blocks
 #define LG_INST_SLOTS 64
@@ -84,7 +104,11 @@ inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 // behind the slots: the 16 status words of an enqueue-only forward (binning.hip k_finish_totals)
 #define LG_TOTALS_STATUS_WORD (LG_TOTALS_SLOT_WORD + 8 * LG_INST_SLOTS)
 #define LG_STATUS_WORDS 16
-#define LG_TOTALS_WORDS (LG_TOTALS_STATUS_WORD + LG_STATUS_WORDS)
+#define LG_TOTALS_READ_WORDS (LG_TOTALS_STATUS_WORD + LG_STATUS_WORDS)      // what the forward's host read copies
+// behind that: LG_INST_SLOTS diagnostic slots of two 64-bit sums (visible Gaussians, reference 16x1 tiles_touched): read only by
+// lidargs_last_counters
+#define LG_TOTALS_DIAG_WORD LG_TOTALS_READ_WORDS
+#define LG_TOTALS_WORDS (LG_TOTALS_DIAG_WORD + 4 * LG_INST_SLOTS)
 struct GeomView {
     float4* rec;
     uint32_t* rowspan;
@@ -208,6 +232,7 @@ struct PreprocessParams {
     float near_f, far_f;        // reference int near/far converted to float (R3/cr/forward.cu:304)
     float shell_lo, shell_hi;   // extra float range shell: keep lo <= range < hi (multi-GPU); +-inf otherwise
     int tile_x_lo, tile_x_hi;   // tile-column window [lo, hi) this call bins and renders (multi-GPU column wedges); 0, tiles_x otherwise
+    int compact;                // 4-byte span records (compact_spans(tiles_x, H))
     float col_step;             // 2*pi/W        (float, as the reference evaluates it)
     float inv_col_step;         // a bound from above on 1 / col_step (footprint pruning only)
     float tan_col_step;         // tanf(2*pi/W)  (host libm)
@@ -274,9 +299,9 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
                             uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr, int scratch_bits = 0,
                             bool vals_are_positions = false);   // true: the values are 0..n-1 and val_a is never read
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
-void launch_instance_offsets(const uint32_t* ids_sorted, const uint4* spans, int TH, uint2* span_sorted, uint32_t* block_off, uint32_t* total_out,
-                             size_t P, hipStream_t s);
-void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const uint2* span_sorted, size_t P, TileGrid grid,
+void launch_instance_offsets(const uint32_t* ids_sorted, const void* spans, bool compact, int TH, void* span_sorted, uint32_t* block_off,
+                             uint32_t* total_out, size_t P, hipStream_t s);   // compact: 4-byte span records (span_pack)
+void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr);
 

@@ -109,7 +109,8 @@ struct PreKernelArgs {
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
     float4* gacc;                       // [4P] packed gradient lines of the backward: zeroed here for every Gaussian with radii > 0
-    unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: instance counts for tile heights 4, 8, 16 (zeroed by the caller)
+    unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: instance counts for tile heights 4, 8, 16, 32 (zeroed by the caller)
+    unsigned long long* diag_slots;     // [LG_INST_SLOTS][2]: visible Gaussians, reference tiles_touched (diagnostics)
     float2* coltab; float2* rowtab;     // pixel-ray tables for the blend, filled by the first workgroups (nullptr: not wanted)
 };
 
@@ -320,15 +321,26 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     {   // instance totals for tile heights 4 / 8 / 16 / 32 (the host picks the height from them, api.hip choose_tile_rows): one block
         // sum, added to one of LG_INST_SLOTS slots -- 31 k waves adding to the same three words cost a millisecond, 7.8 k blocks
         // spread over 64 lines do not show; the host adds the slots up after its one read
-        __shared__ uint32_t s_part[4][4];
-        uint32_t s4 = t4, s8 = t8, s16 = t16, s32 = t32;
+        // (two more sums ride along for lidargs_last_counters: the visible Gaussians and the reference's 16x1 tiles_touched)
+        __shared__ uint32_t s_part[4][6];
+        uint32_t s4 = t4, s8 = t8, s16 = t16, s32 = t32, sv = reftiles ? 1u : 0u, sr = reftiles;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s4 += __shfl_xor(s4, o); s8 += __shfl_xor(s8, o); s16 += __shfl_xor(s16, o); s32 += __shfl_xor(s32, o); }
-        if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = s4; s_part[threadIdx.x >> 6][1] = s8; s_part[threadIdx.x >> 6][2] = s16; s_part[threadIdx.x >> 6][3] = s32; }
+        for (int o = 32; o > 0; o >>= 1) {
+            s4 += __shfl_xor(s4, o); s8 += __shfl_xor(s8, o); s16 += __shfl_xor(s16, o); s32 += __shfl_xor(s32, o);
+            sv += __shfl_xor(sv, o); sr += __shfl_xor(sr, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t* q = s_part[threadIdx.x >> 6];
+            q[0] = s4; q[1] = s8; q[2] = s16; q[3] = s32; q[4] = sv; q[5] = sr;
+        }
         __syncthreads();
-        if (threadIdx.x < 4) {
+        if (threadIdx.x < 6) {
             const uint32_t sum = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
-            if (sum) atomicAdd(a.inst_slots + (size_t)(blockIdx.x % LG_INST_SLOTS) * 4 + threadIdx.x, (unsigned long long)sum);
+            const size_t slot = (size_t)(blockIdx.x % LG_INST_SLOTS);
+            if (sum) {
+                if (threadIdx.x < 4) atomicAdd(a.inst_slots + slot * 4 + threadIdx.x, (unsigned long long)sum);
+                else atomicAdd(a.diag_slots + slot * 2 + (threadIdx.x - 4), (unsigned long long)sum);
+            }
         }
     }
     // The backward blend adds into the packed 64-byte gradient line of a Gaussian: the lines are zeroed here, where the kernel has
@@ -349,7 +361,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     }
     if (!in_range) return;
     a.dkey[idx] = key;
-    a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, t4, reftiles);   // an empty column span = no instances, whatever the row span holds
+    // an empty column span = no instances, whatever the row span holds
+    if (pp.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(rspan, tiles ? xsp : 0u);
+    else a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, 0u, 0u);
     if (live) {
         a.rowspan[idx] = rspan;
         float4* r = a.rec + 4 * (size_t)idx;
@@ -368,6 +382,7 @@ void launch_preprocess(const PreprocessParams& pp, const float* means3D, const f
     a.rec = g.rec; a.rowspan = g.rowspan; a.spans = g.spans; a.dkey = g.key_a; a.ids = g.id_a;
     a.gacc = reinterpret_cast<float4*>(g.gacc);
     a.inst_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_SLOT_WORD);
+    a.diag_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_DIAG_WORD);
     const dim3 grid((pp.P + 255) / 256), block(256);
     if (filter_only) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, a);

@@ -92,6 +92,8 @@ struct SfPreArgs {
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
     uint32_t* dirty;       // the geometry buffer's "gradient lines hold sums" word (LG_TOTALS_DIRTY_WORD): cleared here
     unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: word 0 of each slot = part of the instance total (zeroed by the caller)
+    unsigned long long* diag_slots;     // [LG_INST_SLOTS][2]: visible surfels, reference tiles_touched (diagnostics)
+    int compact;                        // 4-byte span records (compact_spans)
     float4* gacc;          // [8P] packed gradient lines of the backward: zeroed here for every surfel with radii > 0
 };
 
@@ -183,11 +185,15 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     if (FILTER) return;
     {   // the instance total (what the host sizes the binning buffer with), known before anything is sorted: one sum per wave, added
         // to one of LG_INST_SLOTS slots (k_preprocess has the same, per tile height); the host adds the slots up after its one read
-        uint32_t sum = tiles;
+        uint32_t sum = tiles, sv = reftiles ? 1u : 0u, sr = reftiles;       // (+ the diagnostics of lidargs_last_counters)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if ((threadIdx.x & 63) == 0 && sum)
-            atomicAdd(a.inst_slots + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % LG_INST_SLOTS) * 4, (unsigned long long)sum);
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sv += __shfl_xor(sv, o); sr += __shfl_xor(sr, o); }
+        if ((threadIdx.x & 63) == 0 && sv) {
+            const size_t slot = (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % LG_INST_SLOTS);
+            if (sum) atomicAdd(a.inst_slots + slot * 4, (unsigned long long)sum);
+            atomicAdd(a.diag_slots + slot * 2, (unsigned long long)sv);
+            atomicAdd(a.diag_slots + slot * 2 + 1, (unsigned long long)sr);
+        }
     }
     // the packed 128-byte gradient lines the backward adds into are zeroed here, not by a 128 B x P fill launch per frame: the wave
     // writes the 8 KB of its 64 surfels as eight contiguous 1-KB stores
@@ -206,7 +212,9 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     }
     if (!in_range) return;
     a.dkey[idx] = key;                                                 // (the ids of the range sort are the positions: not written)
-    a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, tiles, reftiles);   // lidargs_common.h: one gather per Gaussian when the lists are built
+    // lidargs_common.h: one gather per Gaussian when the lists are built (4-byte records when the image allows)
+    if (a.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(rspan, tiles ? xsp : 0u);
+    else a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, 0u, 0u);
     if (live) {
         a.rowspan[idx] = rspan;
         float4* r = a.rec + 5 * (size_t)idx;

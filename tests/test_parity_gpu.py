@@ -193,6 +193,21 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout
 
 
+@pytest.mark.parametrize("H,W", [(16, 4128), (272, 512)], ids=["258_tile_columns", "272_rows"])
+def test_images_too_big_for_compact_span_records(H, W, hip_lib_built):
+    """The per-Gaussian span record the tile lists are built from is ONE 32-bit word while the image has at most 256 tile columns
+    and 256 rows (csrc/lidargs_common.h span_pack), and the 16-byte form beyond: both forms against the oracle (every other test
+    of this file runs the compact one)."""
+    from util import hip_forward_backward, oracle_forward_backward, GRAD_KEYS_SR
+    scene = sc.make_scene("shell", 15000, H, 77, random_view=True)
+    grads = sc.upstream_grads(H, W, 77)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    hip = hip_forward_backward(scene, W, H, grads)
+    assert np.array_equal(hip["radii"], ref["radii"])
+    for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+        parity(k, hip[k], ref[k])
+
+
 def test_adaptive_tile_height_is_chosen_and_invisible(hip_lib_built):
     """Tall footprints (scale_modifier 6 on a 64-beam view) make the adaptive choice leave the default 4-row tiles;
     the results must still match the oracle, which knows nothing about tile heights."""
