@@ -466,6 +466,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
                                                                const void* __restrict__ span_sorted_, size_t P, int th_shift, int tiles_x,
                                                                uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap) {
     __shared__ uint32_t s_tot[SCAN_BLOCK / 64];                        // instance count of each wave's 64 Gaussians
+    __shared__ uint32_t s_own[SCAN_BLOCK / 64][64];                    // per wave: the lane whose instances start at each slot of the window
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const bool valid = i < P;
@@ -486,15 +487,27 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
     const uint32_t wave_total = __shfl(inc, 63);
     const uint32_t lo = valid ? inc - cnt : 0xFFFFFFFFu;               // local exclusive prefix (+inf past the end)
     const uint32_t t_end = (wave_total + 63u) & ~63u;                  // every lane takes part in the shuffles
+    uint32_t carry = 0;                                                // owner of the slot in front of the window
     for (uint32_t t = lane; t < t_end; t += 64) {
-        // owner = largest lane L with lo_L <= t  (zero-count lanes share their successor's lo and lose)
-        int a = 0, b = 63;
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int mid = (a + b + 1) >> 1;
-            const uint32_t v = __shfl(lo, mid);
-            if (v <= t) a = mid; else b = mid - 1;
-        }
+        // owner = largest lane L with cnt_L > 0 and lo_L <= t.  Every such lane marks the slot its instances start at (inside this
+        // window of 64 slots) with its index; an inclusive max-scan over the window, seeded with the owner in front of it, is the
+        // owner of every slot -- 6 row-shift / broadcast steps instead of a 6-step binary search through 6 lane permutes.
+        // (One wave owns s_own[w][]: its LDS operations execute in program order.)
+        const uint32_t t0 = t - (uint32_t)lane;
+        s_own[w][lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (cnt && lo >= t0 && lo < t0 + 64u) s_own[w][lo - t0] = (uint32_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t m = s_own[w][lane];
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xF, 0xF, false));   // row_shr:1
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xF, 0xF, false));   // row_shr:2
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xF, 0xF, false));   // row_shr:4
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xF, 0xF, false));   // row_shr:8
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+        m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+        m = max(m, carry);
+        carry = __shfl(m, 63);
+        const int a = (int)m;
         const uint32_t o_lo = __shfl(lo, a), o_g = __shfl(g, a), o_nx = __shfl(nx, a), o_x0 = __shfl(x0, a), o_ty0 = __shfl(ty0, a);
         if (t < wave_total && wave_base + t < cap) {                  // cap: the binning buffer's capacity (enqueue-only forward); UINT_MAX otherwise
             const uint32_t jj = t - o_lo;
