@@ -11,9 +11,12 @@
 //                            rec[2] = (u1'.z, u2'.z, A, C)             interleaved by component and the conic's diagonal is a
 //                            rec[3] = (B, opacity, colour0, colour1)   pair: both projections run as packed-fp32 operations
 //     rowspan  u32[P]      ymin | ymax<<16 of the (pruned) pixel-row rect (R3/cr/auxiliary.h:80-92): read per list entry by the blend
-//     spans    u32x4[P]    (rowspan, xspan = xmin | xmax<<16 in 16-pixel tile columns (0 = no instances), instance count at
-//                           4-row tiles, the reference's 16x1 tiles_touched): ONE 16-byte gather per Gaussian when the lists are built
-//     span_sorted u32x2[P] (xspan, rowspan) in range order: the instance emit reads no per-Gaussian array at random
+//     spans    u32[P] (in a u32x4[P] area)   the pruned rect as ONE word, x0 | (nx - 1) << 8 | first row << 16 | last row << 24
+//                           (0xFFFFFFFF = no instances), while the image has <= 256 tile columns and <= 256 rows; beyond, u32x4
+//                           (rowspan, xspan = xmin | xmax<<16 in 16-pixel tile columns (0 = no instances), -, -): ONE gather per
+//                           Gaussian when the lists are built (span_pack / compact_spans below)
+//     span_sorted u32[P] | u32x2[P]  the same in range order (compact | (xspan, rowspan)): the instance emit reads no per-Gaussian
+//                           array at random
 //     key_a    u32[P]      float bits of the range (sort key), 0xFFFFFFFF when culled
 //     sort ping/pong, sorted ids, per-sorted-Gaussian instance offsets, scan/sort scratch
 //   binning buffer   (sized by R = #instances)
