@@ -254,13 +254,19 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     for (int r = 0; r < ITEMS; r++) {
         const bool valid = base + (size_t)r * 64 + lane < n;
         const uint32_t d = (k[r] >> shift) & (BINS - 1);
-        unsigned long long peers = __ballot(valid);
+        // peers = the lanes holding the same digit: for every digit bit, keep the lanes whose bit equals mine.  With `mine` = the bit
+        // spread over a word (0 / ~0), that is peers & ~(ballot ^ mine) -- ONE v_bitop3_b32 per 32 lanes and bit on gfx950
+        // (truth table 0x90 = a & ~(b ^ c)) instead of a select, an xor and an and.
+        const unsigned long long v0 = __ballot(valid);
+        uint32_t plo = (uint32_t)v0, phi = (uint32_t)(v0 >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
+            const uint32_t mine = (uint32_t)(((int)(d << (31 - b))) >> 31);
+            const unsigned long long m = __ballot(mine != 0u);
+            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, mine, 0x90);
+            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), mine, 0x90);
         }
+        const unsigned long long peers = ((unsigned long long)phi << 32) | plo;
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
         // one wave owns run[w][]: its LDS operations execute in program order (read, then the leaders' update)
         pos[r] = run[w][d] + rank;
