@@ -352,8 +352,11 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     //    Everything the host decides on -- the instance totals per tile height -- is known once the preprocess has run: their copy
     //    (2 KB into pinned memory) is queued here, the sort behind it, and the host waits for the copy while the sort runs.
     if (!enqueue_only) LG_HIP((hipError_t)lg::api_read_words_begin(geom.totals, LG_TOTALS_READ_WORDS, stream));
+    lg::RadixTail span_tail;                                           // the sort's last pass leaves the spans in range order as well
+    span_tail.src = geom.spans; span_tail.dst = geom.span_sorted; span_tail.mode = pp.compact ? 1 : 2;
     const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
-                                                 range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true);   // (the scratch is carved for 11-bit digits; ids = positions)
+                                                 range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true,   // (the scratch is carved for 11-bit digits; ids = positions)
+                                                 span_tail);
     const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
     LG_STAGE_CHECK("range sort");
     g_prof.mark("range_sort", stream);
@@ -379,12 +382,12 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         const unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : inst[3]));
         if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
         R = (size_t)R64;
-        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream, true);
         LG_STAGE_CHECK("instance scan");
     } else {
         TH = fixed_tile_rows;
         R = (size_t)instance_capacity;                                     // the capacity stands in for the count everywhere on the host
-        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream);
+        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream, true);
         LG_STAGE_CHECK("instance scan");
         lg::launch_finish_totals(geom.totals, reinterpret_cast<const unsigned long long*>(geom.totals + LG_TOTALS_SLOT_WORD),
                                  (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);

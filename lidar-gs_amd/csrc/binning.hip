@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        size_t n, const uint32_t* __restrict__ n_dev, int shift, const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
-                                                       const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks) {
+                                                       const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks, const RadixTail tail) {
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = 256 * ITEMS;                    // keys per block
     constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
@@ -321,7 +321,11 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
         const uint32_t kk = s_key[i];
         const uint32_t d = (kk >> shift) & (BINS - 1);
         const size_t g = (size_t)gbase[d] + (i - dbase[d]);
-        keys_out[g] = kk; vals_out[g] = s_val[i];
+        const uint32_t v = s_val[i];
+        vals_out[g] = v;
+        if (tail.mode == 0) keys_out[g] = kk;
+        else if (tail.mode == 1) static_cast<uint32_t*>(tail.dst)[g] = static_cast<const uint32_t*>(tail.src)[v];
+        else { const uint4 sp = static_cast<const uint4*>(tail.src)[v]; static_cast<uint2*>(tail.dst)[g] = make_uint2(sp.y, sp.x); }
     }
 }
 
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 // chain is the launch's length.
 template <int BITS, int ITEMS>
 static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
-                             uint32_t* scratch, hipStream_t s, int scratch_bits) {
+                             uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail) {
     const size_t cap_bins = (size_t)1 << scratch_bits;           // the scratch layout of sort_scratch_words(n, scratch_bits)
     constexpr size_t CHUNK = 256 * ITEMS;
     const unsigned nb = (unsigned)((n + CHUNK - 1) / CHUNK);
@@ -350,22 +354,23 @@ static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t*
     else hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
     hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
-                       two_level ? part : (const uint32_t*)nullptr, chunk, chunks);
+                       two_level ? part : (const uint32_t*)nullptr, chunk, chunks, tail);
 }
 template <int BITS>
 static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
-                       uint32_t* scratch, hipStream_t s, int scratch_bits) {
+                       uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail) {
     static const int env = [] { const char* e = getenv("LIDARGS_SORT_ITEMS"); return e ? atoi(e) : 0; }();   // 8 / 16 forces the block size
     const bool room = BITS + 1 <= scratch_bits;                  // twice the blocks x BINS <= the histogram area (and the chunk sums likewise)
     const bool half = room && (env ? env == 8 : n <= ((size_t)4 << 20));
     if constexpr (BITS <= 10) {
-        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); return; }
+        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail); return; }
     }
-    radix_pass_items<BITS, SORT_ITEMS>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits);
+    radix_pass_items<BITS, SORT_ITEMS>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail);
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
-                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions) {
+                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions,
+                            RadixTail tail) {
     if (n == 0 || end_bit <= 0) return 0;
     if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
     if (scratch_bits < max_bits) scratch_bits = max_bits;
@@ -379,18 +384,19 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
         // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4; 31 bits at 11 -> 11+10+10)
         const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
+        const bool last = shift + bits >= end_bit;                       // the tail (a gather by the sorted values) rides on the last pass
         switch (bits) {
-            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
-            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits); break;
+            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
         }
         shift += bits;
         cur ^= 1;
@@ -452,13 +458,36 @@ __global__ void __launch_bounds__(256) k_gather_spans(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
+// The same block sums from spans that are ALREADY in range order (the last pass of the range sort gathered them, RadixTail).
+template <bool COMPACT>
+__global__ void __launch_bounds__(256) k_span_block_sums(const void* __restrict__ span_sorted_, int th_shift, uint32_t* __restrict__ block_sum, size_t P) {
+    __shared__ uint32_t ws[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const size_t i = base + (size_t)r * 256;
+        if (i < P) {
+            const uint2 xr = COMPACT ? span_unpack(static_cast<const uint32_t*>(span_sorted_)[i]) : static_cast<const uint2*>(span_sorted_)[i];
+            sum += span_tiles(xr.x, xr.y, th_shift);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
 // spans in range order + exclusive block offsets in `block_off` (scan_blocks(P) words) + the instance total in *total_out
 void launch_instance_offsets(const uint32_t* ids_sorted, const void* spans, bool compact, int TH, void* span_sorted, uint32_t* block_off,
-                             uint32_t* total_out, size_t P, hipStream_t s) {
+                             uint32_t* total_out, size_t P, hipStream_t s, bool gathered) {
     int sh = 0;
     while ((1 << sh) < TH) sh++;
     const size_t nb = scan_blocks(P);
-    if (compact) hipLaunchKernelGGL(k_gather_spans<true>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
+    if (gathered) {
+        if (compact) hipLaunchKernelGGL(k_span_block_sums<true>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
+        else hipLaunchKernelGGL(k_span_block_sums<false>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
+    } else if (compact) hipLaunchKernelGGL(k_gather_spans<true>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
     else hipLaunchKernelGGL(k_gather_spans<false>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, block_off, nb, total_out);
 }

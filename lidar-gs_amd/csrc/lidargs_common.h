@@ -293,6 +293,10 @@ void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, con
                          const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
                          float* o_scales, float* o_rot, hipStream_t s);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s);
+// What the LAST pass of a sort may do instead of writing the sorted keys (which the range sort's callers never read): gather a
+// per-value record by the sorted value and write it at the value's final position -- mode 1: u32 src[val] -> u32 dst[pos] (compact
+// span records), mode 2: (y, x) of u32x4 src[val] -> u32x2 dst[pos].  The random gather then rides on a launch that exists anyway.
+struct RadixTail { const void* src = nullptr; void* dst = nullptr; int mode = 0; };
 // sorts (key,val) pairs on key bits [0,end_bit) in digits of at most max_bits (<= SORT_MAX_RADIX_BITS; 0 = SORT_RADIX_BITS);
 // result ends in (key_a,val_a) or (key_b,val_b): returns 0 for a, 1 for b
 // n_dev (nullable): the pair count lives on the device and n is only the capacity the launches cover
@@ -300,10 +304,12 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 // inputs be sorted in half-size blocks (binning.hip radix_pass)
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr, int scratch_bits = 0,
-                            bool vals_are_positions = false);   // true: the values are 0..n-1 and val_a is never read
+                            bool vals_are_positions = false,    // true: the values are 0..n-1 and val_a is never read
+                            RadixTail tail = RadixTail());
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
 void launch_instance_offsets(const uint32_t* ids_sorted, const void* spans, bool compact, int TH, void* span_sorted, uint32_t* block_off,
-                             uint32_t* total_out, size_t P, hipStream_t s);   // compact: 4-byte span records (span_pack)
+                             uint32_t* total_out, size_t P, hipStream_t s, bool gathered = false);   // compact: 4-byte span records (span_pack);
+                                                                            // gathered: span_sorted was filled by the range sort's last pass
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr);
