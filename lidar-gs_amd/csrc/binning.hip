@@ -317,15 +317,41 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 
     // D. stream out: thread i writes element i of the sorted block to its digit run
     const uint32_t count = (uint32_t)(n - blk_base < (size_t)CHUNK ? n - blk_base : (size_t)CHUNK);
-    for (uint32_t i = tid; i < count; i += 256) {
-        const uint32_t kk = s_key[i];
-        const uint32_t d = (kk >> shift) & (BINS - 1);
-        const size_t g = (size_t)gbase[d] + (i - dbase[d]);
-        const uint32_t v = s_val[i];
-        vals_out[g] = v;
-        if (tail.mode == 0) keys_out[g] = kk;
-        else if (tail.mode == 1) static_cast<uint32_t*>(tail.dst)[g] = static_cast<const uint32_t*>(tail.src)[v];
-        else { const uint4 sp = static_cast<const uint4*>(tail.src)[v]; static_cast<uint2*>(tail.dst)[g] = make_uint2(sp.y, sp.x); }
+    if (tail.mode == 0) {
+        for (uint32_t i = tid; i < count; i += 256) {
+            const uint32_t kk = s_key[i];
+            const uint32_t d = (kk >> shift) & (BINS - 1);
+            const size_t g = (size_t)gbase[d] + (i - dbase[d]);
+            keys_out[g] = kk; vals_out[g] = s_val[i];
+        }
+    } else {
+        // last pass with a tail: the sorted keys are not written; the record of every value is gathered (all of a thread's gathers
+        // in flight at once) and written at the value's final position
+        uint32_t v[ITEMS]; size_t g[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t i = tid + 256u * (uint32_t)r;
+            const uint32_t ii = i < count ? i : 0u;
+            const uint32_t kk = s_key[ii];
+            const uint32_t d = (kk >> shift) & (BINS - 1);
+            g[r] = (size_t)gbase[d] + (ii - dbase[d]);
+            v[r] = s_val[ii];
+        }
+        if (tail.mode == 1) {
+            uint32_t sp[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) sp[r] = (tid + 256u * (uint32_t)r < count) ? static_cast<const uint32_t*>(tail.src)[v[r]] : 0u;
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (tid + 256u * (uint32_t)r < count) { vals_out[g[r]] = v[r]; static_cast<uint32_t*>(tail.dst)[g[r]] = sp[r]; }
+        } else {
+            uint4 sp[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) sp[r] = (tid + 256u * (uint32_t)r < count) ? static_cast<const uint4*>(tail.src)[v[r]] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (tid + 256u * (uint32_t)r < count) { vals_out[g[r]] = v[r]; static_cast<uint2*>(tail.dst)[g[r]] = make_uint2(sp[r].y, sp[r].x); }
+        }
     }
 }
 
