@@ -382,12 +382,12 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         const unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : inst[3]));
         if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
         R = (size_t)R64;
-        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream, true);
+        lg::launch_instance_offsets(geom.span_sorted, pp.compact != 0, TH, geom.block_off, geom.totals, (size_t)P, stream);
         LG_STAGE_CHECK("instance scan");
     } else {
         TH = fixed_tile_rows;
         R = (size_t)instance_capacity;                                     // the capacity stands in for the count everywhere on the host
-        lg::launch_instance_offsets(ids_sorted, geom.spans, pp.compact != 0, TH, geom.span_sorted, geom.block_off, geom.totals, (size_t)P, stream, true);
+        lg::launch_instance_offsets(geom.span_sorted, pp.compact != 0, TH, geom.block_off, geom.totals, (size_t)P, stream);
         LG_STAGE_CHECK("instance scan");
         lg::launch_finish_totals(geom.totals, reinterpret_cast<const unsigned long long*>(geom.totals + LG_TOTALS_SLOT_WORD),
                                  (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);

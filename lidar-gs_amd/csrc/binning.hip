@@ -439,52 +439,12 @@ __device__ __forceinline__ uint32_t span_tiles(uint32_t xs, uint32_t rs, int th_
 }
 
 // Instance offsets without a per-Gaussian scan array.  A block of SCAN_BLOCK range-consecutive Gaussians:
-//   k_gather_spans   one 16-byte gather per Gaussian -> its spans in range order + the block's instance count -> block_sum[block]
+//   (range sort)     its last pass leaves every Gaussian's span record in range order (RadixTail)
+//   k_span_block_sums  the block's instance count -> block_sum[block]
 //   k_scan_partials  exclusive prefix of the block sums, grand total (= R) -> what the host reads
 //   k_emit_instances re-derives the counts from the range-ordered spans and scans them inside the block
-// COMPACT: 4-byte span records (lidargs_common.h span_pack) in and out instead of 16 / 8 bytes.
-template <bool COMPACT>
-__global__ void __launch_bounds__(256) k_gather_spans(const uint32_t* __restrict__ ids_sorted, const void* __restrict__ spans_, int th_shift,
-                                                      void* __restrict__ span_sorted_, uint32_t* __restrict__ block_sum, size_t P) {
-    __shared__ uint32_t ws[4];
-    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    uint32_t id[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const size_t i = base + (size_t)r * 256; id[r] = i < P ? ids_sorted[i] : 0xFFFFFFFFu; }
-    uint32_t sum = 0;
-    if (COMPACT) {
-        const uint32_t* spans = static_cast<const uint32_t*>(spans_);
-        uint32_t* span_sorted = static_cast<uint32_t*>(span_sorted_);
-        uint32_t w[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) w[r] = id[r] != 0xFFFFFFFFu ? spans[id[r]] : 0xFFFFFFFFu;                 // four gathers in flight
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const size_t i = base + (size_t)r * 256;
-            if (i < P) span_sorted[i] = w[r];
-            const uint2 xr = span_unpack(w[r]);
-            sum += span_tiles(xr.x, xr.y, th_shift);
-        }
-    } else {
-        const uint4* spans = static_cast<const uint4*>(spans_);
-        uint2* span_sorted = static_cast<uint2*>(span_sorted_);
-        uint4 sp[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) sp[r] = id[r] != 0xFFFFFFFFu ? spans[id[r]] : make_uint4(0u, 0u, 0u, 0u); // four gathers in flight
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const size_t i = base + (size_t)r * 256;
-            if (i < P) span_sorted[i] = make_uint2(sp[r].y, sp[r].x);
-            sum += span_tiles(sp[r].y, sp[r].x, th_shift);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-// The same block sums from spans that are ALREADY in range order (the last pass of the range sort gathered them, RadixTail).
+// Block sums of the instance counts from the spans in range order (the last pass of the range sort gathered them there, RadixTail;
+// COMPACT: 4-byte span records, lidargs_common.h span_pack).
 template <bool COMPACT>
 __global__ void __launch_bounds__(256) k_span_block_sums(const void* __restrict__ span_sorted_, int th_shift, uint32_t* __restrict__ block_sum, size_t P) {
     __shared__ uint32_t ws[4];
@@ -505,16 +465,12 @@ __global__ void __launch_bounds__(256) k_span_block_sums(const void* __restrict_
     if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 // spans in range order + exclusive block offsets in `block_off` (scan_blocks(P) words) + the instance total in *total_out
-void launch_instance_offsets(const uint32_t* ids_sorted, const void* spans, bool compact, int TH, void* span_sorted, uint32_t* block_off,
-                             uint32_t* total_out, size_t P, hipStream_t s, bool gathered) {
+void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s) {
     int sh = 0;
     while ((1 << sh) < TH) sh++;
     const size_t nb = scan_blocks(P);
-    if (gathered) {
-        if (compact) hipLaunchKernelGGL(k_span_block_sums<true>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
-        else hipLaunchKernelGGL(k_span_block_sums<false>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
-    } else if (compact) hipLaunchKernelGGL(k_gather_spans<true>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
-    else hipLaunchKernelGGL(k_gather_spans<false>, dim3((unsigned)nb), dim3(256), 0, s, ids_sorted, spans, sh, span_sorted, block_off, P);
+    if (compact) hipLaunchKernelGGL(k_span_block_sums<true>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
+    else hipLaunchKernelGGL(k_span_block_sums<false>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, block_off, nb, total_out);
 }
 

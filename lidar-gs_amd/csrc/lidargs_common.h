@@ -80,7 +80,7 @@ inline size_t scan_scratch_words(size_t n) { return scan_blocks(n) + 64; }
 // Per-Gaussian span record the instance offsets and the emit are built from.  Full form: u32x4 (rowspan = lo | hi << 16 in pixel
 // rows, xspan = x0 | x1 << 16 in 16-pixel tile columns, 0 = no instances, -, -).  COMPACT form, whenever the image has at most 256
 // tile columns and 256 pixel rows (64x2650 and 128x4096 do): ONE u32 = x0 | (nx - 1) << 8 | lo << 16 | (hi - 1) << 24, 0xFFFFFFFF =
-// no instances.  The spans are gathered at random in range order (k_gather_spans): with 16-byte records every 128-byte line of a
+// no instances.  The spans are gathered at random in range order (by the range sort's last pass): with 16-byte records every 128-byte line of a
 // 32-MB table is fetched for one record (measured 243 MB of fabric traffic for 2 M Gaussians); the 8-MB table of compact records
 // stays in the L2s / MALL.
 inline bool compact_spans(int tiles_x, int H) { return tiles_x <= 256 && H <= 256; }
@@ -307,9 +307,8 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
                             bool vals_are_positions = false,    // true: the values are 0..n-1 and val_a is never read
                             RadixTail tail = RadixTail());
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
-void launch_instance_offsets(const uint32_t* ids_sorted, const void* spans, bool compact, int TH, void* span_sorted, uint32_t* block_off,
-                             uint32_t* total_out, size_t P, hipStream_t s, bool gathered = false);   // compact: 4-byte span records (span_pack);
-                                                                            // gathered: span_sorted was filled by the range sort's last pass
+// block instance offsets + the instance total from the spans in range order (filled by the range sort's last pass); compact: span_pack
+void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s);
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu);
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr);
