@@ -754,6 +754,36 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, one process
+    per GPU, exactly as the driver's torch.distributed.run command line would, and pass rank 0's JSON line through.  Fails with
+    a plain statement when the box has fewer than N devices -- not with a launcher error."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not args.launch_check:
+        raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} HIP devices, found {have}")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))   # dmabuf IPC only on these hosts
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args):
+    """--launch-check: the rendezvous of the self-launched (or torchrun-launched) ranks without any GPU work -- gloo, one
+    all-reduce, one JSON line from rank 0.  What tests/test_bench_cli_cpu.py runs here, where there is no GPU."""
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "n_gpus": args.gpus, "sum_of_ranks_plus_1": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -764,12 +794,22 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="time the rasterizer forward alone (default for cfg2)")
     ap.add_argument("--fwd-bwd", action="store_true", help="forward + backward also for cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard", default="wedges", choices=["wedges", "shells"],
-                    help="N > 1: column wedges (every rank renders its pixel columns; image all-gather + gradient all-to-all) or range "
-                         "shells (the north star's cut by range: two-phase transmittance exchange)")
+    ap.add_argument("--shard", default="both", choices=["both", "wedges", "shells"],
+                    help="N > 1: range shells (the north star's cut by range: two-phase transmittance exchange, image all-gather, "
+                         "gradient all-to-all), column wedges (every rank renders its pixel columns; image all-gather + gradient "
+                         "all-to-all), or both timed one after the other in the same job (default): `value` is then the faster cut's, "
+                         "named in config.sharding, and `cuts` holds both")
+    ap.add_argument("--beams", default="uniform", choices=["uniform", "waymo", "neartie"],
+                    help="beam-inclination table of the synthetic scene (lidargs_scenes.beam_table): uniform = SURVEY 8d; waymo = "
+                         "non-uniform stand-in for the measured table the Waymo configs read from the dataset json")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--enqueue-only", action="store_true",
                     help="render with GaussianRasterizer.enqueue_only (lidargs_forward_enqueue: no host wait per frame); single GPU only")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if args.launch_check:
+        return launch_check(args)
 
     if args.workload == "decode":
         return bench_decode(args)
@@ -814,14 +854,52 @@ def main():
     to_torch = lambda sd, device: {k_: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k_, v in sd.items()}
     make_settings = sc.raster_settings
 
-    scene = sc.make_scene(kind, P, H, seed)
+    scene = sc.make_scene(kind, P, H, seed, beams=args.beams)
     st = to_torch(scene, dev)
     gc, gd, go = (torch.from_numpy(g).to(dev) for g in sc.upstream_grads(H, W, seed))
     settings = make_settings(st, W, H)
     leaves = {k: st[k].clone().requires_grad_(not fwd_only) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     means2D = torch.zeros((P, 4), dtype=torch.float32, device=dev, requires_grad=not fwd_only)
 
-    if world == 1 and not force_shells:
+    sharded = world > 1 or force_shells
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_region(step, rebalance=None):
+        """Clock ramp, W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over the ranks."""
+        _C.profile_enable(True)             # pre-creates the event pool (one-off cost, outside the timed region)
+        if rebalance is not None:
+            rebalance()
+            _C.profile_enable(True)
+        clock_ramp(step, fixed_steps=300 if sharded else None)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        _flush_c_stdio()                    # every rank: whatever the collectives' bring-up printed goes out now, not at exit
+        # stage events live inside the timed region, on every STAGE_EVERY-th frame: recording all twelve of them on every frame costs
+        # 55 us of device time per frame (measured: 0.94 ms with, 0.88 ms without), which would be the harness, not the path
+        _C.profile_enable(STAGE_EVERY)
+        allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        _C.profile_enable(False)
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return dict(elapsed=el, stages=_C.profile_summary(), cnt=_C.last_counters(),
+                    allocs=int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0))
+
+    cuts = {}
+    if not sharded:
         rast = GaussianRasterizer(settings)
         rast.enqueue_only = bool(args.enqueue_only)
 
@@ -837,77 +915,57 @@ def main():
                 color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
                                                 colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
                 torch.autograd.backward([color, depth, occ], [gc, gd, go])
+        res = timed_region(step)
     else:
+        import math
+        import torch.distributed as dist
         import lidargs_dist
         comm = lidargs_dist.TorchDistComm()
-        # range-shell edges are a load-balancing choice, not a result: cut once for this (static) scene and view
-        import math
+        # range-shell / wedge edges are a load-balancing choice, not a result: cut once for this (static) scene and view
         beams = st["beams"]
         tile_rad = (16 * 2 * math.pi / W, 4 * float(beams[-1] - beams[0]) / max(1, H - 1))      # 16 columns x 4 rows per tile
-        if args.shard == "shells":
-            cut = lambda shares: comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
-                                                                         tile_rad=tile_rad, shares=shares), 0)
-            rast = lidargs_dist.ShellRasterizer(settings, comm, edges=cut(None))
-        else:
-            def cut(shares):
-                e = torch.tensor(lidargs_dist.wedge_edges(st["means3D"], st["viewmatrix"], W, world, scales=st["scales"], shares=shares),
-                                 dtype=torch.int32, device=dev)
-                return [int(x) for x in comm.broadcast(e, 0).tolist()]
-            rast = lidargs_dist.WedgeRasterizer(settings, comm, edges=cut(None))
+        for shard in (("shells", "wedges") if args.shard == "both" else (args.shard,)):
+            if shard == "shells":
+                cut = lambda shares: comm.broadcast(lidargs_dist.shell_edges(st["means3D"], st["viewmatrix"], world, 0, 80, scales=st["scales"],
+                                                                             tile_rad=tile_rad, shares=shares), 0)
+                rast = lidargs_dist.ShellRasterizer(settings, comm, edges=cut(None))
+            else:
+                def cut(shares):
+                    e = torch.tensor(lidargs_dist.wedge_edges(st["means3D"], st["viewmatrix"], W, world, scales=st["scales"], shares=shares),
+                                     dtype=torch.int32, device=dev)
+                    return [int(x) for x in comm.broadcast(e, 0).tolist()]
+                rast = lidargs_dist.WedgeRasterizer(settings, comm, edges=cut(None))
 
-        def step():
-            for t in list(leaves.values()) + [means2D]:
-                t.grad = None
-            color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
-                                            colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
-            torch.autograd.backward([color, depth, occ], [gc, gd, go])
+            def step(rast=rast):
+                for t in list(leaves.values()) + [means2D]:
+                    t.grad = None
+                color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                                colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+                torch.autograd.backward([color, depth, occ], [gc, gd, go])
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    _C.profile_enable(True)             # pre-creates the event pool (one-off cost, outside the timed region)
-    if world > 1 or force_shells:
-        # Measured load balancing of the (static) cut, outside the timed region: a few frames per round, every rank's own kernel
-        # time (its HIP-event stage sums, which do not include waiting for the other ranks) -> thinner shells for the slow ranks.
-        import torch.distributed as dist
-        shares = [1.0 / world] * world
-        for _round in range(4):
-            _C.profile_enable(True)
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            mine = torch.tensor([sum(v[0] for v in _C.profile_summary().values())], dtype=torch.float64, device=dev)
-            times = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(times, mine)
-            shares = lidargs_dist.rebalance_shares(shares, [float(t) for t in times], fixed=0.25)
-            rast.edges = cut(shares)
-        _C.profile_enable(True)
-    clock_ramp(step, fixed_steps=300 if (world > 1 or force_shells) else None)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    _flush_c_stdio()                    # every rank: whatever the collectives' bring-up printed goes out now, not at exit
-    # stage events live inside the timed region, on every STAGE_EVERY-th frame: recording all twelve of them on every frame costs
-    # 55 us of device time per frame (measured: 0.94 ms with, 0.88 ms without), which would be the harness, not the path
-    _C.profile_enable(STAGE_EVERY)
-    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _C.profile_enable(False)
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    allocs1 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-    stages = _C.profile_summary()
+            def rebalance(rast=rast, cut=cut, step=step):
+                # Measured load balancing of the (static) cut, outside the timed region: a few frames per round, every rank's own
+                # kernel time (its HIP-event stage sums, which do not include waiting for the other ranks) -> thinner shells /
+                # narrower wedges for the slow ranks.
+                shares = [1.0 / world] * world
+                for _round in range(4):
+                    _C.profile_enable(True)
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize()
+                    mine = torch.tensor([sum(v[0] for v in _C.profile_summary().values())], dtype=torch.float64, device=dev)
+                    times = [torch.zeros_like(mine) for _ in range(world)]
+                    dist.all_gather(times, mine)
+                    shares = lidargs_dist.rebalance_shares(shares, [float(t) for t in times], fixed=0.25)
+                    rast.edges = cut(shares)
+            cuts[shard] = timed_region(step, rebalance)
+            cuts[shard]["edges"] = [float(e) for e in (rast.edges.tolist() if hasattr(rast.edges, "tolist") else rast.edges)]
+        best = min(cuts, key=lambda k: cuts[k]["elapsed"])
+        res = cuts[best]
+        args.shard = best
+    elapsed, stages, cnt = res["elapsed"], res["stages"], res["cnt"]
+    allocs0 = 0
+    allocs1 = res["allocs"]
     spread = None
     if world == 1 and not force_shells:
         # per-frame distribution (median and p10 / p90), after and outside the contract's timed region: one event per
@@ -920,7 +978,6 @@ def main():
         torch.cuda.synchronize()
         per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])
         spread = {"p10": float(np.percentile(per, 10)), "median": float(np.median(per)), "p90": float(np.percentile(per, 90))}
-    cnt = _C.last_counters()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         N_pix, T_ref = H * W, H * ((W + 15) // 16)
@@ -930,7 +987,7 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, {what}, "
-                                   f"lidar_far=80 lidar_near=0, bg=0",
+                                   f"lidar_far=80 lidar_near=0, bg=0" + ("" if args.beams == "uniform" else f", beam table '{args.beams}' (non-uniform)"),
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
                        "patch_instance_pairs_taken": cnt["taken_instances"], "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
                        "forward": "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)",
@@ -967,6 +1024,14 @@ def main():
                 out["roofline"]["note"] = f"rank 0 of {world}: {int(cnt['P'])} Gaussians selected, {int(cnt['instances'])} instances binned"
             except Exception as e:      # the headline number must not depend on the diagnostics
                 out["roofline"] = {"error": str(e)}
+        if sharded:
+            # every cut that was timed (same job, same ranks, one after the other); `value` above is the faster one's
+            out["cuts"] = {k: {"value": args.steps / v["elapsed"], "ms_per_step": v["elapsed"] / args.steps * 1e3, "edges": v["edges"],
+                               "stage_ms_rank0": {a: round(b[0], 4) for a, b in v["stages"].items()},
+                               "collectives": ("all_reduce(radii), all_gather(T_pass), all_gather(5 planes), all_to_all(gradient rows)" if k == "shells"
+                                               else "all_reduce_max(radii), all_gather(own columns of 4 planes), all_to_all(gradient rows, added by the owner)")}
+                           for k, v in cuts.items()}
+            out["rccl_ranks"] = world
         out.update({
             "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
             "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",

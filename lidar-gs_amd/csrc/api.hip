@@ -63,6 +63,12 @@ int forced_tile_rows() {
     }();
     return th;
 }
+// LIDARGS_NO_PRUNE=1 switches the conservative footprint pruning of the preprocess off (every tile / row of the reference rect is binned):
+// a diagnostic and a test instrument -- pruned entries are exactly those no pixel can take, so the results must not change.
+bool prune_footprints() {
+    static const bool on = [] { const char* e = getenv("LIDARGS_NO_PRUNE"); return !(e && atoi(e) != 0); }();
+    return on;
+}
 int tile_rows() { return forced_tile_rows() ? forced_tile_rows() : 4; }      // what non-adaptive callers (surfel variant) use
 
 // Tile height from the instance totals the preprocess accumulated for heights 4 / 8 / 16 / 32.  The blend costs the same for every
@@ -331,6 +337,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     pp.near_f = near_f; pp.far_f = far_f; pp.shell_lo = shell_lo; pp.shell_hi = shell_hi;
     pp.tile_x_lo = 0; pp.tile_x_hi = grid4.tiles_x;
     pp.compact = lg::compact_spans(grid4.tiles_x, height) ? 1 : 0;
+    pp.prune = prune_footprints() ? 1 : 0;
     if (col_lo >= 0) {                                                   // column wedge: whole 16-pixel tile columns
         if (col_lo % LG_TILE_W || (col_hi % LG_TILE_W && col_hi != width) || col_hi <= col_lo || col_hi > width)
             return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: a column wedge must be [multiple of 16, multiple of 16 or width)%s");
@@ -600,7 +607,7 @@ int lidargs_visible_filter(lidargs_alloc_fn geometry_alloc, void* geometry_user,
     pp.scale_modifier = scale_modifier;
     pp.near_f = (float)lidar_near; pp.far_f = (float)lidar_far;
     pp.shell_lo = -std::numeric_limits<float>::infinity(); pp.shell_hi = std::numeric_limits<float>::infinity();
-    pp.tile_x_lo = 0; pp.tile_x_hi = grid.tiles_x; pp.compact = 0;
+    pp.tile_x_lo = 0; pp.tile_x_hi = grid.tiles_x; pp.compact = 0; pp.prune = 1;
     const float pi_f = 3.14159265358979323846f;
     pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;
     pp.tan_col_step = tanf(2 * pi_f / width);

@@ -236,6 +236,8 @@ struct PreprocessParams {
     float shell_lo, shell_hi;   // extra float range shell: keep lo <= range < hi (multi-GPU); +-inf otherwise
     int tile_x_lo, tile_x_hi;   // tile-column window [lo, hi) this call bins and renders (multi-GPU column wedges); 0, tiles_x otherwise
     int compact;                // 4-byte span records (compact_spans(tiles_x, H))
+    int prune;                  // conservative footprint pruning on (default); 0 = bin the whole reference rect (LIDARGS_NO_PRUNE=1: the
+                                // results must not depend on it -- tests/test_beam_tables_gpu.py, tools/diag_prune.py)
     float col_step;             // 2*pi/W        (float, as the reference evaluates it)
     float inv_col_step;         // a bound from above on 1 / col_step (footprint pruning only)
     float tan_col_step;         // tanf(2*pi/W)  (host libm)

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         int tx0 = xmin, tx1 = xmax, ty_lo = ymin, ty_hi = ymax;
         const float op = a.opacities[idx];
         if (!(op * 255.f >= 1.f)) { tx1 = tx0; }                       // can never reach 1/255
-        else {
+        else if (pp.prune) {
             // Everything here is a bound from above, so the cheap forms are as safe as the exact ones: the hardware log (the
             // 0.02 covers its error), asin(x) <= x + 0.23 x^3 on [0, 0.7], 1 - cos(t) <= t^2 / 2, |sin(alpha)| = |dir.z|.
             const float tau2 = 2.f * (__logf(255.f * op) + 0.02f);

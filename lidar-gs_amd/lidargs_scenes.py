@@ -26,6 +26,51 @@ def beam_inclinations(H, lo_deg=-17.6, hi_deg=2.4):
     return np.deg2rad(np.linspace(lo_deg, hi_deg, H)).astype(np.float32)
 
 
+BEAM_TABLES = ("uniform", "waymo", "neartie")
+
+
+def beam_table(H, kind="uniform", lo_deg=-17.6, hi_deg=2.4):
+    """Beam-inclination tables, ascending float32 radians.
+
+    uniform  np.linspace over the FOV (also what the reference's get_beam_inclinations gives, utils/lidar_utils.py:296-299).
+    waymo    what the Waymo configs really feed the kernel: a MEASURED, non-uniform table read from the dataset json
+             (scene/dataset_readers.py:358-359).  No dataset ships, so this is a stand-in with the real table's properties: same FOV,
+             gaps shrinking smoothly from the bottom beam to the top one by 4x (the top-lidar is densest near the horizon), and a
+             deterministic +-15 % wobble of every gap on top (a measured table is not smooth).  K1 bisects the table
+             (R3/cr/auxiliary.h:41-63) and sizes the row radius from the LOCAL gap (R3/cr/forward.cu:361), so unequal gaps are the
+             input property that uniform tables never exercise.
+    neartie  the uniform table with two neighbouring beams 2e-5 rad apart (a degenerate calibration): the local gap's tangent is
+             tiny, the row radius of every Gaussian landing in that interval explodes to the whole image height.
+    """
+    if kind == "uniform" or H < 3:
+        return beam_inclinations(H, lo_deg, hi_deg)
+    if kind == "waymo":
+        w = 0.6                                                     # gap(bottom) / gap(top) = (1 + w) / (1 - w) = 4
+        t = (np.arange(H - 1, dtype=np.float64) + 0.5) / (H - 1)
+        gaps = (1.0 - w) + 2.0 * w * (1.0 - t)
+        gaps *= 1.0 + 0.15 * np.sin(12.9898 * np.arange(1, H) + 78.233 * H)      # deterministic, no RNG state involved
+        f = np.concatenate([[0.0], np.cumsum(gaps)]) / gaps.sum()
+        b = np.deg2rad(lo_deg + (hi_deg - lo_deg) * f).astype(np.float32)
+    elif kind == "neartie":
+        b = beam_inclinations(H, lo_deg, hi_deg).copy()
+        k = max(1, (2 * H) // 3)
+        b[k] = b[k - 1] + np.float32(2e-5)
+    else:
+        raise ValueError(f"unknown beam table {kind!r} (one of {BEAM_TABLES})")
+    assert np.all(np.diff(b) > 0), "beam table must be strictly ascending"
+    return b
+
+
+def _beams_arg(H, beams):
+    if beams is None:
+        return beam_inclinations(H)
+    if isinstance(beams, str):
+        return beam_table(H, beams)
+    b = np.ascontiguousarray(beams, dtype=np.float32)
+    assert b.shape == (H,)
+    return b
+
+
 def _rand_quat(rng, n):
     q = rng.normal(size=(n, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
@@ -55,10 +100,10 @@ def rigid_viewmatrix(rng=None, max_angle=0.3, max_shift=1.0):
     return V.astype(np.float32)
 
 
-def shell_scene(P, H, seed):
+def shell_scene(P, H, seed, beams=None):
     """Isotropic 'shell': r~U(5,60), azimuth U(-pi,pi), elevation inside the beam fan."""
     rng = np.random.default_rng(seed)
-    beams = beam_inclinations(H)
+    beams = _beams_arg(H, beams)
     r = rng.uniform(5.0, 60.0, P)
     az = rng.uniform(-np.pi, np.pi, P)
     el = rng.uniform(float(beams[0]), float(beams[-1]), P)
@@ -68,11 +113,11 @@ def shell_scene(P, H, seed):
     return _pack(rng, xyz, scales, rots, beams)
 
 
-def street_scene(P, H, seed):
+def street_scene(P, H, seed, beams=None):
     """Waymo-static stand-in: 70% ground z=-2 (r<75), 25% two walls y=+-12, 5% clutter;
     flat surfels (0.15,0.15,0.02)*lognormal(0.4) aligned with the surface normal."""
     rng = np.random.default_rng(seed)
-    beams = beam_inclinations(H)
+    beams = _beams_arg(H, beams)
     n_g = int(0.70 * P); n_w = int(0.25 * P); n_c = P - n_g - n_w
     # ground: uniform in area inside a 75 m disc
     rg = 75.0 * np.sqrt(rng.uniform(0.0, 1.0, n_g)); ag = rng.uniform(-np.pi, np.pi, n_g)
@@ -111,8 +156,9 @@ def _pack(rng, xyz, scales, rots, beams):
     )
 
 
-def make_scene(kind, P, H, seed, random_view=False):
-    s = shell_scene(P, H, seed) if kind == "shell" else street_scene(P, H, seed)
+def make_scene(kind, P, H, seed, random_view=False, beams=None):
+    """beams: None / "uniform" (SURVEY 8d), "waymo", "neartie" (beam_table) or an explicit ascending float32[H] table."""
+    s = shell_scene(P, H, seed, beams) if kind == "shell" else street_scene(P, H, seed, beams)
     if random_view:
         s["viewmatrix"] = rigid_viewmatrix(np.random.default_rng(seed + 7))
     return s

@@ -19,8 +19,12 @@ Functions executed (reference file:line):
 """
 import ast
 import os
+import sys
 
 import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "lidar-gs_amd"))
+import lidargs_scenes as sc  # noqa: E402  (the non-uniform beam tables of tags c / d)
 
 REF = "/root/reference/utils/lidar_utils.py"
 WANTED = ["find_closest_label", "lidar_to_pano_with_intensities", "pano_to_lidar_with_intensities",
@@ -39,12 +43,19 @@ def load_reference_functions():
 def main():
     ns = load_reference_functions()
     out = {}
-    for tag, (H, W, N, seed) in {"a": (16, 512, 3000, 11), "b": (64, 2650, 4000, 12)}.items():
+    # tags c / d (round 3): NON-UNIFORM tables -- what the Waymo configs read from the dataset json (scene/dataset_readers.py:358-359);
+    # the reference functions are executed on them exactly as on a / b, so the row rule is pinned on unequal gaps too
+    for tag, (H, W, N, seed) in {"a": (16, 512, 3000, 11), "b": (64, 2650, 4000, 12), "c": (64, 2650, 4000, 13),
+                                 "d": (16, 512, 3000, 14)}.items():
         rng = np.random.default_rng(seed)
         if tag == "a":
             beams = ns["get_beam_inclinations"](2.4, 20.0, H)                     # reference's own beam table
-        else:
+        elif tag == "b":
             beams = np.deg2rad(np.linspace(-17.6, 2.4, H)).astype(np.float32)
+        elif tag == "c":
+            beams = sc.beam_table(H, "waymo")                                     # gaps varying 4x, wobbling
+        else:
+            beams = sc.beam_table(H, "neartie")                                   # two beams 2e-5 rad apart
         beams = np.ascontiguousarray(beams)
         r = rng.uniform(3.0, 95.0, N)               # some beyond max_depth=80
         az = rng.uniform(-np.pi, np.pi, N)

@@ -1,0 +1,189 @@
+"""GPU parity on NON-UNIFORM beam tables -- the input class of BASELINE configs 2 / 3 / 5 ("Waymo seq1067").
+
+The Waymo readers take `beam_inclinations` from the dataset json (scene/dataset_readers.py:358-359): a measured table with
+unequal gaps.  K1 bisects it (R3/cr/auxiliary.h:41-63), interpolates the row inside the LOCAL gap and sizes the row radius
+from that gap's tangent (R3/cr/forward.cu:341-362); the blend takes the pixel row's elevation from it (:589).  Every other GPU
+test builds `np.linspace` tables, so the HIP side's per-gap `tan` table, its conservative row pruning (two more bisections of
+the table, csrc/preprocess.hip) and its row-span records had never seen unequal gaps before this file.
+
+Tables (lidargs_scenes.beam_table): "waymo" = same FOV, gaps shrinking 4x from the bottom beam to the top one with a +-15 %
+wobble; "neartie" = two neighbouring beams 2e-5 rad apart (the row radius of everything landing between them covers the whole
+image).  The oracle's row rule on exactly these tables is pinned to the executed reference projector by tags c / d of
+tests/golden/rangeview_golden.npz (tests/test_oracle_cpu.py).
+
+Integer outputs (radii) must agree bit for bit here: 0 mismatches asserted, not the 1e-4 * P budget of the uniform cases.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import lidargs_scenes as sc
+from util import GRAD_KEYS_SR, hip_forward_backward, oracle_forward_backward, parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(hip, ref, keys=GRAD_KEYS_SR, radii_budget=0):
+    mism = int((hip["radii"] != ref["radii"]).sum())
+    print(f"[beams] radii mismatches: {mism} of {ref['radii'].size}")
+    assert mism <= radii_budget, f"{mism} radii differ"
+    for k in ("color", "depth", "occ") + tuple(keys):
+        parity(k, hip[k], ref[k])
+
+
+CASES = [
+    # name, kind, P, H, W, seed, random_view, table
+    ("cfg1_waymo", "shell", 10_000, 16, 512, 1, False, "waymo"),
+    ("cfg1_view_waymo", "shell", 10_000, 16, 512, 1, True, "waymo"),
+    ("street64_waymo", "street", 60_000, 64, 1000, 4, True, "waymo"),        # 64 beams, long lists, early-out active
+    ("ragged_waymo", "shell", 6_000, 18, 500, 3, True, "waymo"),             # W % 16 != 0, H % 4 != 0
+    ("cfg1_neartie", "shell", 10_000, 16, 512, 1, True, "neartie"),
+    ("street64_neartie", "street", 30_000, 64, 700, 5, True, "neartie"),
+    ("h2", "shell", 3_000, 2, 300, 6, True, "waymo"),                        # H = 2: one gap, both clamp branches of the row rule
+    ("h3_neartie", "shell", 3_000, 3, 300, 7, False, "neartie"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_forward_backward_matches_oracle_on_nonuniform_tables(case, hip_lib_built):
+    name, kind, P, H, W, seed, rv, table = case
+    scene = sc.make_scene(kind, P, H, seed, random_view=rv, beams=table)
+    gaps = np.diff(scene["beams"])
+    assert H < 3 or gaps.max() / gaps.min() > 1.9                           # the table really is non-uniform
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    hip = hip_forward_backward(scene, W, H, grads)
+    assert (ref["radii"] > 0).sum() > 0.3 * P
+    _compare(hip, ref)
+
+
+def test_tall_footprints_on_a_nonuniform_table(hip_lib_built):
+    """scale_modifier 6 at 64 beams: footprints span many unequal gaps, the adaptive tile height leaves 4 rows -- the row pruning's
+    two bisections and the per-row opacity mask of the blend work across gap changes."""
+    from diff_lidargs_rasterization import _C
+    scene = sc.make_scene("street", 20000, 64, 23, random_view=True, beams="waymo")
+    grads = sc.upstream_grads(64, 600, 23)
+    ref = oracle_forward_backward(scene, 600, 64, grads, scale_modifier=6.0)
+    hip = hip_forward_backward(scene, 600, 64, grads, scale_modifier=6.0)
+    print("adaptive tile_rows =", _C.last_counters()["tile_rows"])
+    _compare(hip, ref)
+
+
+def _stress_scene(table="waymo"):
+    """Built to stress the conservative footprint pruning (csrc/preprocess.hip): high opacity (tau large), footprints elongated
+    along the beam axis and many rows tall, centres right next to beams (1-5 % of the smallest gap off: the gap -- and with it the
+    row radius -- changes across a beam; exactly ON a beam the bisect is decided by the last ulp of atan2f, which no two libms agree
+    on) or well inside a gap, short range (big angular footprints), azimuth inside a narrow wedge."""
+    H, W, P, seed = 64, 400, 12_000, 31
+    scene = sc.make_scene("shell", P, H, seed, random_view=False, beams=table)
+    rng = np.random.default_rng(seed)
+    beams = scene["beams"].astype(np.float64)
+    off = rng.uniform(0.01, 0.05, P // 2) * rng.choice([-1.0, 1.0], P // 2) * np.diff(beams).min()
+    # the other half: well inside a gap, but never at its exact middle -- there p_r = k + 0.5, the rect's row bounds round(p_r -+ ry)
+    # (R3/cr/auxiliary.h:80-92) sit exactly on a rounding boundary and the last ulp of atan2f decides the row (seen: 3 of 6000)
+    n2 = P - P // 2
+    g = rng.integers(0, H - 1, n2)
+    frac = np.where(rng.random(n2) < 0.5, rng.uniform(0.27, 0.45, n2), rng.uniform(0.55, 0.73, n2))
+    el = np.concatenate([rng.choice(beams, P // 2) + off, beams[g] + frac * (beams[g + 1] - beams[g])])
+    r = rng.uniform(4.0, 25.0, P)
+    az = rng.uniform(-0.4, 0.4, P)
+    scene["means3D"] = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1).astype(np.float32)
+    scene["scales"] = (np.array([[0.03, 0.03, 0.25]]) * np.exp(0.5 * rng.normal(size=(P, 3)))).astype(np.float32)   # tall along z
+    scene["rotations"] = np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1))
+    scene["opacities"] = rng.uniform(0.9, 1.0, (P, 1)).astype(np.float32)
+    return scene, W, H, sc.upstream_grads(H, W, seed)
+
+
+@pytest.mark.parametrize("table", ["waymo", "uniform"])
+def test_row_pruning_never_drops_a_contributing_row(table, hip_lib_built):
+    """The conservative pruning removes rows / tile columns no pixel of which can reach alpha >= 1/255.  A wrong bound would
+    silently drop contributions; the oracle has no pruning at all, so image parity on a scene built to stress it is the check."""
+    scene, W, H, grads = _stress_scene(table)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    hip = hip_forward_backward(scene, W, H, grads)
+    assert ref["fwd"].array("radii_xy").reshape(-1, 2)[:, 1].max() >= 8     # footprints many rows tall
+    _compare(hip, ref)
+
+
+def test_visible_filter_on_a_nonuniform_table(hip_lib_built):
+    """K2 (R3/cr/forward.cu:388-497) at the Waymo image size on the Waymo-like table, as prefilter_voxel calls it."""
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from oracle import lgo
+    from util import make_settings, to_torch
+    for table in ("waymo", "neartie"):
+        P, H, W, seed = 20_000, 64, 2650, 7
+        scene = sc.make_scene("street", P, H, seed, random_view=True, beams=table)
+        st = to_torch(scene)
+        rast = GaussianRasterizer(make_settings(st, W, H))
+        radii = rast.visible_filter(means3D=st["means3D"], scales=st["scales"], rotations=st["rotations"]).cpu().numpy()
+        ref = lgo.visible_filter(scene["means3D"], scene["scales"], scene["rotations"], scene["viewmatrix"], scene["beams"], W, H)
+        mism = int((radii != ref).sum())
+        print(f"[beams] visible_filter {table}: radii mismatches {mism} of {P}")
+        assert mism == 0
+
+
+@pytest.mark.parametrize("table", ["waymo", "neartie"])
+def test_surfel_variant_on_nonuniform_tables(table, hip_lib_built):
+    """cfg5's kernels take the beam table through cpmpute_pix / compute_aabb_cylinder (R2/cr/forward.cu:145-215)."""
+    from test_surfel_gpu import _check
+    from util import surfel_scene
+    s = sc.make_scene("shell", 3000, 16, 3, random_view=True, beams=table)
+    s["scales"] = np.ascontiguousarray(s["scales"][:, :2])
+    _check(s, 512, 16, 3)
+    s = sc.make_scene("street", 20_000, 64, 11, random_view=True, beams=table)
+    s["scales"] = np.ascontiguousarray(s["scales"][:, :2])
+    _check(s, 1200, 64, 11)
+
+
+@pytest.mark.parametrize("wedges", [False, True], ids=["range_shells", "column_wedges"])
+def test_sharded_paths_on_a_nonuniform_table(wedges, hip_lib_built):
+    """One range-shell case and one column-wedge case (4 virtual ranks) on the Waymo-like table."""
+    from test_dist_gpu import _assemble, _virtual_ranks
+    world, grad_sync = 4, "reduce_scatter"
+    kind, P, H, W, seed = "street", 50_000, 64, 800, 93
+    scene = sc.make_scene(kind, P, H, seed, random_view=True, beams="waymo")
+    scene["bg"] = np.array([0.2, 0.1], np.float32)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    results = _virtual_ranks(world, scene, W, H, grads, grad_sync, wedges)
+    for r in range(world):
+        assert int((results[r]["radii"] != ref["radii"]).sum()) == 0
+        for k in ("color", "depth", "occ"):
+            parity(f"{k}@r{r}", results[r][k], ref[k], verbose=(r == 0))
+    full = _assemble(results, ref, P, world, grad_sync)
+    for k in GRAD_KEYS_SR:
+        parity(k, full[k], ref[k])
+
+
+@pytest.mark.parametrize("table", ["waymo", "uniform"])
+def test_pruning_is_invisible(table, hip_lib_built):
+    """LIDARGS_NO_PRUNE=1 bins every tile / row of the reference rect (what the reference does); the default drops those no pixel
+    can take.  Same image and gradients either way (up to the summation grouping: the lists are cut into segments by length), and
+    the pruned run must bin strictly fewer instances on this scene -- i.e. the knob really switches something."""
+    import json, os, subprocess, sys, tempfile
+    code = r"""
+import sys, json, numpy as np
+sys.path[:0] = [%r, %r, %r]
+from test_beam_tables_gpu import _stress_scene
+from util import hip_forward_backward, GRAD_KEYS_SR
+from diff_lidargs_rasterization import _C
+scene, W, H, grads = _stress_scene(%r)
+hip = hip_forward_backward(scene, W, H, grads)
+np.savez(sys.argv[1], instances=_C.last_counters()["instances"], **{k: hip[k] for k in ("color", "depth", "occ", "radii") + GRAD_KEYS_SR})
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "lidar-gs_amd"), os.path.join(root, "tests"), table)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (("pruned", {}), ("unpruned", {"LIDARGS_NO_PRUNE": "1"})):
+            out = os.path.join(tmp, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[name] = dict(np.load(out))
+    a, b = res["pruned"], res["unpruned"]
+    print(f"[prune] instances binned: {int(a['instances'])} pruned, {int(b['instances'])} unpruned")
+    assert int(a["instances"]) < 0.9 * int(b["instances"])
+    assert np.array_equal(a["radii"], b["radii"])
+    for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+        parity(f"pruned vs unpruned {k}", a[k], b[k], rtol=2e-5, outlier_frac=0.0, verbose=False)

@@ -402,3 +402,40 @@ def test_wedge_with_no_gaussian_in_reach(hip_lib_built):
     full = _assemble(results, plain, P, world, grad_sync)
     for k in GRAD_KEYS_SR:
         parity(f"{k} vs plain", full[k], plain[k], verbose=False)
+
+
+# ---- bench.py's sharded legs ------------------------------------------------------------------------------------------------------
+def _bench(*args, env=None, timeout=900):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_sharded_legs_with_a_world_of_one(hip_lib_built):
+    """The code the driver's N > 1 bench runs (both cuts timed one after the other over the RCCL communicator, rebalancing rounds,
+    one JSON line carrying `cuts`, `config.sharding`, `rccl_ranks`, `roofline`) with the only world this box can form."""
+    j = _bench("--workload", "cfg2", "--fwd-bwd", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", env={"LIDARGS_BENCH_FORCE_SHELLS": "1"})
+    assert j["rccl_ranks"] == 1 and set(j["cuts"]) == {"shells", "wedges"}
+    assert j["config"]["sharding"] in ("1 range shells", "1 column wedges")
+    assert abs(j["value"] - max(c["value"] for c in j["cuts"].values())) < 1e-6 * j["value"]
+    assert j["roofline"].get("frac", 0) > 0, j["roofline"]
+    for c in j["cuts"].values():
+        assert c["ms_per_step"] > 0 and len(c["edges"]) == 2
+
+
+def test_bench_two_ranks_over_rccl(hip_lib_built):
+    """`python bench.py --gpus 2` with no launcher in front: self-launched ranks, RCCL over xGMI, both cuts.  Needs two devices."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f"RCCL with more than one rank needs two HIP devices; this box has {n} (covered by gloo world-2 on CPU and by "
+                    f"virtual ranks on one GPU)")
+    j = _bench("--gpus", "2", "--workload", "cfg2", "--fwd-bwd", "--steps", "5", "--warmup", "2")
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and set(j["cuts"]) == {"shells", "wedges"}

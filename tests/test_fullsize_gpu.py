@@ -121,14 +121,17 @@ def _wedge_subset(scene, W, radii, c0, c1):
     return (pc >= c0 - reach) & (pc <= c1 + reach)
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg3_waymo", "cfg2_neartie"])
 def test_fullsize_wedge_matches_oracle(cfg, hip_lib_built):
     """The headline frame's own code path, value by value (see the module docstring).  cfg4 (8 M Gaussians @ 128 x 4096) runs at
-    the adaptive 16- or 32-row tile height; cfg2 / cfg3 on the fine segment plan (64-entry segments, 45 slots, gated first round)."""
+    the adaptive 16- or 32-row tile height; cfg2 / cfg3 on the fine segment plan (64-entry segments, 45 slots, gated first round).
+    `cfg3_waymo` / `cfg2_neartie` (round 3): the same frames on NON-UNIFORM beam tables (lidargs_scenes.beam_table) -- what the Waymo
+    configs really read from the dataset json (scene/dataset_readers.py:358-359); radii must then agree with 0 mismatches."""
     from diff_lidargs_rasterization import _C
     from util import GRAD_KEYS_SR, hip_forward_backward, oracle_forward_backward, parity
+    cfg, _, table = cfg.partition("_")
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[cfg]
-    scene = sc.make_scene(kind, P, H, seed)
+    scene = sc.make_scene(kind, P, H, seed, beams=table or None)
     grads = sc.upstream_grads(H, W, seed)
     hip = hip_forward_backward(scene, W, H, grads)                    # the FULL frame
     cnt = _C.last_counters()
@@ -136,7 +139,7 @@ def test_fullsize_wedge_matches_oracle(cfg, hip_lib_built):
           f"visible {int((hip['radii'] > 0).sum())}")
     if cfg == "cfg4":
         assert cnt["tile_rows"] in (16, 32), cnt                      # the adaptive choice the bench line of this config runs with (32 since r02)
-    else:
+    elif not table:
         assert cnt["tile_rows"] == 4 and cnt["segments"] == 45, cnt   # the fine plan of api.hip plan_segments
     half = 96 if cfg != "cfg4" else 64
     # two wedges: looking down the street (long lists, early saturation) and at a wall / across the shell
@@ -151,7 +154,7 @@ def test_fullsize_wedge_matches_oracle(cfg, hip_lib_built):
         rows = np.nonzero(keep)[0]
         mism = int((hip["radii"][rows] != ref["radii"]).sum())
         print(f"[wedge] {cfg} columns [{c0},{c1}): {keep.sum()} Gaussians in reach, radii mismatches {mism}")
-        assert mism <= max(1, int(1e-4 * keep.sum()))
+        assert mism <= (0 if table else max(1, int(1e-4 * keep.sum())))
         for k in ("color", "depth", "occ"):
             parity(f"{cfg}.{k}[{c0}:{c1}]", hip[k][..., c0:c1], ref[k][..., c0:c1])
         # Gaussians whose whole reference rect (R3/cr/auxiliary.h:80-92, 16-pixel tile columns) lies inside the wedge: every pixel

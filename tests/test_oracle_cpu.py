@@ -14,7 +14,8 @@ GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"
 
 
 # ---- golden vectors produced by the reference's numpy projector -------------------------------------------------
-@pytest.mark.parametrize("tag", ["a", "b"])
+# tags a / b: uniform beam tables; c: Waymo-like non-uniform table (gaps 4x apart, wobbling); d: two beams 2e-5 rad apart
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_rangeview_restatement_matches_reference_fixture(tag):
     H, W = int(GOLD[f"{tag}_H"]), int(GOLD[f"{tag}_W"])
     beams, pts = GOLD[f"{tag}_beams"], GOLD[f"{tag}_points"]
@@ -35,24 +36,26 @@ def test_beam_table_restatement():
     assert np.all(np.diff(GOLD["a_beams"]) > 0)          # ascending, as R3/cr/forward.cu:337 needs
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_oracle_pixel_rays_match_reference_rays(tag):
     """The blend kernels' pixel->ray rule (R3/cr/forward.cu:589-591) == the reference's pano_to_lidar rays."""
     H, W = int(GOLD[f"{tag}_H"]), int(GOLD[f"{tag}_W"])
-    if tag == "b":
-        pytest.skip("covered by tag a; 64x2650 per-pixel ctypes loop is slow")
+    if tag in ("b", "c"):
+        pytest.skip("covered by tags a / d; 64x2650 per-pixel ctypes loop is slow")
     q = lgo.pixel_dirs(W, H, GOLD[f"{tag}_beams"]).reshape(-1, 3).astype(np.float64)
     ref = GOLD[f"{tag}_rays"] / 10.0
     np.testing.assert_allclose(q, ref, atol=3e-7)
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_oracle_projection_inverts_reference_rays(tag):
-    """K1's (column,row) of a point on the reference ray of pixel (x,y) is (x,y) (R3/cr/forward.cu:333-359)."""
+    """K1's (column,row) of a point on the reference ray of pixel (x,y) is (x,y) (R3/cr/forward.cu:333-359) -- on the non-uniform
+    tables (c, d) this pins the bisect + local-gap interpolation of R3/cr/auxiliary.h:41-63 / forward.cu:341-359 to the rows the
+    reference's own pano_to_lidar assigns."""
     H, W = int(GOLD[f"{tag}_H"]), int(GOLD[f"{tag}_W"])
     beams = GOLD[f"{tag}_beams"]
     pts = GOLD[f"{tag}_rays"].astype(np.float32)            # one point per pixel, row-major, range 10 m
-    step = 1 if tag == "a" else 13
+    step = 1 if tag in ("a", "d") else 13
     idx = np.arange(0, pts.shape[0], step)
     P = idx.size
     f = lgo.forward(pts[idx], np.ones((P, 2), np.float32), np.full((P, 1), 0.5, np.float32),
