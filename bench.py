@@ -36,9 +36,73 @@ import torch
 
 STAGE_EVERY = 8           # frames between two frames whose stages are bracketed by HIP events
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU issue roof: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32
-# vector = 64 flop/clk/SIMD = one PACKED fp32 fma wave-instruction per 4 clocks) -> 614.4 G wave-instructions/s
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+# VALU issue roofs, MEASURED on the MI355X (tools/micro/valu_rate2.hip -> profiles/r03_valu_rate2.json, wall clock, DVFS included, >= 4
+# waves per SIMD): a wave64 instruction issues at one of three rates by opcode class --
+#   full     v_add/sub/mul/fma/fmac_f32, v_mov, v_and/or/xor, v_lshrrev, v_add/sub_u32, v_bitop3 with VGPR / constant operands
+#   half     the same with an SGPR source, v_max/min/med3, conversions, compares, v_cndmask, DPP forms, v_pk_*_f32, f64, integer multiplies
+#   quarter  v_exp/log/rcp/rsq/sqrt/sin/cos_f32, v_permlane32_swap
+# (round 2 priced everything at 256 CU x 4 SIMD x 2.4 GHz / 4 clocks = 614 G/s; the guide's "2 clocks per wave64 v_fma_f32" is the
+# `full` class only, and a lone wave per SIMD issues one instruction of ANY class per 4-5 clocks).  A launch is priced with the class
+# shares of its hot loop (tools/isa_mix.py -> profiles/r03_isa_mix.json): time at the roof = insts x sum_c share_c / rate_c.
+VALU_CLASS_RATES = {"full": 1100.0, "half": 580.0, "quarter": 300.0}      # G wave-instructions/s; overwritten from the committed profile below
+
+
+def _load_valu_rates():
+    """Class rates from profiles/r03_valu_rate2.json (median of the class's representative opcodes at 4 waves per SIMD)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*valu_rate2*.json")))
+    if not files:
+        return None
+    try:
+        j = json.load(open(files[-1]))
+        by = {r["op"]: r["w4"]["ginst_per_s"] for r in j["results"]}
+        med = lambda names: float(np.median([by[n] for n in names if n in by]))
+        VALU_CLASS_RATES.update(full=med(["v_add_f32", "v_sub_f32", "v_mul_f32", "v_fmac_f32", "v_fma_f32", "v_mov_b32", "v_and_b32", "v_add_u32"]),
+                                half=med(["v_max_f32", "v_cndmask_sgpr_mask", "v_cmp_gt_f32_vcc", "v_pk_fma_f32", "v_mov_dpp_row_ror", "v_cvt_f32_u32", "v_fma_f32_sgpr"]),
+                                quarter=med(["v_exp_f32", "v_rsq_f32", "v_sin_f32"]))
+        return os.path.basename(files[-1])
+    except Exception:
+        return None
+
+
+VALU_RATES_FROM = _load_valu_rates()
+
+
+def valu_class_shares(kernel):
+    """(shares {full, half, quarter}, where from) of a kernel's VALU instructions: its hot loop's mix from the committed
+    profiles/*isa_mix*.json (`whole` = the whole kernel, for the one-thread-per-Gaussian streams that have no hot loop)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*isa_mix*.json")))
+    if not files:
+        return None, None
+    try:
+        j = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    for k, v in j["kernels"].items():
+        if k == kernel or k.startswith(kernel + "<") or kernel.startswith(k):
+            m = v.get("whole") if v.get("use") == "whole" else v.get("hot")
+            if not m:
+                continue
+            tot = float(m["full"] + m["half"] + m["quarter"]) or 1.0
+            return {c: m[c] / tot for c in ("full", "half", "quarter")}, os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
+
+
+def valu_roof(kernel_names, insts, ms):
+    """Class-weighted VALU-issue roofline of a launch (group): {achieved G/s, peak = the mix's mean rate, frac}."""
+    shares, src = None, None
+    for k in kernel_names:
+        shares, src = valu_class_shares(k.replace("lg::", "lg::") if k.startswith("lg::") else "lg::" + k)
+        if shares:
+            break
+    if not shares:
+        shares, src = {"full": 0.4, "half": 0.55, "quarter": 0.05}, "no ISA profile: a typical blend mix assumed"
+    mean_rate = 1.0 / sum(shares[c] / VALU_CLASS_RATES[c] for c in shares)
+    g = insts / (ms * 1e-3) / 1e9
+    return {"bound": "valu-issue (class-weighted)", "achieved": g, "peak": mean_rate, "unit": "G wave-instructions/s", "frac": g / mean_rate,
+            "valu_insts_per_launch": insts, "class_shares": {c: round(v, 3) for c, v in shares.items()},
+            "class_rates": dict(VALU_CLASS_RATES), "rates_from": VALU_RATES_FROM, "shares_from": src}
 
 
 def reference_dataflow_bytes(P, V, R_ref, N, T):
@@ -66,8 +130,17 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
         dict(kernel="k_sf_preprocess" if surfel else "k_preprocess", stage="preprocess", launches=1, bound="hbm",
              bytes=(pin + 36 + (128 if surfel else 64)) * P + (88 if surfel else 76) * V,
              units=f"{pin} B in + 36 B (radii, radii_xy, key, id, spans) out + the {128 if surfel else 64}-B gradient line it zeroes per Gaussian, + record / row span / colours per visible one"),
-        dict(kernel="radix sort of the range keys (hist + prefix + scatter) x4", stage="range_sort", launches=12, bound="hbm",
-             bytes=4 * 20 * P, units="4 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per Gaussian"),
+        dict(kernel="range sort of the Gaussians (hist + prefix + scatter per pass; the last pass gathers the span records)", stage="range_sort",
+             launches="3 per pass", bound="hbm", bytes=4 * 20 * P + 8 * P,
+             units="per pass 4 B key read by the histogram + 8 B pair read + 8 B pair written per Gaussian (priced at 4 passes), + the span gather of the last one"),
+        dict(kernel="span block sums + scan of the block sums (+ the 2-KB totals read-back)", stage="scan+readback", launches=2, bound="hbm", bytes=4 * P,
+             units="4 B span record per Gaussian read in range order"),
+        dict(kernel="k_emit_instances", stage="emit", launches=1, bound="hbm", bytes=8 * P + 8 * R,
+             units="4 B span + 4 B id per Gaussian in, 4 B tile key + 4 B id per instance out"),
+        dict(kernel="tile sort of the instances (hist + prefix + scatter per pass)", stage="tile_bin", launches="3 per pass", bound="hbm", bytes=2 * 20 * R,
+             units="2 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per instance"),
+        dict(kernel="k_tile_ranges", stage="ranges", launches=1, bound="hbm", bytes=4 * R + 8 * max(1, N // 64),
+             units="4 B tile key per instance in, 8 B range per tile out"),
         dict(kernel="forward blend group (reference K7): T-only walks + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
              launches="4-7 by plan", bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
@@ -138,7 +211,12 @@ def pmc_lookup(kind, workload, kernel_names, field):
         for k, v in j["kernels"].items():
             base = k[5:] if k.startswith("void ") else k
             if any(base.startswith(pre) for pre in kernel_names["any_of"]) and field in v:
-                tot += v[field] * v.get("launches_sampled", frames) / frames
+                # `weight(name)`: the share of this kernel's launches that belong to the group (kernels two groups share, e.g. the
+                # radix sort's digit prefix, used by the range sort and the tile sort alike)
+                wgt = kernel_names["weight"](base) if "weight" in kernel_names else 1.0
+                if wgt <= 0:
+                    continue
+                tot += wgt * v[field] * v.get("launches_sampled", frames) / frames
                 found = True
         return (tot if found else None), os.path.basename(f)
     for name in kernel_names:
@@ -148,6 +226,36 @@ def pmc_lookup(kind, workload, kernel_names, field):
             return None, os.path.basename(f)
         tot += times * hit[0][field]
     return tot, os.path.basename(f)
+
+
+def sort_pmc_groups(tiles):
+    """PMC lookup groups of the two radix sorts of a frame.  Their kernels share names: hist / scatter launches are told apart by
+    their digit width (the range sort's passes are >= 7 bits wide, the tile sort's ceil(log2 tiles) bits split evenly are narrower on
+    every BASELINE image size), the digit-prefix launches (no width in the name) are shared out by pass count."""
+    import math
+    import re
+    tb = max(1, math.ceil(math.log2(max(2, tiles))))
+    t_passes = (tb + 7) // 8
+    t_bits = (tb + t_passes - 1) // t_passes
+    r_passes = 4
+    sort_kernels = ["lg::k_radix_hist<", "lg::k_radix_scatter<", "lg::k_radix_digit_prefix<", "lg::k_radix_chunk_prefix"]
+
+    def weight(for_tile_sort):
+        def w(name):
+            m = re.search(r"k_radix_(?:hist|scatter)<(\d+),", name)
+            if m is None:                                  # digit / chunk prefix: shared by pass count
+                return (t_passes if for_tile_sort else r_passes) / float(t_passes + r_passes)
+            narrow = int(m.group(1)) <= t_bits and t_bits < 7
+            if t_bits >= 7:
+                return 0.5                                 # widths overlap: cannot be told apart by name
+            return 1.0 if narrow == for_tile_sort else 0.0
+        return w
+    return {"range sort of the Gaussians (hist + prefix + scatter per pass; the last pass gathers the span records)":
+                {"any_of": sort_kernels, "per_frame": "k_preprocess", "weight": weight(False)},
+            "tile sort of the instances (hist + prefix + scatter per pass)":
+                {"any_of": sort_kernels, "per_frame": "k_preprocess", "weight": weight(True)},
+            "span block sums + scan of the block sums (+ the 2-KB totals read-back)":
+                {"any_of": ["lg::k_span_block_sums", "lg::k_scan_partials"], "per_frame": "k_preprocess"}}
 
 
 def host_cores():
@@ -289,23 +397,25 @@ def roofline_object(table, workload, blend_kernels_pmc, ref_flow=None):
             roof["traffic_GBs"] = tr / (dom["ms"] * 1e-3) / 1e9
         insts, src2 = pmc_lookup("sq", workload, names, "SQ_INSTS_VALU")
         if insts:
-            g = insts / (dom["ms"] * 1e-3) / 1e9
-            roof["compute"] = {"bound": "valu-issue", "achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                               "frac": g / VALU_PEAK_GINST, "valu_insts_per_launch": insts, "profile": src2,
-                               "note": "SQ_INSTS_VALU of the committed profile / this run's launch time; peak = 256 CU x 4 SIMD x 2.4 GHz / 4 "
-                                       "clocks per wave64 instruction.  The nearer roof of the two is the one to read."}
-            if roof["compute"]["frac"] > roof["frac"]:
-                roof["nearer_roof"] = "valu-issue"
-            else:
-                roof["nearer_roof"] = "hbm"
-    # the VALU-issue fraction of every launch (group) the committed SQ profile of this workload covers
+            roof["compute"] = valu_roof(names if isinstance(names, list) else names["any_of"], insts, dom["ms"])
+            roof["compute"]["profile"] = src2
+            roof["compute"]["note"] = ("SQ_INSTS_VALU of the committed profile / this run's launch time against the launch's class-weighted issue "
+                                       "roof (measured class rates x the hot loop's class shares).  The nearer roof of the two is the one to read.")
+            roof["nearer_roof"] = "valu-issue" if roof["compute"]["frac"] > roof["frac"] else "hbm"
+    # every launch (group) the committed profiles of this workload cover: PMC traffic and the class-weighted VALU-issue fraction
     for k in table:
         names = blend_kernels_pmc.get(k["kernel"])
         if names:
+            tr, _src = pmc_lookup("traffic", workload, names, "hbm_bytes_per_launch_corrected")
+            if tr:
+                k["traffic"] = tr
+                k["traffic_over_algorithmic"] = tr / k["bytes"]
             insts, _src = pmc_lookup("sq", workload, names, "SQ_INSTS_VALU")
             if insts:
+                vr = valu_roof(names if isinstance(names, list) else names["any_of"], insts, k["ms"])
                 k["valu_insts"] = insts
-                k["valu_issue_frac"] = insts / (k["ms"] * 1e-3) / 1e9 / VALU_PEAK_GINST
+                k["valu_issue_frac"] = vr["frac"]
+                k["valu_issue_peak"] = vr["peak"]
     roof["kernels"] = [{k2: (round(v, 5) if isinstance(v, float) else v) for k2, v in k.items()} for k in table]
     if ref_flow is not None:
         roof["vs_reference_dataflow"] = ref_flow
@@ -1005,10 +1115,12 @@ def main():
                         "note": "SURVEY 8d formula on R_ref (16x1 instances the reference would bin) / our frame time: above the 8000 GB/s "
                                 "peak means the frame is faster than that data flow could be at HBM speed; NOT a roofline fraction"}
             pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
-                         "k_gaussian_backward": ["lg::k_gaussian_backward"],
+                         "k_gaussian_backward": ["lg::k_gaussian_backward"], "k_emit_instances": ["lg::k_emit_instances<true>"],
+                         "k_tile_ranges": ["lg::k_tile_ranges"],
                          "forward blend group (reference K7): T-only walks + alive + full walk + combine":
-                             {"any_of": ["lg::k_render_forward<", "lg::k_render_pass2_grouped", "lg::k_render_alive", "lg::k_render_combine"],
-                              "per_frame": "k_render_combine"}}
+                             {"any_of": ["lg::k_render_forward<", "lg::k_render_pass2_grouped", "lg::k_render_alive", "lg::k_render_combine", "lg::k_render_fused"],
+                              "per_frame": "k_preprocess"}}
+            pmc_names.update(sort_pmc_groups(int(cnt["tiles"]) if "tiles" in cnt else T_ref // max(1, int(cnt["tile_rows"]))))
             out["roofline"] = roofline_object(table, args.workload, pmc_names, ref_flow)
             # the frame as a whole against the HBM roof, from the same per-launch units (+ what the table leaves out is small)
             own = sum(k["bytes"] for k in table)

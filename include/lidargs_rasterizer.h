@@ -428,7 +428,8 @@ const char* lidargs_profile_stage_name(int stage);            /* NULL past the l
  * (at most 256 calls are kept; lidargs_profile_enable(1) pre-creates the events and resets.) */
 int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* count_out, int max_stages);
 
-/* Counters of the last forward on this thread: [0]=P, [1]=visible Gaussians V,
+/* Counters of the last forward ON THE CALLING THREAD (thread-local diagnostics: a call from another thread -- autograd's
+ * backward thread, a monitoring thread -- sees that thread's own last forward, or zeros): [0]=P, [1]=visible Gaussians V,
  * [2]=instances binned by this library (num_rendered), [3]=R_ref = sum of the reference's
  * 16x1 tiles_touched (what SURVEY.md 8d's byte formula is written in), [4]=tile rows TH,
  * [5]=number of tiles, [6]=instances that at least one pixel of their patch took in pass 1 (-1 if the

@@ -158,6 +158,15 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
     // 0.09 ms, 0.5 M are even; heads of 1 or 2 segments there lose 0.03-0.04 ms to the extra launches (r02 measurements).
     p.head = (fine || surfel) ? 0 : 1;
     { static const int env_head = [] { const char* e = getenv("LIDARGS_HEAD"); return e ? atoi(e) : -1; }(); if (env_head >= 0 && !surfel) p.head = env_head ? 1 : 0; }
+    // Small frames (<= 1 M instances: per-rank sub-frames of a sharded scene, small scenes) run the fine plan's forward blend as ONE
+    // launch, a workgroup of 8 waves per patch walking the list in rounds of 8 segments (render.hip k_render_fused): the records are
+    // gathered once instead of 2-3 times, there are no workgroups that only read a range and retire, and five launches become one.
+    // Measured (r03): 0.17 M instances 0.095 -> 0.057 ms, 0.7 M 0.137 -> 0.114 ms; at 1.3 M (0.165 -> 0.196 ms) and 5.7 M
+    // (0.195 -> 0.252 ms) the few long unsaturated lists, walked round after round by one workgroup, are a tail the multi-launch
+    // form does not have.  The two forms produce bit-identical images.  LIDARGS_FUSED = 0 / 1 forces one of them.
+    { static const int env_fused = [] { const char* e = getenv("LIDARGS_FUSED"); return e ? atoi(e) : -1; }();
+      p.fused = (fine && !surfel && R <= (size_t)1000000) ? 1 : 0;
+      if (env_fused >= 0 && !surfel) p.fused = env_fused ? 1 : 0; }
     if (env_len) p.seg_len = env_len;
     if (env_max) p.max_segments = env_max;
     if (env_nrounds >= 0) { p.n_rounds = env_nrounds; for (int k = 0; k < env_nrounds; k++) p.rounds[k] = env_rounds[k]; }
@@ -393,11 +402,14 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         LG_STAGE_CHECK("instance scan");
     } else {
         TH = fixed_tile_rows;
-        R = (size_t)instance_capacity;                                     // the capacity stands in for the count everywhere on the host
+        // the capacity, rounded up to the multiple of 4 `num_rendered` can carry, stands in for the count everywhere on the host: the
+        // emit's cap, k_finish_totals' cap, the tile sort, the tile ranges and the buffer carving all see this ONE number (round 2
+        // sorted and ranged only the unrounded capacity: need in (capacity, rounded] dropped instances with no overflow flag)
+        R = ((size_t)instance_capacity + 3) & ~(size_t)3;
         lg::launch_instance_offsets(geom.span_sorted, pp.compact != 0, TH, geom.block_off, geom.totals, (size_t)P, stream);
         LG_STAGE_CHECK("instance scan");
         lg::launch_finish_totals(geom.totals, reinterpret_cast<const unsigned long long*>(geom.totals + LG_TOTALS_SLOT_WORD),
-                                 (uint32_t)(((size_t)instance_capacity + 3) & ~(size_t)3), status_dev, stream);
+                                 (uint32_t)R, status_dev, stream);
         if (status_host) LG_HIP(hipMemcpyAsync(status_host, status_dev, LG_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
     lg::TileGrid grid = lg::make_grid(width, height, TH);
@@ -446,6 +458,13 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.transmittance_only = transmittance_pass;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
     int head = 0;                                                      // segments at the head of every list that round 1 walked completely
+    const bool fused = plan.fused && !transmittance_pass && !T_in && !T_out;   // the plain frame (a range shell's two phases keep the launches)
+    if (fused) {
+        ra.flags = bin.flags; ra.alive = bin.alive;
+        lg::launch_render_fused(ra, stream);
+        LG_STAGE_CHECK("render fused");
+        g_prof.mark("render_fused", stream);
+    } else {
     if (ra.run_pass1) {
         run_pass1_rounds(ra, plan, bin.alive, stream, transmittance_pass ? nullptr : &head);
         LG_STAGE_CHECK("render pass 1");
@@ -460,6 +479,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render combine");
     g_prof.mark("render_combine", stream);
+    }
 
     g_counters[0] = P; g_counters[1] = -1; g_counters[2] = (long long)R; g_counters[3] = -1; g_counters[4] = TH;
     g_counters[5] = grid.num_tiles();
@@ -510,8 +530,9 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
     rb.seg = bin.seg; rb.S = S; rb.seg_len = plan.seg_len;
-    rb.alive = pass1_gated(plan, S) ? bin.alive : nullptr;
-    rb.flags = (S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = Rp;
+    const bool fused = plan.fused && !shell_mode;                      // as the forward decided (forward_impl): flags and limits always exist
+    rb.alive = (fused || pass1_gated(plan, S)) ? bin.alive : nullptr;
+    rb.flags = (fused || S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = Rp;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
     lg::launch_render_backward(rb, stream);
@@ -653,6 +674,9 @@ int lidargs_forward_wedge(lidargs_alloc_fn geometry_alloc, void* geometry_user, 
                           const float* beam_inclinations, int lidar_far, int lidar_near, int col_lo, int col_hi, float* out_color,
                           float* out_depth, float* out_occ, int* radii, int* radii_xy, int debug, void* stream) {
     if (col_lo < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_wedge: col_lo < 0%s");
+    // lidargs_wedge_select_count bounds a Gaussian's reach from its scales and rotation; a precomputed covariance has no such bound
+    // there, and a wedge rendered from an under-selected set would silently miss its boundary Gaussians
+    if (cov3D_precomp) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_wedge: cov3D_precomp is not supported on the column-wedge path (give scales + rotations)%s");
     const float inf = std::numeric_limits<float>::infinity();
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
                         height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
@@ -667,6 +691,7 @@ int lidargs_backward_wedge(int P, int R, const float* background, int width, int
                            float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot, int debug,
                            void* stream) {
     if (col_lo < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward_wedge: col_lo < 0%s");
+    if (cov3D_precomp) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "backward_wedge: cov3D_precomp is not supported on the column-wedge path (give scales + rotations)%s");
     return backward_impl(P, R, background, width, height, means3D, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                          beam_inclinations, radii, geom_buffer, binning_buffer, image_buffer, nullptr, nullptr, 0, dL_dpix, dL_dout_depth,
                          dL_dout_occ, dL_dmean2D, nullptr, dL_dopacity, dL_dcolor, nullptr, dL_dmean3D, nullptr, nullptr, nullptr, dL_dcov3D,

@@ -250,7 +250,8 @@ int api_check_launch(hipStream_t s, int debug, const char* what);
 int api_tile_rows();
 int api_ceil_log2(uint32_t n);
 int api_range_sort_bits();
-struct SegPlan { int seg_len, max_segments, n_rounds, rounds[8]; int head; };   // api.hip plan_segments (head: walk round 1 completely)
+struct SegPlan { int seg_len, max_segments, n_rounds, rounds[8]; int head; int fused; };   // api.hip plan_segments (head: walk round 1
+                                                                                          // completely; fused: one workgroup per patch does it all)
 SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel);
 // Device -> host read of `n` (<= 1024) words with `zero_bytes` at `zero` cleared BEHIND the copy on the same stream: the host waits
 // for the copy only.  Returns a hipError_t.
@@ -369,6 +370,7 @@ void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s);
 void launch_render_head(const RenderFwdArgs& a, int head, hipStream_t s);   // the first `head` segments of every list, walked once     // full walk from the true T_in
 void launch_render_alive(const RenderFwdArgs& a, hipStream_t s);     // which patches are still unsaturated behind the front segments
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s);   // fold the segments into the image planes
+void launch_render_fused(const RenderFwdArgs& a, hipStream_t s);     // all of the above for a patch in one workgroup (64-entry plan)
 
 struct RenderBwdArgs {
     TileGrid grid;

@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // (float)sqrt((double)L) is the correctly rounded fp32 square root of the float L (53 >= 2 * 24 + 2 bits: rounding twice is
         // harmless for sqrt), i.e. sqrtf(L); below the floor it is the constant (float)sqrt(1e-9)
         const float lmax = fmaxf(lambda1, lambda2);
-        const float my_radius = ((double)lmax <= 1e-9) ? (float)3.1622776601683795e-05 : sqrtf(lmax);
+        // (a NaN lmax -- degenerate scales / rotations -- takes the floor like fmax(1e-9, NaN) does in the reference: the test is written
+        //  so that the comparison is false for NaN on the sqrt side)
+        const float my_radius = !((double)lmax > 1e-9) ? (float)3.1622776601683795e-05 : sqrtf(lmax);
 
         const float pi_f = 3.14159265358979323846f;
         const float p_c = (pi_f - atan2f(p.y, p.x)) / pp.col_step;  // :333-334

@@ -111,9 +111,11 @@ struct WalkState {
 // register moves per entry, and plain loads get folded into the top of the next iteration, where every entry waits out the LDS
 // latency.  Only what the pass uses is read (the T-only walk needs neither depth nor colours, nobody the record's opacity): a register
 // that is loaded but never used gets reused as a temporary, and the walk would wait for the load to land first.
+// `stop` is the transmittance below which a hit ends the walk (R3/cr/forward.cu:608-613): 1e-4 for a walk that carries the true T;
+// the fused kernel's T-only walks, which start every segment from 1, pass 1e-4 / (T at the round's start) per lane.
 template <bool T_ONLY, bool TRACK = T_ONLY>
 __device__ __forceinline__ void walk_flagged(unsigned long long todo, const float4* s_rec, const float* oprow, const v2f qxy, const float qz,
-                                             const uint32_t chunk_base, WalkState& w) {
+                                             const uint32_t chunk_base, WalkState& w, const float stop = 0.0001f) {
     struct Rec { float4 r0, r1, r2, r3; float op; };
     auto read = [&](int jj) {
         Rec r;
@@ -144,7 +146,7 @@ __device__ __forceinline__ void walk_flagged(unsigned long long todo, const floa
         const float alpha = fminf(0.99f, r.op * __expf(pw));
         const bool hit = alpha >= 1.0f / 255.0f;
         const float test_T = w.T * (1.f - alpha);
-        const bool trip = hit && (test_T < 0.0001f);
+        const bool trip = hit && (test_T < stop);
         if (T_ONLY) {
             // only the hand-over value is kept: T takes the tripping value too, and the lane is done from there on
             w.T = hit ? test_T : w.T;
@@ -377,6 +379,172 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole forward blend of a patch in ONE workgroup of NW waves (the 64 x 2650 frames' plan: 64-entry segments).
+//
+// The multi-launch form above -- T-only walks of the first segments, k_render_alive, T-only walks of the rest, pass 2, combine --
+// gathers every walked record two or three times (measured: 420 MB of fabric traffic for 84 MB of needed records), launches S
+// workgroups per patch of which most retire at once, and can only notice that a patch has saturated at a launch boundary.  Here the
+// patch's segments are walked in ROUNDS of NW consecutive segments, one per wave:
+//   1. wave w walks segment k = r NW + w transmittance-only from T = 1 (the product is what the segments behind it need) and records
+//      the contribution flags; its stop test is against 1e-4 / carry, carry = the true transmittance at the round's start -- the
+//      true T of any later point is <= carry x (local product), so a lane is done here no later than in the serial walk;
+//   2. the waves exchange their products through LDS: T_in(k) = carry x prod_{v < w} Tpass(r NW + v), multiplied in list order, i.e.
+//      the very sequence of products plane_product() forms in the multi-launch form -- the images of the two forms are bit-identical;
+//   3. wave w walks the FLAGGED entries of its segment again from T_in(k) with the reference's stop rule, accumulating colour and
+//      range; a 64-entry segment is still parked in the wave's LDS slot from step 1 (no second gather), longer ones are re-gathered
+//      chunk by chunk (they were fetched microseconds ago);
+//   4. every wave folds the round's NW partial results in list order (the combine's logic), the carry advances, and the patch
+//      leaves as soon as every pixel has stopped -- at most one round behind the point where the serial walk ends.
+// The per-segment planes, the flags and the patch's limit are written exactly as the backward expects them (k_render_backward).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a) {
+    __shared__ float4 s_rec_all[NW][4 * LG_CHUNK];
+    __shared__ float4 s_oprow_all[NW][LG_CHUNK];
+    __shared__ float s_x[NW][6][64];                                   // per wave: Tpass | C0, C1, D, T_end, T_break of its segment
+    __shared__ unsigned long long s_took[NW][8];                       // contribution masks of the chunks of the wave's segment (<= 8 kept)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4* s_rec = s_rec_all[w];
+    float4* s_oprow = s_oprow_all[w];
+    const int S = a.S;
+    const int wpt = a.grid.waves_per_tile;
+    const int patch = a.grid.global_patch(blockIdx.x);
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
+    const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;
+    const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
+    const v2f qxy = v2f{px.q.x, px.q.y};
+    const size_t pstride = LG_SEG_PLANES * 64;
+    float* pbase = a.seg + (size_t)patch * S * pstride;
+    uint8_t* flp = a.flags + (size_t)sub * a.R;
+
+    float carry = (a.T_in && px.inside) ? a.T_in[px.pix] : 1.0f;       // true transmittance in front of the current round
+    // what the combine folds, kept by every wave (identical values): running sums, T after the last blended entry, hand-over value
+    float C0 = 0.f, C1 = 0.f, D = 0.f, T_final = carry, T_hand = carry;
+    bool stopped = !px.inside;
+    int walked = 0;                                                    // segments whose planes are written
+
+    for (int k0 = 0; k0 < St; k0 += NW) {                              // (an empty list has one empty segment: its planes are written too)
+        const int k = k0 + w;
+        const bool mine = k < St;
+        uint2 sr = make_uint2(0u, 0u);
+        uint32_t n = 0, nchunks = 0;
+        if (mine) { sr = segment_range(tr, St, k); n = sr.y - sr.x; nchunks = (n + LG_CHUNK - 1) / LG_CHUNK; }
+        // ---- 1. transmittance-only walk from 1, flags -------------------------------------------------------------------------
+        float Tp = 1.0f;
+        if (mine) {
+            // (a hair low: a smaller threshold only walks further, never stops a lane the serial walk would still blend)
+            const float stop = carry > 0.0001f ? (0.0001f / carry) * 0.999f : 2.0f;   // carry already below: every hit ends the walk
+            WalkState ws{1.0f, 1.0f, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || carry < 0.0001f, 0ull};
+            uint32_t c_done = 0;
+            if (__ballot(!ws.done) != 0ull && n > 0) {
+                bool have;
+                auto fetch = [&](uint32_t kk, bool& hv) {
+                    const uint32_t g = kk < n ? a.point_list[sr.x + kk] : 0u;
+                    hv = kk < n;
+                    return gather_record(a.rec, a.rowspan, g, hv);
+                };
+                Staged st = fetch((uint32_t)lane, have);
+                for (uint32_t c = 0; c < nchunks; c++) {
+                    __builtin_amdgcn_wave_barrier();
+                    park_record(s_rec, lane, st);
+                    s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
+                    const unsigned long long todo = __ballot(have);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (c + 1 < nchunks) st = fetch((c + 1) * LG_CHUNK + lane, have);
+                    if (__ballot(!ws.done) == 0ull) break;
+                    ws.took = 0ull;
+                    if (todo) walk_flagged<true>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, ws, stop);
+                    const uint32_t kk = c * LG_CHUNK + lane;
+                    if (kk < n) flp[sr.x + kk] = (uint8_t)((ws.took >> lane) & 1ull);
+                    if (lane == 0 && c < 8) s_took[w][c] = ws.took;
+                    c_done = c + 1;
+                }
+            }
+            for (uint32_t c = c_done; c < nchunks; c++) {              // entries the walk never reached: nobody can take them
+                const uint32_t kk = c * LG_CHUNK + lane;
+                if (kk < n) flp[sr.x + kk] = 0;
+                if (lane == 0 && c < 8) s_took[w][c] = 0ull;
+            }
+            Tp = ws.T;
+        }
+        s_x[w][0][lane] = Tp;
+        __syncthreads();
+        // ---- 2. the transmittance this wave's segment starts from ---------------------------------------------------------------
+        float T = carry;
+        for (int v = 0; v < w; v++) T *= s_x[v][0][lane];
+        // ---- 3. full walk of the flagged entries from the true T -------------------------------------------------------------
+        WalkState wf{T, T, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || T < 0.0001f, 0ull};
+        if (mine && __ballot(!wf.done) != 0ull && n > 0) {
+            if (nchunks == 1) {
+                const unsigned long long todo = s_took[w][0];         // (own wave's write, in program order)
+                if (todo) walk_flagged<false>(todo, s_rec, oprow, qxy, px.q.z, 0u, wf);
+            } else {
+                for (uint32_t c = 0; c < nchunks; c++) {
+                    unsigned long long todo;
+                    bool have;
+                    const uint32_t kk = c * LG_CHUNK + lane;
+                    if (c < 8) { todo = s_took[w][c]; have = (todo >> lane) & 1ull; }
+                    else { have = kk < n && flp[sr.x + kk] != 0; todo = __ballot(have); }
+                    if (todo == 0ull) continue;
+                    const uint32_t g = have ? a.point_list[sr.x + kk] : 0u;
+                    const Staged st = gather_record(a.rec, a.rowspan, g, have);
+                    __builtin_amdgcn_wave_barrier();
+                    park_record(s_rec, lane, st);
+                    s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (__ballot(!wf.done) == 0ull) break;
+                    walk_flagged<false>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, wf);
+                }
+            }
+        }
+        if (mine) {
+            float* segbase = pbase + (size_t)k * pstride;
+            segbase[LG_SEG_TPASS * 64 + lane] = Tp;
+            segbase[LG_SEG_C0 * 64 + lane] = wf.C01.x;
+            segbase[LG_SEG_C1 * 64 + lane] = wf.C01.y;
+            segbase[LG_SEG_D * 64 + lane] = wf.D;
+            segbase[LG_SEG_TEND * 64 + lane] = wf.T;
+            segbase[LG_SEG_TBREAK * 64 + lane] = wf.T_break;
+            reinterpret_cast<uint32_t*>(segbase)[LG_SEG_LAST * 64 + lane] = wf.last;
+        }
+        s_x[w][1][lane] = wf.C01.x; s_x[w][2][lane] = wf.C01.y; s_x[w][3][lane] = wf.D; s_x[w][4][lane] = wf.T; s_x[w][5][lane] = wf.T_break;
+        __syncthreads();
+        // ---- 4. fold the round in list order (k_render_combine's logic), advance the carry ------------------------------------
+        const int nseg = min(NW, St - k0);
+        for (int v = 0; v < nseg; v++) {
+            const bool use = !stopped;
+            C0 += use ? s_x[v][1][lane] : 0.f; C1 += use ? s_x[v][2][lane] : 0.f; D += use ? s_x[v][3][lane] : 0.f;
+            T_final = use ? s_x[v][4][lane] : T_final;
+            const float tb = s_x[v][5][lane];
+            T_hand = use ? tb : T_hand;
+            stopped = stopped || (use && tb < 0.0001f);
+            carry *= s_x[v][0][lane];
+        }
+        walked = k0 + nseg;
+        const bool all_stopped = __ballot(!stopped) == 0ull;
+        __syncthreads();                                               // s_x is rewritten by the next round
+        if (all_stopped) break;
+    }
+    if (w == 0) {
+        if (lane == 0) a.alive[patch] = (walked >= St) ? 255 : (uint8_t)min(walked, 254);
+        if (px.inside) {
+            const size_t N = (size_t)a.grid.W * a.grid.H;
+            a.final_T[px.pix] = T_final;
+            if (a.T_pass) a.T_pass[px.pix] = T_hand;
+            const float b0 = a.bg ? a.bg[0] : 0.f, b1 = a.bg ? a.bg[1] : 0.f;
+            a.out_color[px.pix] = C0 + T_final * b0;
+            a.out_color[N + px.pix] = C1 + T_final * b1;
+            a.out_depth[px.pix] = D;
+            a.out_occ[px.pix] = 1.f - T_final;
+        }
+    }
+}
+
 // Pass 1 runs in rounds of growing depth; after the round that ends at segment `front`, a patch stays open (limit 255) if
 // some pixel's transmittance through those segments (product of the T-only walks, i.e. the hand-over value of a walk from
 // T = 1) is still >= 1e-4 and its list goes on; otherwise its limit becomes `front` and nothing behind is ever walked.
@@ -460,6 +628,14 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     a.out_occ[pix] = 1.f - T_final;
 }
 
+// waves per workgroup of the fused forward blend: LIDARGS_FUSED_WAVES = 4, 8 (default) or 16
+void launch_render_fused(const RenderFwdArgs& a, hipStream_t s) {
+    static const int env = [] { const char* e = getenv("LIDARGS_FUSED_WAVES"); return e ? atoi(e) : 0; }();
+    const unsigned patches = (unsigned)a.grid.window_patches();
+    if (env == 4) hipLaunchKernelGGL(k_render_fused<4>, dim3(patches), dim3(256), 0, s, a);
+    else if (env == 16) hipLaunchKernelGGL(k_render_fused<16>, dim3(patches), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(k_render_fused<8>, dim3(patches), dim3(512), 0, s, a);
+}
 void launch_render_alive(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned patches = (unsigned)a.grid.window_patches();
     hipLaunchKernelGGL(k_render_alive, dim3(patches), dim3(64), 0, s, a);

@@ -62,7 +62,7 @@ class _EnqueueState:
         """From an ordinary frame's num_rendered (instance capacity | tile-height code)."""
         need = int(num_rendered) & ~3
         self.th = 4 << (int(num_rendered) & 3)
-        self.cap = max(int(need * self.HEADROOM) + 4096, self.cap or 0)
+        self.cap = max((int(need * self.HEADROOM) + 4096 + 3) & ~3, self.cap or 0)      # multiples of 4: what num_rendered can carry
 
     def plan(self):
         """(capacity, tile_rows, status) for the next frame, or None while nothing has been learnt.  Looks at the status of
@@ -75,7 +75,7 @@ class _EnqueueState:
             self.pending = False
             need, over = int(self.status[0]), int(self.status[8])
             if need * 1.08 > self.cap:
-                self.cap = int(need * self.HEADROOM) + 4096
+                self.cap = (int(need * self.HEADROOM) + 4096 + 3) & ~3
             if over:
                 raise RuntimeError(f"diff_lidargs_rasterization: an enqueue-only frame needed {need} list instances but its binning "
                                    f"buffer held {int(self.status[9])}; that frame's outputs are invalid (capacity raised to {self.cap}, "

@@ -611,7 +611,9 @@ class ShellRasterizer(nn.Module):
 # ======================================================================================================================
 # Column wedges: the pixels of a range image are independent, so rank g can own the pixel COLUMNS [e_g, e_{g+1}) (whole
 # 16-pixel tile columns) and bin every Gaussian that can reach them.  Its lists are then the complete single-GPU lists of its
-# tiles: same instances, same order, same early-out -- the image columns it renders are BIT-IDENTICAL to a single GPU's, with no
+# tiles: same instances, same order, same early-out -- the image columns it renders equal a single GPU's up to the GROUPING of the
+# per-segment partial sums (a rank derives its segment plan from its own instance total; whenever the plan coincides with the
+# single-GPU one -- every configuration the tests and the bench run -- they are bit-identical, which the tests assert), with no
 # transmittance exchange and no second pass.  What crosses xGMI:
 #   forward   all_gather of the rank's columns of the four image planes (4 H W / N floats per rank; the gradient split sizes ride
 #             along) + an all-reduce(max) of the scattered radii, overlapped with the rendering;
@@ -733,7 +735,8 @@ class _WedgeRasterize(torch.autograd.Function):
 
 class WedgeRasterizer(nn.Module):
     """Column-wedge sharded counterpart of GaussianRasterizer.forward (colors_precomp + scales/rotations path).  Inputs are
-    REPLICATED on every rank; outputs are identical on every rank and, for the image, bit-identical to the single-GPU forward;
+    REPLICATED on every rank; outputs are identical on every rank and, for the image, equal to the single-GPU forward's up to the
+    grouping of the per-segment partial sums (bit-identical whenever the rank's segment plan is the single-GPU one);
     gradients follow `grad_sync` ("reduce_scatter": rank r ends with rows [r*P/N, (r+1)*P/N); "all_reduce"; "none")."""
 
     def __init__(self, raster_settings, comm=None, backend=None, grad_sync="reduce_scatter", edges=None):

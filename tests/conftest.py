@@ -50,15 +50,18 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         return
     worst_p999 = max(log, key=lambda s: s["p999"])
     worst_max = max(log, key=lambda s: s["max"])
-    worst_frac = max(log, key=lambda s: s["outlier_frac_used"])
+    worst_frac = max(log, key=lambda s: s["soft_frac_used"])
+    worst_flip = max(log, key=lambda s: s["flip_frac_used"])
     with_out = [s for s in log if s["outliers"] > 0]
     tr = terminalreporter
     tr.write_sep("-", "parity budget used (tests/util.py: rtol 1e-4 with floor 1e-3 max|ref|)")
     tr.write_line(f"parity() calls: {len(log)}; calls with any entry over rtol: {len(with_out)}")
     tr.write_line(f"worst p99.9 : {worst_p999['p999']:.3e}  ({worst_p999['name']}, n={worst_p999['n']})")
-    tr.write_line(f"worst max   : {worst_max['max']:.3e}  ({worst_max['name']}, n={worst_max['n']}); cap {worst_max['outlier_max']:g}")
-    tr.write_line(f"worst outlier fraction: {worst_frac['outlier_frac_used']:.3e} = {worst_frac['outliers']} of {worst_frac['n']} "
+    tr.write_line(f"worst max   : {worst_max['max']:.3e}  ({worst_max['name']}, n={worst_max['n']})")
+    tr.write_line(f"worst soft fraction (rtol < err <= 1e-3): {worst_frac['soft_frac_used']:.3e} = {worst_frac['soft']} of {worst_frac['n']} "
                   f"({worst_frac['name']}); allowed {worst_frac['allowed']}")
+    tr.write_line(f"worst flip fraction (err > 1e-3): {worst_flip['flip_frac_used']:.3e} = {worst_flip['flips']} of {worst_flip['n']} "
+                  f"({worst_flip['name']}); allowed {worst_flip['allowed_flips']}")
     try:
         import json
         out = os.path.join(ROOT, "gpurun_out")
@@ -66,7 +69,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
             os.makedirs(out, exist_ok=True)
             with open(os.path.join(out, "parity_budget.json"), "w") as f:
                 json.dump(dict(calls=len(log), calls_with_outliers=len(with_out), worst_p999=worst_p999, worst_max=worst_max,
-                               worst_outlier_fraction=worst_frac,
-                               over_rtol=[dict(name=s["name"], n=s["n"], outliers=s["outliers"], max=s["max"]) for s in with_out]), f, indent=1)
+                               worst_soft_fraction=worst_frac, worst_flip_fraction=worst_flip,
+                               over_rtol=[dict(name=s["name"], n=s["n"], soft=s["soft"], flips=s["flips"], max=s["max"]) for s in with_out]), f, indent=1)
     except Exception as e:      # the summary must never fail a run
         tr.write_line(f"(parity_budget.json not written: {e})")

@@ -57,6 +57,20 @@ def test_argument_validation_happens_before_any_device_work(hip_lib_built):
     assert rc == 0
 
 
+def test_column_wedge_entry_points_refuse_a_precomputed_covariance(hip_lib_built):
+    """lidargs_wedge_select_count bounds a Gaussian's reach from scales + rotations; with cov3D_precomp there is no bound and the wedge
+    would silently miss boundary Gaussians -- the wedge forward / backward refuse it before any device work."""
+    lib = ctypes.CDLL(hip_lib_built)
+    lib.lidargs_last_error.restype = ctypes.c_char_p
+    f = ctypes.c_float
+    dummy = (f * 16)()
+    p = ctypes.cast(dummy, ctypes.c_void_p)
+    rc = lib.lidargs_forward_wedge(None, None, None, None, None, None, ctypes.c_int(4), p, ctypes.c_int(512), ctypes.c_int(16), p, p, p, None,
+                                   f(1.0), None, p, p, p, ctypes.c_int(80), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(256), p, p, p, p, p,
+                                   ctypes.c_int(0), None)
+    assert rc < 0 and b"cov3D_precomp is not supported on the column-wedge path" in lib.lidargs_last_error()
+
+
 def test_python_surface_matches_reference(hip_lib_built):
     import diff_lidargs_rasterization as d
     assert d.GaussianRasterizationSettings._fields == (

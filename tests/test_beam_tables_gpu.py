@@ -186,4 +186,4 @@ np.savez(sys.argv[1], instances=_C.last_counters()["instances"], **{k: hip[k] fo
     assert int(a["instances"]) < 0.9 * int(b["instances"])
     assert np.array_equal(a["radii"], b["radii"])
     for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
-        parity(f"pruned vs unpruned {k}", a[k], b[k], rtol=2e-5, outlier_frac=0.0, verbose=False)
+        parity(f"pruned vs unpruned {k}", a[k], b[k], rtol=2e-5, verbose=False)

@@ -13,9 +13,7 @@ from test_neural_gaussians_cpu import PARAM_KEYS, load_case
 from util import parity
 
 pytestmark = pytest.mark.gpu
-# the decode chains tanh / sigmoid / normalise through fp32 MLPs: an opacity within an ulp of the `> 0` mask edge flips a whole row;
-# measured use 6e-4 (r02_a), budget:
-NG_OUTLIER_FRAC = 1.5e-3
+# (no outlier-budget override any more: tests/util.py's soft / flip classes apply as everywhere else)
 
 
 def build_pc(p, device="cuda"):
@@ -51,11 +49,11 @@ def test_decode_matches_reference_golden(tag, hip_lib_built):
     flips = int((r["mask"] != exp["out_mask"]).sum())
     assert flips == 0, f"{flips} opacity-sign flips"
     for k in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
-        parity(k, r[k], exp["out_" + k], outlier_frac=NG_OUTLIER_FRAC)
+        parity(k, r[k], exp["out_" + k])
     for k in ("anchor_feat", "anchor", "offset", "scaling"):
-        parity("d" + k, r["g_" + k], exp["g_" + k], outlier_frac=NG_OUTLIER_FRAC)
+        parity("d" + k, r["g_" + k], exp["g_" + k])
     for k in PARAM_KEYS:
-        parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4, outlier_frac=NG_OUTLIER_FRAC)       # fp32 GEMM accumulation order, see the CPU test
+        parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4)       # fp32 GEMM accumulation order, see the CPU test
 
 
 def random_case(N, k, seed, flags=(True, True, True)):
@@ -75,12 +73,16 @@ def test_decode_matches_oracle_random(N, k, flags, hip_lib_built):
     flips = int((r["mask"] != f["mask"]).sum())
     assert flips <= max(1, int(1e-5 * f["mask"].size)), flips
     if flips == 0:
+        # tanh(y), y = b2 + sum_j W2[o][j] h[j]: a sum of 32 fp32 products that cancels to ~0 for the opacities near the mask's edge, so
+        # the rounding error is relative to the magnitude of the TERMS (as for the surfel distortion): scale = max_o (|b2| + sum |W2 h|)
+        hid = f["_ctx"]["hid"]["opacity"]
+        op_scale = float((np.abs(hid) @ np.abs(p["opacity_W2"]).T + np.abs(p["opacity_b2"])).max())
         for key in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
-            parity(key, r[key], f[key], outlier_frac=NG_OUTLIER_FRAC)
+            parity(key, r[key], f[key], scale=(op_scale if "opacity" in key else None))
         for key in ("anchor_feat", "anchor", "offset", "scaling"):
-            parity("d" + key, r["g_" + key], g[key], outlier_frac=NG_OUTLIER_FRAC)
+            parity("d" + key, r["g_" + key], g[key])
         for key in PARAM_KEYS:
-            parity("d" + key, r["g_" + key], g[key], rtol=5e-4, outlier_frac=NG_OUTLIER_FRAC)
+            parity("d" + key, r["g_" + key], g[key], rtol=5e-4)
 
 
 def test_decode_edge_cases(hip_lib_built):
@@ -96,7 +98,7 @@ def test_decode_edge_cases(hip_lib_built):
     r = run_hip(p, cam, None)                                          # visible_mask=None: every anchor
     f = ng.forward(p, cam, None)
     assert np.array_equal(r["mask"], f["mask"])
-    parity("xyz", r["xyz"], f["xyz"], outlier_frac=NG_OUTLIER_FRAC)
+    parity("xyz", r["xyz"], f["xyz"])
     # unsupported configurations are refused loudly
     from neural_gaussians import generate_neural_gaussians
     pc = build_pc(p); pc.use_feat_bank = True
@@ -112,9 +114,9 @@ def test_decode_gemm_fed_backward_still_matches(hip_lib_built, monkeypatch):
     ups = [exp["up_" + k] for k in ("xyz", "color", "opacity", "scaling", "rot")]
     r = run_hip(p, cam, vis, ups)
     for k in ("anchor_feat", "anchor", "offset", "scaling"):
-        parity("d" + k, r["g_" + k], exp["g_" + k], outlier_frac=NG_OUTLIER_FRAC)
+        parity("d" + k, r["g_" + k], exp["g_" + k])
     for k in PARAM_KEYS:
-        parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4, outlier_frac=NG_OUTLIER_FRAC)
+        parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4)
 
 
 def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_built, monkeypatch):
@@ -127,4 +129,4 @@ def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_buil
     r = run_hip(p, cam, vis, None)
     assert int((r["mask"] != exp["out_mask"]).sum()) == 0
     for k in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
-        parity(k, r[k], exp["out_" + k], outlier_frac=NG_OUTLIER_FRAC)
+        parity(k, r[k], exp["out_" + k])

@@ -10,6 +10,7 @@ from util import (GRAD_KEYS_SURFEL, hip_surfel_forward_backward, oracle_surfel_f
 pytestmark = pytest.mark.gpu
 
 OTHERS = ("depth", "alpha", "normal_x", "normal_y", "normal_z", "median_depth", "distortion")
+MEDIAN_TIE_FRAC = 1e-3      # pixels whose T sits within rounding of 0.5 when a surfel is blended: the median-depth selection may pick the neighbour
 
 
 def _check(scene, W, H, seed, grads=True, **kw):
@@ -21,7 +22,9 @@ def _check(scene, W, H, seed, grads=True, **kw):
         h0 = hip_surfel_forward_backward(scene, W, H, None, **kw)
         r0 = oracle_surfel_forward_backward(scene, W, H, None, **kw)
         tie = np.abs(h0["others"][5] - r0["others"][5]) > 1e-4 * (np.abs(r0["others"][5]) + 1e-3)
-        assert tie.mean() < 2e-3
+        n_tie, allowed = int(tie.sum()), max(2, int(MEDIAN_TIE_FRAC * tie.size))
+        print(f"[surfel] median-depth near-tie pixels removed from the upstream gradient: {n_tie} of {tie.size} (allowed {allowed})")
+        assert n_tie <= allowed
         g[1][5][tie] = 0.0
     hip = hip_surfel_forward_backward(scene, W, H, g, **kw)
     ref = oracle_surfel_forward_backward(scene, W, H, g, **kw)
@@ -33,12 +36,16 @@ def _check(scene, W, H, seed, grads=True, **kw):
             # the median depth is a selection (the depth of the surfel at which T crosses 0.5): a pixel whose T lands
             # within an ulp of 0.5 picks the neighbour surfel; those pixels are bounded in number, not in size
             d = np.abs(hip["others"][k] - ref["others"][k]) > 1e-4 * (np.abs(ref["others"][k]) + 1e-3)
-            assert d.mean() < 2e-3, f"median depth differs on {d.mean():.2%} of the pixels"
+            assert int(d.sum()) <= max(2, int(MEDIAN_TIE_FRAC * d.size)), f"median depth differs on {int(d.sum())} of {d.size} pixels"
         elif name == "distortion":
             # sum of (m^2 (1-T) + M2 - 2 m M1) w (R2/cr/forward.cu:497-499): a difference of O(1) terms (m in [0,1)) that
             # cancels 4-5 digits, evaluated in fp32 by the reference.  Its rounding error is absolute, ~ulp(1) per blended
             # surfel, so the 1e-4 relative bar applies to the magnitude of the terms, not of the (tiny) difference.
-            parity("others." + name, hip["others"][k], ref["others"][k], scale=10.0)
+            # The terms' magnitude comes from the oracle's own running sums M1 = sum m w, M2 = sum m^2 w (image state planes 1, 2,
+            # R2/cr/rasterizer_impl.cu:177): scale = max(M1^2, M2) over the image (<= 1), not a constant.
+            acc = ref["fwd"].array("accum").reshape(3, -1)
+            scale = float(max(np.square(acc[1]).max(), acc[2].max(), 1e-6))
+            parity("others." + name, hip["others"][k], ref["others"][k], scale=scale)
         else:
             parity("others." + name, hip["others"][k], ref["others"][k])
     if grads:

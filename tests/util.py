@@ -3,29 +3,36 @@ oracle, and the parity metric.
 
 Parity metric (north star: "within 1e-4 relative fp32 on identical inputs"):
     err_i = |hip_i - ref_i| / (|ref_i| + FLOOR * max|ref|)         FLOOR = 1e-3
-must be <= RTOL = 1e-4 for all but a tiny OUTLIER_FRAC of the entries.  The outlier budget exists
-because the algorithm has hard thresholds (alpha < 1/255, power > 0, T < 1e-4, ceil/round of the
-footprint rect): an input that lands within one ulp of a threshold can legitimately fall on either
-side when exp/atan2/cos round differently (device libm vs host libm vs CUDA libdevice), and such a
-flip moves a pixel by up to ~1 % and a gradient row by more.  Outliers are counted, bounded in size, and reported.
+Every entry is put in one of three classes:
+    ok     err <= RTOL = 1e-4
+    soft   RTOL < err <= SOFT_MAX = 1e-3     rounding that went through a cancellation (s - q loses three digits): at most SOFT_FRAC
+                                             of the entries
+    flip   err > SOFT_MAX                    a hard threshold of the algorithm landed on the other side (alpha < 1/255, power > 0,
+                                             T < 1e-4, ceil / round of the footprint rect): the input sat within an ulp of it and
+                                             exp / atan2 / cos round differently (device libm vs host libm vs CUDA libdevice).
+                                             A flip moves a pixel by up to a whole contribution and a gradient row by more, so
+                                             its SIZE is not bounded; its COUNT is: at most FLIP_FRAC of the entries.
+(both counts: at least MIN_COUNT = 2, so that a 100-entry array is not judged on a fraction of one entry).  There are no
+per-call overrides of these budgets; a test that needs another rule states it as its own assertion (the surfel variant's median
+depth, a selection, is checked by count in tests/test_surfel_gpu.py).
 
-Budget vs use (GPU run r02_a, 741 parity() calls, gpurun_out/parity_budget.json; conftest.py prints the summary of every run):
-the rasterizer's worst call had 1.3e-4 of its entries over 1e-4 (8 of 60 000, a dense 64-beam case), the full-size wedge
-checks 0 (cfg2/3/4) to 1.0e-4 (surfel cfg5); the largest single error was 3.5e-2 (one threshold flip); p99.9 of the full-size
-wedges is <= 3e-6.  OUTLIER_FRAC is therefore 5e-4 (it was 2e-3), the cap stays at 5e-2.  For scale: two conforming
+Budget vs use: conftest.py prints the summary of every run and writes gpurun_out/parity_budget.json (committed per round under
+profiles/); round 3's run (profiles/r03_*_parity_budget.json) is what SOFT_FRAC / FLIP_FRAC were set from.  For scale: two conforming
 evaluations of the reference itself differ by more (tests/test_ulp_band_cpu.py: 0.2-2.5 % of the gradient entries over 1e-4).
 """
 import numpy as np
 
 RTOL = 1e-4
 FLOOR = 1e-3
-OUTLIER_FRAC = 5e-4
-OUTLIER_MAX = 5e-2
+SOFT_MAX = 1e-3
+SOFT_FRAC = 5e-4
+FLIP_FRAC = 2e-4
+MIN_COUNT = 2
 # every parity() call of the session, for the "budget used" summary conftest.py prints and writes (gpurun_out/parity_budget.json)
 PARITY_LOG = []
 
 
-def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, outlier_frac=OUTLIER_FRAC, outlier_max=OUTLIER_MAX, verbose=True, scale=None):
+def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, verbose=True, scale=None):
     hip = np.asarray(hip, dtype=np.float64).ravel()
     ref = np.asarray(ref, dtype=np.float64).ravel()
     assert hip.shape == ref.shape, (name, hip.shape, ref.shape)
@@ -34,18 +41,21 @@ def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, outlier_frac=OUTLIER_FRAC, ou
         return dict(name=name, max=0.0, outliers=0, n=0)
     scale = np.abs(ref).max() if scale is None else float(scale)   # `scale`: magnitude of the terms the value is a difference of
     err = np.abs(hip - ref) / (np.abs(ref) + floor * scale + 1e-30)
-    bad = err > rtol
-    nbad = int(bad.sum())
+    soft_max = max(SOFT_MAX, 10.0 * rtol)
+    n_soft = int(((err > rtol) & (err <= soft_max)).sum())
+    n_flip = int((err > soft_max).sum())
     stats = dict(name=name, max=float(err.max()), p999=float(np.quantile(err, 0.999)), median=float(np.median(err)),
-                 outliers=nbad, n=int(ref.size), scale=float(scale))
+                 outliers=n_soft + n_flip, soft=n_soft, flips=n_flip, n=int(ref.size), scale=float(scale))
     if verbose:
         print(f"[parity] {name:18s} n={ref.size:9d} scale={scale:.3e} median={stats['median']:.2e} "
-              f"p99.9={stats['p999']:.2e} max={stats['max']:.2e} outliers(>{rtol:g})={nbad}")
-    allowed = max(2, int(outlier_frac * ref.size))
-    stats.update(allowed=allowed, outlier_frac_used=nbad / ref.size, rtol=rtol, outlier_max=outlier_max)
+              f"p99.9={stats['p999']:.2e} max={stats['max']:.2e} soft(>{rtol:g})={n_soft} flips(>{soft_max:g})={n_flip}")
+    allowed_soft = max(MIN_COUNT, int(SOFT_FRAC * ref.size))
+    allowed_flip = max(MIN_COUNT, int(FLIP_FRAC * ref.size))
+    stats.update(allowed=allowed_soft, allowed_flips=allowed_flip, outlier_frac_used=(n_soft + n_flip) / ref.size, soft_frac_used=n_soft / ref.size,
+                 flip_frac_used=n_flip / ref.size, rtol=rtol, soft_max=soft_max)
     PARITY_LOG.append(stats)
-    assert nbad <= allowed, f"{name}: {nbad} of {ref.size} entries exceed rtol={rtol} (allowed {allowed}); max err {err.max():.3e}"
-    assert err.max() <= outlier_max, f"{name}: largest error {err.max():.3e} exceeds the outlier cap {outlier_max}"
+    assert n_soft <= allowed_soft, f"{name}: {n_soft} of {ref.size} entries in ({rtol}, {soft_max}] (allowed {allowed_soft}); max err {err.max():.3e}"
+    assert n_flip <= allowed_flip, f"{name}: {n_flip} of {ref.size} entries over {soft_max} (threshold flips; allowed {allowed_flip}); max err {err.max():.3e}"
     return stats
 
 
