@@ -913,6 +913,9 @@ def main():
                     help="beam-inclination table of the synthetic scene (lidargs_scenes.beam_table): uniform = SURVEY 8d; waymo = "
                          "non-uniform stand-in for the measured table the Waymo configs read from the dataset json")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: capture forward + backward of the enqueue-only path (lidargs_forward_enqueue: no host wait) in a HIP graph "
+                         "and time its replays -- what a training loop does when the host, not the GPU, bounds a small frame")
     ap.add_argument("--enqueue-only", action="store_true",
                     help="render with GaussianRasterizer.enqueue_only (lidargs_forward_enqueue: no host wait per frame); single GPU only")
     args = ap.parse_args()
@@ -1025,7 +1028,41 @@ def main():
                 color, depth, occ, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
                                                 colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
                 torch.autograd.backward([color, depth, occ], [gc, gd, go])
+        eager_step = step
+        if args.graph:
+            assert not fwd_only, "--graph captures forward + backward"
+            rast.enqueue_only = True
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # learn capacity / tile height and warm up off the default stream, as capture asks
+                for _ in range(4):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for t in list(leaves.values()) + [means2D]:
+                t.grad = None
+            import gc as _gc
+            _gc.collect()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager_step()
+            step = graph.replay
         res = timed_region(step)
+        if args.graph:
+            assert not rast.enqueue_status()["overflow"], "the captured binning capacity was too small"
+            _C.profile_enable(True)                       # a replay makes no library calls: the stage events come from eager frames, after the timed region
+            rast2 = GaussianRasterizer(settings)
+            def eager2():
+                for t in list(leaves.values()) + [means2D]:
+                    t.grad = None
+                color, depth, occ, radii = rast2(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                                 colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+                torch.autograd.backward([color, depth, occ], [gc, gd, go])
+            for _ in range(16):
+                eager2()
+            torch.cuda.synchronize()
+            res["stages"], res["cnt"] = _C.profile_summary(), _C.last_counters()
+            _C.profile_enable(False)
     else:
         import math
         import torch.distributed as dist
@@ -1100,7 +1137,8 @@ def main():
                                    f"lidar_far=80 lidar_near=0, bg=0" + ("" if args.beams == "uniform" else f", beam table '{args.beams}' (non-uniform)"),
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
                        "patch_instance_pairs_taken": cnt["taken_instances"], "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
-                       "forward": "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)",
+                       "forward": ("HIP-graph replay of forward + backward (enqueue-only path captured once)" if args.graph else
+                                   "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)"),
                        "sharding": "single GPU" if world == 1 and not force_shells else
                                    (f"{world} range shells" if args.shard == "shells" else f"{world} column wedges")},
         }

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits>
+#include <algorithm>
 #include <mutex>
 
 namespace {
@@ -370,12 +371,23 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (!enqueue_only) LG_HIP((hipError_t)lg::api_read_words_begin(geom.totals, LG_TOTALS_READ_WORDS, stream));
     lg::RadixTail span_tail;                                           // the sort's last pass leaves the spans in range order as well
     span_tail.src = geom.spans; span_tail.dst = geom.span_sorted; span_tail.mode = pp.compact ? 1 : 2;
-    const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
-                                                 range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true,   // (the scratch is carved for 11-bit digits; ids = positions)
-                                                 span_tail);
-    const uint32_t* ids_sorted = side ? geom.id_b : geom.id_a;
-    LG_STAGE_CHECK("range sort");
-    g_prof.mark("range_sort", stream);
+    const uint32_t* ids_sorted;
+    // The sort runs on key - kmin (the preprocess left ~kmin and kmax in the totals' slots): a frame's ranges span far fewer than 31 key
+    // bits -- 2 m .. 80 m is 26 -- and every 8-9 bits less is a pass (three launches) less.  kmin is rounded down to a multiple of 256,
+    // so the first pass (the key's own low byte) needs no host knowledge and is queued right behind the totals' copy; the host then
+    // reads the span and queues as many more passes as it has bits.
+    if (enqueue_only) {                                                // no host read: all 31 bits of the raw key
+        const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
+                                                     range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true, span_tail);   // (scratch carved for 11-bit digits; ids = positions)
+        ids_sorted = side ? geom.id_b : geom.id_a;
+        LG_STAGE_CHECK("range sort");
+        g_prof.mark("range_sort", stream);
+    } else {
+        lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 8, geom.scratch, stream, 8, nullptr,
+                                    lg::SORT_MAX_RADIX_BITS, true);                                       // -> (key_b, id_b)
+        LG_STAGE_CHECK("range sort, first pass");
+        ids_sorted = nullptr;
+    }
 
     // 2. the one host wait (R3/cr/rasterizer_impl.cu:292), for a copy that was queued before the sort: the instance totals for tile
     //    heights 4 / 8 / 16 / 32 -> tile height, R; then the instance offsets in range order for that height.  The device is still
@@ -387,6 +399,26 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (!enqueue_only) {
         uint32_t totals_h[LG_TOTALS_READ_WORDS];                           // the slots of 64-bit instance totals the preprocess filled
         LG_HIP((hipError_t)lg::api_read_words_end(LG_TOTALS_READ_WORDS, totals_h));
+        {   // the rest of the range sort: bits [8, bits of (kmax - kmin + 1)) in passes of at most 9 bits; at least one pass, for the tail
+            uint32_t kinv = 0u, kmax = 0u;
+            for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
+                kinv = std::max(kinv, totals_h[LG_TOTALS_KEYSPAN_WORD + 2 * slot]); kmax = std::max(kmax, totals_h[LG_TOTALS_KEYSPAN_WORD + 2 * slot + 1]);
+            }
+            lg::KeyBias kb;
+            kb.kmin = (~kinv) & ~255u;                                      // a multiple of 256: (key - kmin) & 255 == key & 255
+            if (kmax < kb.kmin) { kb.kmin = 0u; kmax = 0u; }               // no visible Gaussian: every key is the culled one
+            kb.cull = ((kmax - kb.kmin) | 255u) + 1u;                       // above every valid key - kmin in the bits the later passes sort on
+            const uint32_t top = kb.cull;
+            int bits = 32 - __builtin_clz(top | 1u);
+            if (bits < 9) bits = 9;
+            static const int env_full = [] { const char* e = getenv("LIDARGS_RANGE_SORT_FULL"); return e ? atoi(e) : 0; }();   // 1: always 31 bits (A/B)
+            if (env_full) { bits = 32; kb.kmin = 0u; kb.cull = 0xFFFFFFFFu; }
+            const int side = lg::launch_radix_sort_pairs(geom.key_b, geom.key_a, geom.id_b, geom.id_a, (size_t)P, bits, geom.scratch, stream,
+                                                         bits > 26 ? 8 : 9, nullptr, lg::SORT_MAX_RADIX_BITS, false, span_tail, 8, &kb);
+            ids_sorted = side ? geom.id_a : geom.id_b;
+            LG_STAGE_CHECK("range sort");
+            g_prof.mark("range_sort", stream);
+        }
         unsigned long long inst[4] = {0, 0, 0, 0};
         for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
             unsigned long long v[4];

@@ -113,9 +113,17 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 //                         amplification with direct per-key scatter).
 // `n_dev` (nullable): the pair count lives on the device (enqueue-only forward: the host never learns it); the launch then covers the
 // capacity `n` and the blocks behind *n_dev see no keys (their histograms are zero, their scatter retires).
+// The value a pass takes its digit from: the key itself, or (range sort with a bias) key - kmin with the culled key 0xFFFFFFFF mapped
+// just above the largest valid one.
+struct KeyMap {
+    uint32_t kmin, cull; bool on;                                      // by value in the kernel arguments (host-side: KeyBias)
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return on ? (k == 0xFFFFFFFFu ? cull : k - kmin) : k; }
+};
+static inline KeyMap key_map(const KeyBias* b) { KeyMap m; m.on = b != nullptr; m.kmin = b ? b->kmin : 0u; m.cull = b ? b->cull : 0xFFFFFFFFu; return m; }
+
 template <int BITS, int ITEMS>
 __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev, int shift,
-                                                    uint32_t* __restrict__ hist, unsigned nblocks) {
+                                                    uint32_t* __restrict__ hist, unsigned nblocks, const KeyMap km) {
     constexpr int BINS = 1 << BITS;
     if (n_dev) n = min(n, (size_t)*n_dev);
     __shared__ uint32_t cnt[BINS];
@@ -132,7 +140,7 @@ __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
-        if (i < n) atomicAdd(&cnt[(k[r] >> shift) & (BINS - 1)], 1u);
+        if (i < n) atomicAdd(&cnt[(km(k[r]) >> shift) & (BINS - 1)], 1u);
     }
     __syncthreads();
     for (int d = tid; d < BINS; d += 256) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
@@ -197,7 +205,8 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        size_t n, const uint32_t* __restrict__ n_dev, int shift, const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
-                                                       const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks, const RadixTail tail) {
+                                                       const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks, const RadixTail tail,
+                                                       const KeyMap km) {
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = 256 * ITEMS;                    // keys per block
     constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
@@ -253,7 +262,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const bool valid = base + (size_t)r * 64 + lane < n;
-        const uint32_t d = (k[r] >> shift) & (BINS - 1);
+        const uint32_t d = (km(k[r]) >> shift) & (BINS - 1);
         // peers = the lanes holding the same digit: for every digit bit, keep the lanes whose bit equals mine.  With `mine` = the bit
         // spread over a word (0 / ~0), that is peers & ~(ballot ^ mine) -- ONE v_bitop3_b32 per 32 lanes and bit on gfx950
         // (truth table 0x90 = a & ~(b ^ c)) instead of a select, an xor and an and.
@@ -308,7 +317,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         if (base + (size_t)r * 64 + lane < n) {
-            const uint32_t d = (k[r] >> shift) & (BINS - 1);
+            const uint32_t d = (km(k[r]) >> shift) & (BINS - 1);
             const uint32_t p = run[w][d] + pos[r];
             s_key[p] = k[r]; s_val[p] = v[r];
         }
@@ -320,7 +329,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     if (tail.mode == 0) {
         for (uint32_t i = tid; i < count; i += 256) {
             const uint32_t kk = s_key[i];
-            const uint32_t d = (kk >> shift) & (BINS - 1);
+            const uint32_t d = (km(kk) >> shift) & (BINS - 1);
             const size_t g = (size_t)gbase[d] + (i - dbase[d]);
             keys_out[g] = kk; vals_out[g] = s_val[i];
         }
@@ -333,7 +342,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
             const uint32_t i = tid + 256u * (uint32_t)r;
             const uint32_t ii = i < count ? i : 0u;
             const uint32_t kk = s_key[ii];
-            const uint32_t d = (kk >> shift) & (BINS - 1);
+            const uint32_t d = (km(kk) >> shift) & (BINS - 1);
             g[r] = (size_t)gbase[d] + (ii - dbase[d]);
             v[r] = s_val[ii];
         }
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 // chain is the launch's length.
 template <int BITS, int ITEMS>
 static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
-                             uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail) {
+                             uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail, const KeyBias* bias) {
     const size_t cap_bins = (size_t)1 << scratch_bits;           // the scratch layout of sort_scratch_words(n, scratch_bits)
     constexpr size_t CHUNK = 256 * ITEMS;
     const unsigned nb = (unsigned)((n + CHUNK - 1) / CHUNK);
@@ -371,7 +380,7 @@ static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t*
     const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
     const bool two_level = chunks_all > 2;
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
-    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb);
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb, key_map(bias));
     // single level: the chunk sums ARE the digit totals, written straight to `tot`
     const dim3 pgrid(BINS * chunks);
     uint32_t* const pout = two_level ? part : tot;
@@ -380,49 +389,184 @@ static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t*
     else hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
     hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
-                       two_level ? part : (const uint32_t*)nullptr, chunk, chunks, tail);
+                       two_level ? part : (const uint32_t*)nullptr, chunk, chunks, tail, key_map(bias));
 }
+// ------------------------------------------------------------------------------------------------
+// Small inputs (<= SMALL_SORT_MAX pairs: small scenes, tests): the WHOLE multi-pass sort in ONE launch of one 1024-thread workgroup.
+// The general form spends three launches per pass on what is a few microseconds of work each at this size (a 10 k-Gaussian frame:
+// 12 + 6 launches, 80 us of a 0.2-ms frame).  Same algorithm, with the whole array as one block: wave w owns the w-th contiguous
+// slice (so (wave, round, lane) is the key order: stable), ballot-match ranks per 64-key round, per-(digit, wave) counts and their
+// digit-major scan in LDS, scatter through global memory (the ping-pong buffers are L2-resident); a workgroup barrier separates the
+// passes (workgroup-scope release: the waves of one workgroup share their CU's L1, which is coherent for them -- an agent-scope fence
+// by 1024 threads cost ~20 us per pass).
+constexpr int SMALL_SORT_WAVES = 16;
+constexpr int SMALL_SORT_ROUNDS = 16;                                  // rounds of 64 keys a wave holds in registers
+constexpr size_t SMALL_SORT_MAX = (size_t)SMALL_SORT_WAVES * SMALL_SORT_ROUNDS * 64;   // 16384 pairs
+__device__ __forceinline__ uint32_t load_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n,
+                                                                            const uint32_t* __restrict__ n_dev, int begin_bit, int end_bit, int max_bits,
+                                                                            int vals_are_positions, const RadixTail tail, const KeyMap km) {
+    constexpr int W = SMALL_SORT_WAVES, MAXB = 8, BINS = 1 << MAXB;
+    __shared__ uint32_t cnt[BINS][W + 1];                              // [digit][wave] counts, then bases (+1: no bank conflicts down a column)
+    __shared__ uint32_t wsum[W];
+    if (n_dev) n = min(n, *n_dev);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t per = ((n + W - 1) / W + 63u) & ~63u;               // keys per wave, whole rounds
+    const uint32_t lo = min(n, (uint32_t)w * per), hi = min(n, lo + per);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cur = 0, shift = begin_bit;
+    while (shift < end_bit) {
+        const int left = end_bit - shift;
+        const int passes_left = (left + max_bits - 1) / max_bits;
+        const int bits = (left + passes_left - 1) / passes_left;
+        const uint32_t mask = (1u << bits) - 1u;
+        const bool last = shift + bits >= end_bit;
+        const uint32_t* kin = cur ? key_b : key_a; const uint32_t* vin = cur ? val_b : val_a;
+        uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
+        const bool positions = shift == 0 && vals_are_positions;
+        for (int i = tid; i < BINS * (W + 1); i += 64 * W) (&cnt[0][0])[i] = 0u;
+        __syncthreads();
+        // the wave's slice -> registers, every load in flight at once (a load per round inside the loops below is an L2 round trip per
+        // round: measured 25 us per pass at 10 k keys)
+        uint32_t kreg[SMALL_SORT_ROUNDS], vreg[SMALL_SORT_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
+            const uint32_t i = lo + (uint32_t)r * 64u + lane;
+            kreg[r] = i < hi ? load_l2(kin + i) : 0u;
+            vreg[r] = i < hi ? (positions ? i : load_l2(vin + i)) : 0u;
+        }
+        // 1. per-(digit, wave) counts (one wave owns its column: plain LDS read-modify-writes in program order, through the peers' leader)
+#pragma unroll
+        for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
+            const uint32_t i = lo + (uint32_t)r * 64u + lane;
+            if (lo + (uint32_t)r * 64u >= hi) break;                   // wave-uniform
+            const bool valid = i < hi;
+            const uint32_t d = valid ? (km(kreg[r]) >> shift) & mask : 0u;
+            // all MAXB digit bits, unrolled (bits above the pass's width are 0 in every lane and change nothing): the eight ballots are
+            // independent, only the folds are a chain -- and each fold is one v_bitop3_b32 per half (a & ~(b ^ c), as in k_radix_scatter)
+            const unsigned long long v0 = __ballot(valid);
+            uint32_t plo = (uint32_t)v0, phi = (uint32_t)(v0 >> 32);
+#pragma unroll
+            for (int q = 0; q < MAXB; q++) {
+                const uint32_t mine = (uint32_t)(((int)(d << (31 - q))) >> 31);
+                const unsigned long long m = __ballot(mine != 0u);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, mine, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), mine, 0x90);
+            }
+            const unsigned long long peers = ((unsigned long long)phi << 32) | plo;
+            if (valid && (peers & lt) == 0ull) cnt[d][w] += (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // 2. exclusive scan, digit-major then wave-major: thread t owns BINS * W / 1024 = 4 consecutive (digit, wave) cells
+        {
+            constexpr int PER = BINS * W / (64 * W);                   // 4
+            uint32_t c[PER], tsum = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const int cell = tid * PER + q; c[q] = cnt[cell / W][cell % W]; tsum += c[q]; }
+            const uint32_t inc = wave_incl_scan(tsum, lane);
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            uint32_t off = inc - tsum;
+            for (int q = 0; q < w; q++) off += wsum[q];
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const int cell = tid * PER + q; cnt[cell / W][cell % W] = off; off += c[q]; }
+        }
+        __syncthreads();
+        // 3. scatter in key order
+#pragma unroll
+        for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
+            const uint32_t i = lo + (uint32_t)r * 64u + lane;
+            if (lo + (uint32_t)r * 64u >= hi) break;
+            const bool valid = i < hi;
+            const uint32_t k = kreg[r], v = vreg[r];
+            const uint32_t d = (km(k) >> shift) & mask;
+            // all MAXB digit bits, unrolled (bits above the pass's width are 0 in every lane and change nothing): the eight ballots are
+            // independent, only the folds are a chain -- and each fold is one v_bitop3_b32 per half (a & ~(b ^ c), as in k_radix_scatter)
+            const unsigned long long v0 = __ballot(valid);
+            uint32_t plo = (uint32_t)v0, phi = (uint32_t)(v0 >> 32);
+#pragma unroll
+            for (int q = 0; q < MAXB; q++) {
+                const uint32_t mine = (uint32_t)(((int)(d << (31 - q))) >> 31);
+                const unsigned long long m = __ballot(mine != 0u);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, mine, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), mine, 0x90);
+            }
+            const unsigned long long peers = ((unsigned long long)phi << 32) | plo;
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            const uint32_t pos = valid ? cnt[d][w] + rank : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) cnt[d][w] += (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                if (last && tail.mode != 0) {                          // the sorted keys are not needed: the value's record goes to its final place
+                    vout[pos] = v;
+                    if (tail.mode == 1) static_cast<uint32_t*>(tail.dst)[pos] = static_cast<const uint32_t*>(tail.src)[v];
+                    else { const uint4 sp = static_cast<const uint4*>(tail.src)[v]; static_cast<uint2*>(tail.dst)[pos] = make_uint2(sp.y, sp.x); }
+                } else {
+                    kout[pos] = k; vout[pos] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the pass's stores are visible to the workgroup's waves before the next pass reads them
+        __syncthreads();
+        shift += bits;
+        cur ^= 1;
+    }
+}
+
 template <int BITS>
 static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
-                       uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail) {
+                       uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail, const KeyBias* bias) {
     static const int env = [] { const char* e = getenv("LIDARGS_SORT_ITEMS"); return e ? atoi(e) : 0; }();   // 8 / 16 forces the block size
     const bool room = BITS + 1 <= scratch_bits;                  // twice the blocks x BINS <= the histogram area (and the chunk sums likewise)
     const bool half = room && (env ? env == 8 : n <= ((size_t)4 << 20));
     if constexpr (BITS <= 10) {
-        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail); return; }
+        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias); return; }
     }
-    radix_pass_items<BITS, SORT_ITEMS>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail);
+    radix_pass_items<BITS, SORT_ITEMS>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias);
 }
 
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions,
-                            RadixTail tail) {
-    if (n == 0 || end_bit <= 0) return 0;
+                            RadixTail tail, int begin_bit, const KeyBias* bias) {
+    if (n == 0 || end_bit <= begin_bit) return 0;
     if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
+    static const int small_off = [] { const char* e = getenv("LIDARGS_NO_SMALL_SORT"); return e ? atoi(e) : 0; }();
+    if (n <= SMALL_SORT_MAX && !small_off) {                           // the whole sort in one launch (k_radix_sort_small)
+        const int mb = max_bits > 8 ? 8 : max_bits;
+        int passes = 0;
+        for (int sh = begin_bit; sh < end_bit;) { const int left = end_bit - sh, pl = (left + mb - 1) / mb; sh += (left + pl - 1) / pl; passes++; }
+        hipLaunchKernelGGL(k_radix_sort_small, dim3(1), dim3(64 * SMALL_SORT_WAVES), 0, s, key_a, key_b, val_a, val_b, (uint32_t)n, n_dev, begin_bit, end_bit,
+                           mb, vals_are_positions ? 1 : 0, tail, key_map(bias));
+        return passes & 1;
+    }
     if (scratch_bits < max_bits) scratch_bits = max_bits;
     int cur = 0;
-    int shift = 0;
+    int shift = begin_bit;
     while (shift < end_bit) {
         const int left = end_bit - shift;
         uint32_t* kin = cur ? key_b : key_a; uint32_t* vin = cur ? val_b : val_a;
         if (shift == 0 && vals_are_positions) vin = nullptr;              // val_a is not read (and need not have been written)
+        const RadixTail none;
         uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
         // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4; 31 bits at 11 -> 11+10+10)
         const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
         const bool last = shift + bits >= end_bit;                       // the tail (a gather by the sorted values) rides on the last pass
         switch (bits) {
-            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
-            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : RadixTail()); break;
+            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
         }
         shift += bits;
         cur ^= 1;

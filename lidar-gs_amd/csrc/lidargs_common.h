@@ -104,10 +104,15 @@ __device__ __forceinline__ uint2 span_unpack(uint32_t w) {            // -> (xsp
 // word 4 of the totals: 0 while the packed gradient lines (gacc) are all-zero as the forward left them, 1 once a backward has
 // accumulated into them (k_gaussian_backward sets it; a further backward on the same buffers then clears the lines first)
 #define LG_TOTALS_DIRTY_WORD 4
+// behind the status words: LG_INST_SLOTS slots of (~smallest, largest) range key of the frame's visible Gaussians (atomicMax of the
+// preprocess blocks, spread over the slots like the instance totals; all start at 0, so an empty frame reads kmin = 0xFFFFFFFF,
+// kmax = 0).  The host folds them after its one read: the range sort then works on key - kmin and needs only as many passes as the
+// span has bits.
 // behind the slots: the 16 status words of an enqueue-only forward (binning.hip k_finish_totals)
 #define LG_TOTALS_STATUS_WORD (LG_TOTALS_SLOT_WORD + 8 * LG_INST_SLOTS)
 #define LG_STATUS_WORDS 16
-#define LG_TOTALS_READ_WORDS (LG_TOTALS_STATUS_WORD + LG_STATUS_WORDS)      // what the forward's host read copies
+#define LG_TOTALS_KEYSPAN_WORD (LG_TOTALS_STATUS_WORD + LG_STATUS_WORDS)
+#define LG_TOTALS_READ_WORDS (LG_TOTALS_KEYSPAN_WORD + 2 * LG_INST_SLOTS)   // what the forward's host read copies
 // behind that: LG_INST_SLOTS diagnostic slots of two 64-bit sums (visible Gaussians, reference 16x1 tiles_touched): read only by
 // lidargs_last_counters
 #define LG_TOTALS_DIAG_WORD LG_TOTALS_READ_WORDS
@@ -305,10 +310,15 @@ struct RadixTail { const void* src = nullptr; void* dst = nullptr; int mode = 0;
 // n_dev (nullable): the pair count lives on the device and n is only the capacity the launches cover
 // scratch_bits: the scratch holds sort_scratch_words(n, scratch_bits) words (0 = max_bits); room beyond the digit width lets small
 // inputs be sorted in half-size blocks (binning.hip radix_pass)
+// begin_bit: the sort runs on key bits [begin_bit, end_bit) (an LSD sort cut in two calls: the input of the second is the first's output)
+// bias (nullable): the passes sort on key - bias->kmin, with 0xFFFFFFFF (a culled Gaussian) mapped to bias->cull, so that end_bit only
+// has to cover the frame's key SPAN.  With kmin a multiple of 256 the low byte of key - kmin is the key's own low byte: a first pass
+// over bits [0, 8) needs no bias and can be queued before the host knows the span.
+struct KeyBias { uint32_t kmin, cull; };
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr, int scratch_bits = 0,
                             bool vals_are_positions = false,    // true: the values are 0..n-1 and val_a is never read
-                            RadixTail tail = RadixTail());
+                            RadixTail tail = RadixTail(), int begin_bit = 0, const KeyBias* bias = nullptr);
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
 // block instance offsets + the instance total from the spans in range order (filled by the range sort's last pass); compact: span_pack
 void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s);

@@ -111,6 +111,7 @@ struct PreKernelArgs {
     float4* gacc;                       // [4P] packed gradient lines of the backward: zeroed here for every Gaussian with radii > 0
     unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: instance counts for tile heights 4, 8, 16, 32 (zeroed by the caller)
     unsigned long long* diag_slots;     // [LG_INST_SLOTS][2]: visible Gaussians, reference tiles_touched (diagnostics)
+    uint32_t* key_span;                 // [LG_INST_SLOTS][2]: ~(smallest), largest range key of the visible Gaussians (zeroed by the caller)
     float2* coltab; float2* rowtab;     // pixel-ray tables for the blend, filled by the first workgroups (nullptr: not wanted)
 };
 
@@ -324,18 +325,26 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // sum, added to one of LG_INST_SLOTS slots -- 31 k waves adding to the same three words cost a millisecond, 7.8 k blocks
         // spread over 64 lines do not show; the host adds the slots up after its one read
         // (two more sums ride along for lidargs_last_counters: the visible Gaussians and the reference's 16x1 tiles_touched)
-        __shared__ uint32_t s_part[4][6];
+        __shared__ uint32_t s_part[4][8];
         uint32_t s4 = t4, s8 = t8, s16 = t16, s32 = t32, sv = reftiles ? 1u : 0u, sr = reftiles;
+        // ~(smallest) and largest range key of the block's visible Gaussians (key = 0xFFFFFFFF: culled -> neutral for both maxima)
+        uint32_t kinv = ~key, kmx = (key == 0xFFFFFFFFu) ? 0u : key;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             s4 += __shfl_xor(s4, o); s8 += __shfl_xor(s8, o); s16 += __shfl_xor(s16, o); s32 += __shfl_xor(s32, o);
             sv += __shfl_xor(sv, o); sr += __shfl_xor(sr, o);
+            kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, o)); kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o));
         }
         if ((threadIdx.x & 63) == 0) {
             uint32_t* q = s_part[threadIdx.x >> 6];
-            q[0] = s4; q[1] = s8; q[2] = s16; q[3] = s32; q[4] = sv; q[5] = sr;
+            q[0] = s4; q[1] = s8; q[2] = s16; q[3] = s32; q[4] = sv; q[5] = sr; q[6] = kinv; q[7] = kmx;
         }
         __syncthreads();
+        if (threadIdx.x == 6 || threadIdx.x == 7) {
+            const int c = threadIdx.x;
+            const uint32_t m = max(max(s_part[0][c], s_part[1][c]), max(s_part[2][c], s_part[3][c]));
+            if (m) atomicMax(a.key_span + 2 * (size_t)(blockIdx.x % LG_INST_SLOTS) + (c - 6), m);
+        }
         if (threadIdx.x < 6) {
             const uint32_t sum = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
             const size_t slot = (size_t)(blockIdx.x % LG_INST_SLOTS);
@@ -385,6 +394,7 @@ void launch_preprocess(const PreprocessParams& pp, const float* means3D, const f
     a.gacc = reinterpret_cast<float4*>(g.gacc);
     a.inst_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_SLOT_WORD);
     a.diag_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_DIAG_WORD);
+    a.key_span = g.totals + LG_TOTALS_KEYSPAN_WORD;
     const dim3 grid((pp.P + 255) / 256), block(256);
     if (filter_only) hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, a);
