@@ -128,7 +128,7 @@ thread_local HostRead t_host_read;
 //   round of 5 segments (cfg3 0.99 -> 0.93 ms).  Frames with plenty of segments (8 M Gaussians at 128x4096) lose 10 % that way
 //   and keep 128 / 33 / 3.  The surfel blend does twice the arithmetic per entry and sits in between: 96 / 45 / 6.
 //   LIDARGS_SEG_LEN, LIDARGS_MAX_SEGMENTS, LIDARGS_ROUNDS ("3,9") override.
-SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
+SegPlan plan_segments(size_t R, int waves_per_tile, int surfel, size_t patches = 0) {
     static const int env_len = [] { const char* e = getenv("LIDARGS_SEG_LEN"); return e ? std::max(64, atoi(e)) : 0; }();
     static const int env_max = [] { const char* e = getenv("LIDARGS_MAX_SEGMENTS"); return e ? std::min(63, std::max(1, atoi(e))) | 1 : 0; }();
     static int env_rounds[8];
@@ -166,7 +166,10 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel) {
     // (0.195 -> 0.252 ms) the few long unsaturated lists, walked round after round by one workgroup, are a tail the multi-launch
     // form does not have.  The two forms produce bit-identical images.  LIDARGS_FUSED = 0 / 1 forces one of them.
     { static const int env_fused = [] { const char* e = getenv("LIDARGS_FUSED"); return e ? atoi(e) : -1; }();
-      p.fused = (fine && !surfel && R <= (size_t)1000000) ? 1 : 0;
+      // ... and short lists (<= 600 instances per patch the launch covers on average): a column wedge of a sharded frame has few
+      // instances but the single-GPU frame's long lists, and its 300-odd patches leave nothing to hide the long ones' rounds behind
+      // (8 wedges of the 2 M frame: kernel stages 0.41 -> 0.47 ms per rank with the fused form, r03 replay)
+      p.fused = (fine && !surfel && R <= (size_t)1000000 && (patches == 0 || R <= 600 * patches)) ? 1 : 0;
       if (env_fused >= 0 && !surfel) p.fused = env_fused ? 1 : 0; }
     if (env_len) p.seg_len = env_len;
     if (env_max) p.max_segments = env_max;
@@ -453,7 +456,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     const int rendered = encode_rendered(R, TH);
     const size_t Rp = rendered_capacity(rendered);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
+    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0, (size_t)grid.window_patches());
     const int S = lg::choose_segments(Rp, plan.max_segments);
     char* bin_p = binning_alloc(binning_user, lg::bin_carve(nullptr, Rp, patches, grid.waves_per_tile, S, nullptr));
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
@@ -547,7 +550,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
         grid.x_lo = col_lo / LG_TILE_W; grid.x_n = (col_hi + LG_TILE_W - 1) / LG_TILE_W - grid.x_lo;
     }
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
+    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0, (size_t)grid.window_patches());
     const int S = lg::choose_segments(Rp, plan.max_segments);
     lg::BinView bin; lg::bin_carve(binning_buffer, Rp, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
@@ -785,7 +788,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     const size_t Rp = rendered_capacity(R);
     const lg::TileGrid grid = lg::make_grid(width, height, TH);
     const size_t patches = (size_t)grid.num_tiles() * grid.waves_per_tile;
-    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0);
+    const lg::SegPlan plan = plan_segments(Rp, grid.waves_per_tile, 0, (size_t)grid.window_patches());
     const int S = lg::choose_segments(Rp, plan.max_segments);
     lg::BinView bin; lg::bin_carve(binning_buffer, Rp, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
