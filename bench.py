@@ -113,7 +113,7 @@ def reference_dataflow_bytes(P, V, R_ref, N, T):
     return fwd, bwd, 68 * R_ref + 24 * N, 68 * R_ref + 24 * N + 84 * V
 
 
-def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
+def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None, tile_key_bytes=2):
     """ALGORITHMIC bytes of each launch in ITS OWN units: R = the instances this frame binned (R'),
     V = visible Gaussians, N = pixels.  rec = bytes gathered per list entry (id 4 + record 64/80 + row span 4), pix = per-pixel
     planes.  `stage` = the lidargs_profile stage that brackets the launch(es); `launches` = launches inside that stage.
@@ -126,6 +126,7 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
     pix_f = 56 if surfel else 24                                # surfel: 2 + 7 output planes, 3 accum planes, 2 count planes
     acc = 128 if surfel else 84                                 # per visible Gaussian: the raster-gradient line the backward blend fills
     pin = 40 if surfel else 44
+    kb = tile_key_bytes                                         # 2 when the frame has <= 65536 tiles (every BASELINE size), else 4
     t = [
         dict(kernel="k_sf_preprocess" if surfel else "k_preprocess", stage="preprocess", launches=1, bound="hbm",
              bytes=(pin + 36 + (128 if surfel else 64)) * P + (88 if surfel else 76) * V,
@@ -135,12 +136,12 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None):
              units="per pass 4 B key read by the histogram + 8 B pair read + 8 B pair written per Gaussian (priced at 4 passes), + the span gather of the last one"),
         dict(kernel="span block sums + scan of the block sums (+ the 2-KB totals read-back)", stage="scan+readback", launches=2, bound="hbm", bytes=4 * P,
              units="4 B span record per Gaussian read in range order"),
-        dict(kernel="k_emit_instances", stage="emit", launches=1, bound="hbm", bytes=8 * P + 8 * R,
-             units="4 B span + 4 B id per Gaussian in, 4 B tile key + 4 B id per instance out"),
-        dict(kernel="tile sort of the instances (hist + prefix + scatter per pass)", stage="tile_bin", launches="3 per pass", bound="hbm", bytes=2 * 20 * R,
-             units="2 passes x (4 B key read by the histogram + 8 B pair read + 8 B pair written) per instance"),
-        dict(kernel="k_tile_ranges", stage="ranges", launches=1, bound="hbm", bytes=4 * R + 8 * max(1, N // 64),
-             units="4 B tile key per instance in, 8 B range per tile out"),
+        dict(kernel="k_emit_instances", stage="emit", launches=1, bound="hbm", bytes=8 * P + (kb + 4) * R,
+             units=f"4 B span + 4 B id per Gaussian in, {kb} B tile key + 4 B id per instance out"),
+        dict(kernel="tile sort of the instances (hist + prefix + scatter per pass)", stage="tile_bin", launches="3 per pass", bound="hbm", bytes=2 * (3 * kb + 8) * R,
+             units=f"2 passes x ({kb} B key read by the histogram + {kb + 4} B pair read + {kb + 4} B pair written) per instance"),
+        dict(kernel="k_tile_ranges", stage="ranges", launches=1, bound="hbm", bytes=kb * R + 8 * max(1, N // 64),
+             units=f"{kb} B tile key per instance in, 8 B range per tile out"),
         dict(kernel="forward blend group (reference K7): T-only walks + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
              launches="4-7 by plan", bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
@@ -472,7 +473,9 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
                  "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"],
                  "forward blend group (reference K7): T-only walks + alive + full walk + combine":
-                     {"any_of": ["lg::k_sf_render_forward<", "lg::k_sf_alive", "lg::k_sf_combine"], "per_frame": "k_sf_combine"}}
+                     {"any_of": ["lg::k_sf_render_forward<", "lg::k_sf_alive", "lg::k_sf_combine"], "per_frame": "k_sf_combine"},
+                 "k_emit_instances": ["lg::k_emit_instances"], "k_tile_ranges": ["lg::k_tile_ranges"]}
+    pmc_names.update({k: dict(v, per_frame="k_sf_preprocess") for k, v in sort_pmc_groups(((W + 15) // 16) * ((H + 3) // 4)).items()})
     out = {
         "metric": "LiDAR range-view frames/sec (fwd+bwd)", "value": args.steps / elapsed, "unit": "frames/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -1153,7 +1156,7 @@ def main():
                         "note": "SURVEY 8d formula on R_ref (16x1 instances the reference would bin) / our frame time: above the 8000 GB/s "
                                 "peak means the frame is faster than that data flow could be at HBM speed; NOT a roofline fraction"}
             pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
-                         "k_gaussian_backward": ["lg::k_gaussian_backward"], "k_emit_instances": ["lg::k_emit_instances<true>"],
+                         "k_gaussian_backward": ["lg::k_gaussian_backward"], "k_emit_instances": ["lg::k_emit_instances"],
                          "k_tile_ranges": ["lg::k_tile_ranges"],
                          "forward blend group (reference K7): T-only walks + alive + full walk + combine":
                              {"any_of": ["lg::k_render_forward<", "lg::k_render_pass2_grouped", "lg::k_render_alive", "lg::k_render_combine", "lg::k_render_fused"],

@@ -377,13 +377,17 @@ int lidargs_shell_scatter_radii(int M, const int* idx, const int* radii_shell, i
  * scales is f32[2P] (vec2 per surfel, the reference reads the tensor with a row stride of 2 floats,
  * R2/cr/rasterizer_impl.cu:256).  out_others f32[7*H*W] = depth, alpha, normal xyz, median depth, distortion
  * (R2/cr/auxiliary.h:23-27).  `pixels` f32[P] is accepted and never written (neither does the reference:
- * the atomicAdd is commented out, R2/cr/forward.cu:522).  transMat_precomp must be NULL (the reference's
- * backward rejects it, R2/cr/backward.cu:655-658).  Backward outputs (written for all P rows): dL_dmean2D f32[4P],
+ * the atomicAdd is commented out, R2/cr/forward.cu:522).  transMat_precomp f32[9P] (rows Tu, Tv, Tw per surfel) may be given NEXT TO
+ * scales and rotations, as in the reference: the preprocess builds its own rows from scales / rotations whatever is passed (rect,
+ * normal, sort depth, pixel centre: R2/cr/forward.cu:271-325) and the blends -- forward and backward -- read the precomputed rows
+ * (R2/cr/rasterizer_impl.cu:332, :408); pass the same pointer to the backward.  Without scales / rotations it is refused
+ * (LIDARGS_ERR_INVALID_ARGUMENT; the reference reads an empty tensor there and its backward prints "Ts_precomp error",
+ * R2/cr/backward.cu:661-664).  Backward outputs (written for all P rows): dL_dmean2D f32[4P],
  * dL_dnormal f32[3P], dL_dopacity f32[P], dL_dcolor f32[2P], dL_dmean3D f32[3P], dL_dtransMat f32[9P],
  * dL_dtransMat_2dtemp f32[3P], dL_dscale f32[2P], dL_drot f32[4P], depth f32[P]; dL_depths is the gradient of
  * all 7 planes of out_others.  dL_dnormal, dL_dtransMat and dL_dtransMat_2dtemp are intermediates of the reference's
- * two-kernel backward (transMat_precomp being rejected, nobody receives dL_dtransMat): each may be NULL, in which case it
- * is not materialised (60 bytes per surfel less to write). */
+ * two-kernel backward (dL_dtransMat is also the gradient of transMat_precomp when that was given): each may be NULL, in which case
+ * it is not materialised (60 bytes per surfel less to write). */
 int lidargs_surfel_forward(
     lidargs_alloc_fn geometry_alloc, void* geometry_user,
     lidargs_alloc_fn binning_alloc, void* binning_user,

@@ -462,23 +462,27 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (!bin_p) return fail(LIDARGS_ERR_ALLOC, "binning allocator returned NULL%s");
     lg::BinView bin; lg::bin_carve(bin_p, Rp, patches, grid.waves_per_tile, S, &bin);
 
-    // 3. emit instances in range order, bin them by tile (stable)
+    // 3. emit instances in range order, bin them by tile (stable); 16-bit tile keys whenever the tile ids fit (LIDARGS_TILE_KEY32=1: A/B)
+    static const bool key32 = [] { const char* e = getenv("LIDARGS_TILE_KEY32"); return e && atoi(e) != 0; }();
+    const bool key16 = grid.num_tiles() <= 65536 && !key32;
     const uint32_t* point_list = bin.val_a;
     if (R) {
         lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, pp.compact != 0, (size_t)P, grid,
-                                  bin.tile_a, bin.val_a, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu);
+                                  bin.tile_a, bin.val_a, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
         const int bits = ceil_log2((uint32_t)grid.num_tiles());
-        const int bside = lg::launch_radix_sort_pairs(bin.tile_a, bin.tile_b, bin.val_a, bin.val_b, R, bits, bin.scratch, stream, 0, R_dev);
+        const int bside = key16 ? lg::launch_radix_sort_pairs16(reinterpret_cast<uint16_t*>(bin.tile_a), reinterpret_cast<uint16_t*>(bin.tile_b), bin.val_a, bin.val_b, R,
+                                                                bits, bin.scratch, stream, R_dev)
+                                : lg::launch_radix_sort_pairs(bin.tile_a, bin.tile_b, bin.val_a, bin.val_b, R, bits, bin.scratch, stream, 0, R_dev);
         if (bside) {   // keep the backward's view independent of the pass count: result always in (tile_a, val_a)
-            LG_HIP(hipMemcpyAsync(bin.tile_a, bin.tile_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            LG_HIP(hipMemcpyAsync(bin.tile_a, bin.tile_b, R * (key16 ? sizeof(uint16_t) : sizeof(uint32_t)), hipMemcpyDeviceToDevice, stream));
             LG_HIP(hipMemcpyAsync(bin.val_a, bin.val_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
         }
         LG_STAGE_CHECK("tile bin");
         g_prof.mark("tile_bin", stream);
     }
-    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev);
+    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev, key16);
     LG_STAGE_CHECK("tile ranges");
     g_prof.mark("ranges", stream);
 

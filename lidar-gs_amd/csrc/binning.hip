@@ -121,8 +121,8 @@ struct KeyMap {
 };
 static inline KeyMap key_map(const KeyBias* b) { KeyMap m; m.on = b != nullptr; m.kmin = b ? b->kmin : 0u; m.cull = b ? b->cull : 0xFFFFFFFFu; return m; }
 
-template <int BITS, int ITEMS>
-__global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev, int shift,
+template <int BITS, int ITEMS, typename KT = uint32_t>
+__global__ void __launch_bounds__(256) k_radix_hist(const KT* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev, int shift,
                                                     uint32_t* __restrict__ hist, unsigned nblocks, const KeyMap km) {
     constexpr int BINS = 1 << BITS;
     if (n_dev) n = min(n, (size_t)*n_dev);
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_radix_hist(const uint32_t* __restrict__
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
-        k[r] = i < n ? keys[i] : 0u;
+        k[r] = i < n ? (uint32_t)keys[i] : 0u;
     }
     for (int d = tid; d < BINS; d += 256) cnt[d] = 0;
     __syncthreads();
@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(256) k_radix_chunk_prefix(uint32_t* __restrict
     if (lane == 0) tot[d] = carry;
 }
 
-template <int BITS, int ITEMS>
-__global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+template <int BITS, int ITEMS, typename KT = uint32_t>
+__global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                       KT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        size_t n, const uint32_t* __restrict__ n_dev, int shift, const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
                                                        const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks, const RadixTail tail,
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
     for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
         const bool valid = i < n;
-        k[r] = valid ? keys_in[i] : 0u;
+        k[r] = valid ? (uint32_t)keys_in[i] : 0u;
         v[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;    // vals_in == nullptr: the values are the positions (first pass of an id sort)
     }
     // global digit bases: exclusive scan of the digit totals (every block repeats this tiny scan)
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
             const uint32_t kk = s_key[i];
             const uint32_t d = (km(kk) >> shift) & (BINS - 1);
             const size_t g = (size_t)gbase[d] + (i - dbase[d]);
-            keys_out[g] = kk; vals_out[g] = s_val[i];
+            keys_out[g] = (KT)kk; vals_out[g] = s_val[i];
         }
     } else {
         // last pass with a tail: the sorted keys are not written; the record of every value is gathered (all of a thread's gathers
@@ -367,8 +367,8 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const uint32_t* __restric
 // Keys per sort block: 4096 (16 per lane), or 2048 for inputs up to 4 M pairs when the scratch has room for twice the blocks -- at
 // 2 M keys 489 blocks of 4 waves leave half of the 1024 SIMDs without a wave, and each block's load -> rank -> park -> stream-out
 // chain is the launch's length.
-template <int BITS, int ITEMS>
-static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
+template <int BITS, int ITEMS, typename KT>
+static void radix_pass_items(const KT* kin, const uint32_t* vin, KT* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
                              uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail, const KeyBias* bias) {
     const size_t cap_bins = (size_t)1 << scratch_bits;           // the scratch layout of sort_scratch_words(n, scratch_bits)
     constexpr size_t CHUNK = 256 * ITEMS;
@@ -380,7 +380,7 @@ static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t*
     const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
     const bool two_level = chunks_all > 2;
     const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
-    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb, key_map(bias));
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS, KT>), dim3(nb), dim3(256), 0, s, kin, n, n_dev, shift, hist, nb, key_map(bias));
     // single level: the chunk sums ARE the digit totals, written straight to `tot`
     const dim3 pgrid(BINS * chunks);
     uint32_t* const pout = two_level ? part : tot;
@@ -388,7 +388,7 @@ static void radix_pass_items(const uint32_t* kin, const uint32_t* vin, uint32_t*
     else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<4>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     else hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
-    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS, KT>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
                        two_level ? part : (const uint32_t*)nullptr, chunk, chunks, tail, key_map(bias));
 }
 // ------------------------------------------------------------------------------------------------
@@ -404,7 +404,10 @@ constexpr int SMALL_SORT_ROUNDS = 16;                                  // rounds
 constexpr size_t SMALL_SORT_MAX = (size_t)SMALL_SORT_WAVES * SMALL_SORT_ROUNDS * 64;   // 16384 pairs
 __device__ __forceinline__ uint32_t load_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n,
+template <typename KT>
+__device__ __forceinline__ uint32_t load_key_l2(const KT* p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <typename KT = uint32_t>
+__global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n,
                                                                             const uint32_t* __restrict__ n_dev, int begin_bit, int end_bit, int max_bits,
                                                                             int vals_are_positions, const RadixTail tail, const KeyMap km) {
     constexpr int W = SMALL_SORT_WAVES, MAXB = 8, BINS = 1 << MAXB;
@@ -422,8 +425,8 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(uint
         const int bits = (left + passes_left - 1) / passes_left;
         const uint32_t mask = (1u << bits) - 1u;
         const bool last = shift + bits >= end_bit;
-        const uint32_t* kin = cur ? key_b : key_a; const uint32_t* vin = cur ? val_b : val_a;
-        uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
+        const KT* kin = cur ? key_b : key_a; const uint32_t* vin = cur ? val_b : val_a;
+        KT* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
         const bool positions = shift == 0 && vals_are_positions;
         for (int i = tid; i < BINS * (W + 1); i += 64 * W) (&cnt[0][0])[i] = 0u;
         __syncthreads();
@@ -433,7 +436,7 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(uint
 #pragma unroll
         for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
             const uint32_t i = lo + (uint32_t)r * 64u + lane;
-            kreg[r] = i < hi ? load_l2(kin + i) : 0u;
+            kreg[r] = i < hi ? load_key_l2(kin + i) : 0u;
             vreg[r] = i < hi ? (positions ? i : load_l2(vin + i)) : 0u;
         }
         // 1. per-(digit, wave) counts (one wave owns its column: plain LDS read-modify-writes in program order, through the peers' leader)
@@ -505,7 +508,7 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(uint
                     if (tail.mode == 1) static_cast<uint32_t*>(tail.dst)[pos] = static_cast<const uint32_t*>(tail.src)[v];
                     else { const uint4 sp = static_cast<const uint4*>(tail.src)[v]; static_cast<uint2*>(tail.dst)[pos] = make_uint2(sp.y, sp.x); }
                 } else {
-                    kout[pos] = k; vout[pos] = v;
+                    kout[pos] = (KT)k; vout[pos] = v;
                 }
             }
         }
@@ -516,19 +519,20 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(uint
     }
 }
 
-template <int BITS>
-static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
+template <int BITS, typename KT>
+static void radix_pass(const KT* kin, const uint32_t* vin, KT* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
                        uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail, const KeyBias* bias) {
     static const int env = [] { const char* e = getenv("LIDARGS_SORT_ITEMS"); return e ? atoi(e) : 0; }();   // 8 / 16 forces the block size
     const bool room = BITS + 1 <= scratch_bits;                  // twice the blocks x BINS <= the histogram area (and the chunk sums likewise)
     const bool half = room && (env ? env == 8 : n <= ((size_t)4 << 20));
     if constexpr (BITS <= 10) {
-        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias); return; }
+        if (half) { radix_pass_items<BITS, SORT_ITEMS / 2, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias); return; }
     }
-    radix_pass_items<BITS, SORT_ITEMS>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias);
+    radix_pass_items<BITS, SORT_ITEMS, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias);
 }
 
-int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
+template <typename KT>
+static int radix_sort_pairs_t(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions,
                             RadixTail tail, int begin_bit, const KeyBias* bias) {
     if (n == 0 || end_bit <= begin_bit) return 0;
@@ -538,7 +542,7 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
         const int mb = max_bits > 8 ? 8 : max_bits;
         int passes = 0;
         for (int sh = begin_bit; sh < end_bit;) { const int left = end_bit - sh, pl = (left + mb - 1) / mb; sh += (left + pl - 1) / pl; passes++; }
-        hipLaunchKernelGGL(k_radix_sort_small, dim3(1), dim3(64 * SMALL_SORT_WAVES), 0, s, key_a, key_b, val_a, val_b, (uint32_t)n, n_dev, begin_bit, end_bit,
+        hipLaunchKernelGGL(k_radix_sort_small<KT>, dim3(1), dim3(64 * SMALL_SORT_WAVES), 0, s, key_a, key_b, val_a, val_b, (uint32_t)n, n_dev, begin_bit, end_bit,
                            mb, vals_are_positions ? 1 : 0, tail, key_map(bias));
         return passes & 1;
     }
@@ -547,31 +551,43 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
     int shift = begin_bit;
     while (shift < end_bit) {
         const int left = end_bit - shift;
-        uint32_t* kin = cur ? key_b : key_a; uint32_t* vin = cur ? val_b : val_a;
+        KT* kin = cur ? key_b : key_a; uint32_t* vin = cur ? val_b : val_a;
         if (shift == 0 && vals_are_positions) vin = nullptr;              // val_a is not read (and need not have been written)
         const RadixTail none;
-        uint32_t* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
+        KT* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
         // split the remaining bits evenly over the remaining passes (e.g. 12 bits -> 6+6, not 8+4; 31 bits at 11 -> 11+10+10)
         const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
         const bool last = shift + bits >= end_bit;                       // the tail (a gather by the sorted values) rides on the last pass
         switch (bits) {
-            case 1: radix_pass<1>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 2: radix_pass<2>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 3: radix_pass<3>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 4: radix_pass<4>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 5: radix_pass<5>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 6: radix_pass<6>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 7: radix_pass<7>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 8: radix_pass<8>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 9: radix_pass<9>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            case 10: radix_pass<10>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
-            default: radix_pass<11>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 1: radix_pass<1, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 2: radix_pass<2, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 3: radix_pass<3, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 4: radix_pass<4, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 5: radix_pass<5, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 6: radix_pass<6, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 7: radix_pass<7, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 8: radix_pass<8, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 9: if constexpr (sizeof(KT) == 2) { break; } else radix_pass<9, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            case 10: if constexpr (sizeof(KT) == 2) { break; } else radix_pass<10, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
+            default: if constexpr (sizeof(KT) == 2) { break; } else radix_pass<11, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, last ? tail : none, bias); break;
         }
         shift += bits;
         cur ^= 1;
     }
     return cur;
+}
+
+int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
+                            uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions,
+                            RadixTail tail, int begin_bit, const KeyBias* bias) {
+    return radix_sort_pairs_t<uint32_t>(key_a, key_b, val_a, val_b, n, end_bit, scratch, s, max_bits, n_dev, scratch_bits, vals_are_positions, tail, begin_bit, bias);
+}
+// 16-bit keys (the tile sort whenever the image has at most 65536 list tiles): 6 instead of 8 bytes per pair moved by a pass, 2 instead
+// of 4 read by its histogram.  Digits of at most 8 bits.
+int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit, uint32_t* scratch, hipStream_t s,
+                              const uint32_t* n_dev) {
+    return radix_sort_pairs_t<uint16_t>(key_a, key_b, val_a, val_b, n, end_bit, scratch, s, SORT_RADIX_BITS, n_dev, 0, false, RadixTail(), 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,10 +638,10 @@ void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint
 // instances cooperatively, 64 consecutive output slots per step (coalesced 256-B stores),
 // instead of one thread looping over its own rect (the reference's duplicateWithKeys,
 // R3/cr/rasterizer_impl.cu:70-112, whose per-thread trip count varies 1..100s).
-template <bool COMPACT>
+template <bool COMPACT, typename KT = uint32_t>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ block_off,
                                                                const void* __restrict__ span_sorted_, size_t P, int th_shift, int tiles_x,
-                                                               uint32_t* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap) {
+                                                               KT* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap) {
     __shared__ uint32_t s_tot[SCAN_BLOCK / 64];                        // instance count of each wave's 64 Gaussians
     __shared__ uint32_t s_own[SCAN_BLOCK / 64][64];                    // per wave: the lane whose instances start at each slot of the window
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -683,16 +699,24 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
                 ry = jj / o_nx;
             }
             const uint32_t rx = jj - ry * o_nx;
-            inst_tile[(size_t)wave_base + t] = (o_ty0 + ry) * (uint32_t)tiles_x + o_x0 + rx;
+            inst_tile[(size_t)wave_base + t] = (KT)((o_ty0 + ry) * (uint32_t)tiles_x + o_x0 + rx);
             inst_val[(size_t)wave_base + t] = o_g;
         }
     }
 }
 
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
-                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap) {
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap, bool key16) {
     int sh = 0;
     while ((1 << sh) < grid.TH) sh++;
+    if (key16) {
+        uint16_t* t16 = reinterpret_cast<uint16_t*>(inst_tile);
+        if (compact) hipLaunchKernelGGL((k_emit_instances<true, uint16_t>), dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
+                                        P, sh, grid.tiles_x, t16, inst_val, cap);
+        else hipLaunchKernelGGL((k_emit_instances<false, uint16_t>), dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
+                                P, sh, grid.tiles_x, t16, inst_val, cap);
+        return;
+    }
     if (compact) hipLaunchKernelGGL(k_emit_instances<true>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
                                     P, sh, grid.tiles_x, inst_tile, inst_val, cap);
     else hipLaunchKernelGGL(k_emit_instances<false>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
@@ -702,7 +726,8 @@ void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles
 // without instances read (0, 0); here the thread at a boundary writes the empty ranges of the tiles it skips over (and the
 // first / last thread those before the first / behind the last key): every entry is written, no separate fill launch.
-__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ tile_sorted, size_t R, const uint32_t* __restrict__ R_dev,
+template <typename KT = uint32_t>
+__global__ void __launch_bounds__(256) k_tile_ranges(const KT* __restrict__ tile_sorted, size_t R, const uint32_t* __restrict__ R_dev,
                                                      uint2* __restrict__ ranges, uint32_t tiles) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (R_dev) R = min(R, (size_t)*R_dev);                             // enqueue-only forward: the count lives on the device
@@ -728,8 +753,10 @@ __global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict_
     }
 }
 
-void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev) {
-    if (R) hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, R_dev, ranges, (uint32_t)tiles);
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev, bool key16) {
+    if (R && key16) hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(tile_sorted), R, R_dev,
+                                       ranges, (uint32_t)tiles);
+    else if (R) hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, R_dev, ranges, (uint32_t)tiles);
     else hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
 }
 

@@ -88,6 +88,8 @@ struct SfPreArgs {
     float scale_modifier, near_f, far_f, col_step;
     const float* view;
     const float* means3D; const float* scales; const float* rotations; const float* opacities; const float* colors; const float* beams;
+    const float* transMat; // transMat_precomp or nullptr: the rows (Tu, Tv, Tw) the BLEND uses (the rect, the normal, the sort depth and the
+                           // pixel centre still come from scales / rotations / means3D: R2/cr/rasterizer_impl.cu:332 vs forward.cu:271-325)
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
     uint32_t* dirty;       // the geometry buffer's "gradient lines hold sums" word (LG_TOTALS_DIRTY_WORD): cleared here
@@ -166,16 +168,24 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         rspan = (uint32_t)ymin | ((uint32_t)ymax << 16);
         xsp = (uint32_t)xmin | ((uint32_t)xmax << 16);
         key = __float_as_uint(dist);
-        const float uu = sdot(Tu, Tu), vv = sdot(Tv, Tv);
+        float3 Bu = Tu, Bv = Tv, Bw = pv;                                 // the blend's rows
+        float bw_len = dist;
+        if (a.transMat) {
+            const float* t = a.transMat + 9 * (size_t)idx;
+            Bu = sf3(t[0], t[1], t[2]); Bv = sf3(t[3], t[4], t[5]); Bw = sf3(t[6], t[7], t[8]);
+            bw_len = sqrtf(Bw.x * Bw.x + Bw.y * Bw.y + Bw.z * Bw.z);
+        }
+        const float uu = sdot(Bu, Bu), vv = sdot(Bv, Bv);
         const float iu = uu > 0.f ? 1.f / uu : 0.f, iv = vv > 0.f ? 1.f / vv : 0.f;
         // (Tu', Tv') interleaved by component: the blend evaluates s = (dp.Tu', dp.Tv') and its gradients as packed-fp32 pairs
-        r0 = make_float4(Tu.x * iu, Tv.x * iv, Tu.y * iu, Tv.y * iv);
-        r1 = make_float4(Tu.z * iu, Tv.z * iv, a.opacities[idx], a.colors[2 * idx]);
-        r2 = make_float4(pv.x, pv.y, pv.z, a.colors[2 * idx + 1]);
+        r0 = make_float4(Bu.x * iu, Bv.x * iv, Bu.y * iu, Bv.y * iv);
+        r1 = make_float4(Bu.z * iu, Bv.z * iv, a.opacities[idx], a.colors[2 * idx]);
+        r2 = make_float4(Bw.x, Bw.y, Bw.z, a.colors[2 * idx + 1]);
         // lambda = |Tw| * cos(phi1) with cos(phi1) = (Tw.n)/|Tw|, rounded in the reference's order (:449-452): the hit
         // point lam2 * p - Tw cancels ~3 digits, so a 1-ulp change of lambda is a 1e-4 change of the Gaussian weight
-        r3 = make_float4(n.x, n.y, n.z, dist * ((pv.x * n.x + pv.y * n.y + pv.z * n.z) / dist));
-        r4 = make_float4(pim.x, pim.y, dist, pv.x * n.x + pv.y * n.y + pv.z * n.z);
+        const float wn = Bw.x * n.x + Bw.y * n.y + Bw.z * n.z;
+        r3 = make_float4(n.x, n.y, n.z, bw_len * (wn / bw_len));
+        r4 = make_float4(pim.x, pim.y, bw_len, wn);
     } while (false);
 
     if (in_range) {
@@ -770,6 +780,7 @@ void launch_sf_render_backward(const SfBwdArgs& a, hipStream_t s) {
 struct SfGaussBwdArgs {
     int P, W, H;
     const float* view; const float* means3D; const float* scales; const float* rotations; const float* beams; const int* radii;
+    const float* transMat;             // transMat_precomp or nullptr: the Tw the blend's backward saw (the per-pair terms reconstructed below)
     const float* gacc; uint32_t* dirty;
     float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D; float* dL_dtransMat;
     float* dL_dtransMat_2dtemp; float* dL_dscale; float* dL_drot; float* depth;
@@ -794,8 +805,11 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const float* vm = a.view;
     const float* g = a.gacc + 32 * (size_t)idx;
     const float3 pw = sf3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-    const float3 Tw = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
+    const float3 pv = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
                           vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
+    // the per-pair terms folded into per-surfel coefficients below were evaluated with the blend's Tw (R2/cr/backward.cu:267); the
+    // chain through scales / rotations / means3D that follows uses p_view whatever the blend used (:625-690, Ts_precomp == nullptr)
+    const float3 Tw = a.transMat ? sf3(a.transMat[9 * (size_t)idx + 6], a.transMat[9 * (size_t)idx + 7], a.transMat[9 * (size_t)idx + 8]) : pv;
     const float rho_r = sqrtf(sdot(Tw, Tw));
     const float rxy = sqrtf(Tw.x * Tw.x + Tw.y * Tw.y);
     const float pi_f = 3.14159265358979323846f;
@@ -844,9 +858,9 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const float3 dL0 = sf_rot_world(vm, gTu), dL1 = sf_rot_world(vm, gTv), dLp = sf_rot_world(vm, gTw);
     float3 dtn = sf_rot_world(vm, gn);
     const float3 nv = sf_rot_view(vm, c2);
-    const float cs = -(Tw.x * nv.x + Tw.y * nv.y + Tw.z * nv.z);
+    const float cs = -(pv.x * nv.x + pv.y * nv.y + pv.z * nv.z);
     if (!(cs > 0.f)) { dtn.x = -dtn.x; dtn.y = -dtn.y; dtn.z = -dtn.z; }
-    a.depth[idx] = sqrtf(Tw.x * Tw.x + Tw.z * Tw.z);                   // :670 (x,z only, as the reference)
+    a.depth[idx] = sqrtf(pv.x * pv.x + pv.z * pv.z);                   // :670 (x,z only, as the reference)
     const float s0 = a.scales[2 * idx], s1 = a.scales[2 * idx + 1];   // the backward ignores scale_modifier (:632)
     a.dL_dscale[2 * idx] = sdot(dL0, c0);
     a.dL_dscale[2 * idx + 1] = sdot(dL1, c1);

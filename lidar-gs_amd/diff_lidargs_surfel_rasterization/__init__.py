@@ -4,8 +4,9 @@ Same public surface as R2/diff_lidargs_surfel_rasterization/__init__.py: `Gaussi
 (14 fields, :188-202), `GaussianRasterizer` with forward / markVisible / visible_filter (:204-273) and the
 functional `rasterize_gaussians` (:21-43).  forward returns (color[2,H,W], radii[P], others[7,H,W], pixels[P,1]);
 gradients flow to means3D, means2D (the [P,4] densification statistics), colors_precomp, opacities, scales[P,2]
-and rotations.  Spherical harmonics and precomputed transforms are not part of the LiDAR path
-(both are rejected natively).
+and rotations.  A precomputed transform (`cov3Ds_precomp` = transMat_precomp [P,9]) is honoured as the reference honours it --
+given NEXT TO scales / rotations through the functional `rasterize_gaussians`, it replaces the rows the blends use, and receives
+dL_dtransMat; spherical harmonics are not part of the LiDAR path (rejected natively).
 """
 from typing import NamedTuple
 

@@ -39,6 +39,7 @@ def lib():
         _lib.lgo_forward_ex.restype = C.c_void_p
         _lib.lgo_backward_ex.restype = C.c_int
         _lib.sfo_forward.restype = C.c_void_p
+        _lib.sfo_forward_tm.restype = C.c_void_p
         _lib.sfo_state_array.restype = C.c_void_p
         _lib.sfo_last_error.restype = C.c_char_p
         _lib.lgo_state_array.restype = C.c_void_p

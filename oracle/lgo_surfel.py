@@ -31,8 +31,10 @@ class SurfelForward:
             lib().sfo_free(C.c_void_p(self._h)); self._h = None
 
 
-def forward(means3D, colors, opacities, scales2, rotations, viewmatrix, beams, W, H, bg=None, scale_modifier=1.0, far=80, near=0):
-    """Restates R2 Rasterizer::forward (R2/cr/rasterizer_impl.cu:200-360): color[2,H,W], others[7,H,W], radii[P]."""
+def forward(means3D, colors, opacities, scales2, rotations, viewmatrix, beams, W, H, bg=None, scale_modifier=1.0, far=80, near=0,
+            transMat_precomp=None):
+    """Restates R2 Rasterizer::forward (R2/cr/rasterizer_impl.cu:200-360): color[2,H,W], others[7,H,W], radii[P].
+    transMat_precomp [P,9] (optional): the rows the blends use instead of the ones built from scales / rotations (:332, :408)."""
     means3D = _f32(means3D); colors = _f32(colors); opacities = _f32(opacities); scales2 = _f32(scales2); rotations = _f32(rotations)
     vm = _f32(viewmatrix).reshape(16); beams = _f32(beams); bg = _f32(np.zeros(2) if bg is None else bg)
     P = means3D.shape[0]
@@ -41,9 +43,10 @@ def forward(means3D, colors, opacities, scales2, rotations, viewmatrix, beams, W
                   W=W, H=H, scale_modifier=scale_modifier)
     if P == 0:
         return SurfelForward(None, color, others, radii, inputs)
-    h = lib().sfo_forward(C.c_int(P), _p(bg), C.c_int(W), C.c_int(H), _p(means3D), _p(colors), _p(opacities), _p(scales2),
-                          C.c_float(scale_modifier), _p(rotations), _p(vm), _p(beams), C.c_int(far), C.c_int(near),
-                          _p(color), _p(others), _p(radii))
+    tm = None if transMat_precomp is None else _f32(transMat_precomp).reshape(P, 9)
+    h = lib().sfo_forward_tm(C.c_int(P), _p(bg), C.c_int(W), C.c_int(H), _p(means3D), _p(colors), _p(opacities), _p(scales2),
+                             C.c_float(scale_modifier), _p(rotations), _p(tm), _p(vm), _p(beams), C.c_int(far),
+                             C.c_int(near), _p(color), _p(others), _p(radii))
     if not h:
         raise RuntimeError(lib().sfo_last_error().decode())
     return SurfelForward(h, color, others, radii, inputs)

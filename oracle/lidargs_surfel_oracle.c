@@ -311,10 +311,26 @@ static int sf_pair_geom(const sfo_state* s, uint32_t g, int x, int y, sf3 p, sf_
 
 /* Forward: R2/cr/rasterizer_impl.cu:200-360.  Outputs: out_color[2,H,W], out_others[7,H,W], radii[P]
  * (pixels[P,1] is allocated by the binding and never written: the atomicAdd is commented out, forward.cu:522). */
+/* transMat_precomp (may be NULL): the preprocess builds T from scales and rotations whatever is passed (rect, normal, depth, centre:
+ * R2/cr/forward.cu:271-325); the blend -- forward AND backward -- then reads the rows from transMat_precomp when it is there
+ * (R2/cr/rasterizer_impl.cu:332, :408).  Restated by overwriting the state's rows after the preprocess: only the blends read them. */
+void* sfo_forward_tm(int P, const float* background, int width, int height, const float* means3D, const float* colors_precomp,
+                     const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+                     const float* viewmatrix, const float* beams, int far_, int near_,
+                     float* out_color, float* out_others, int* radii);
+
 void* sfo_forward(int P, const float* background, int width, int height, const float* means3D, const float* colors_precomp,
                   const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                   const float* viewmatrix, const float* beams, int far_, int near_,
                   float* out_color, float* out_others, int* radii) {
+    return sfo_forward_tm(P, background, width, height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, NULL,
+                          viewmatrix, beams, far_, near_, out_color, out_others, radii);
+}
+
+void* sfo_forward_tm(int P, const float* background, int width, int height, const float* means3D, const float* colors_precomp,
+                     const float* opacities, const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+                     const float* viewmatrix, const float* beams, int far_, int near_,
+                     float* out_color, float* out_others, int* radii) {
     if (colors_precomp == NULL) { snprintf(sfo_err, sizeof sfo_err, "For non-RGB, provide precomputed Gaussian colors!"); return NULL; }
     const int W = width, H = height;
     const long long N = (long long)W * H;
@@ -329,6 +345,7 @@ void* sfo_forward(int P, const float* background, int width, int height, const f
     s->accum = (float*)calloc((size_t)N * 3, 4); s->n_contrib = (uint32_t*)calloc((size_t)N * 2, 4);
     for (int i = 0; i < P; i++)
         sf_preprocess_one(i, 0, s, means3D, scales, scale_modifier, rotations, opacities, viewmatrix, beams, far_, near_, radii);
+    if (transMat_precomp && P > 0) memcpy(s->transMat, transMat_precomp, sizeof(float) * 9 * (size_t)P);
     uint32_t run = 0;
     for (int i = 0; i < P; i++) { run += s->tiles_touched[i]; s->point_offsets[i] = run; }
     const long long R = P > 0 ? (long long)s->point_offsets[P - 1] : 0;

@@ -166,21 +166,36 @@ print("OK")
 @pytest.mark.parametrize("env", [{"LIDARGS_HEAD": "1"}, {"LIDARGS_HEAD": "1", "LIDARGS_ROUNDS": "2,6"}, {"LIDARGS_HEAD": "0", "LIDARGS_SEG_LEN": "128"},
                                  {"LIDARGS_P2_GROUP": "3"}, {"LIDARGS_SORT_ITEMS": "16"}, {"LIDARGS_RANGE_SORT_BITS": "11"},
                                  {"LIDARGS_FUSED": "0"}, {"LIDARGS_FUSED_WAVES": "4"}, {"LIDARGS_FUSED_WAVES": "16"},
-                                 {"LIDARGS_FUSED": "1", "LIDARGS_SEG_LEN": "128", "LIDARGS_MAX_SEGMENTS": "33"}, {"LIDARGS_FUSED": "0", "LIDARGS_HEAD": "1"}],
+                                 {"LIDARGS_FUSED": "1", "LIDARGS_SEG_LEN": "128", "LIDARGS_MAX_SEGMENTS": "33"}, {"LIDARGS_FUSED": "0", "LIDARGS_HEAD": "1"},
+                                 {"LIDARGS_TILE_KEY32": "1"}, {"LIDARGS_NO_SMALL_SORT": "1"}, {"LIDARGS_RANGE_SORT_FULL": "1"}, {}],
                          ids=["head5", "head2_rounds26", "nohead_seg128", "pass2_groups_of_3", "sort_blocks_4096", "sort_digits_11",
-                              "five_launch_forward", "fused_4_waves", "fused_16_waves", "fused_on_128_entry_segments", "unfused_head"])
+                              "five_launch_forward", "fused_4_waves", "fused_16_waves", "fused_on_128_entry_segments", "unfused_head",
+                              "tile_keys_32_bit", "no_single_launch_sort", "range_sort_all_31_bits", "defaults"])
 def test_plan_variants_are_invisible(env, hip_lib_built):
     """The segment plan is an internal choice too: round 1 as the complete walk of the list heads (what the big frames take by default:
     k_render_pass2_grouped<true>, here forced onto the 64-entry plan with heads of 5 and 2 segments), pass 2 over groups of segments
     behind a head, no head on 128-entry segments, the sort's block size and digit width -- the image and the gradients must not
-    depend on any of it."""
+    depend on any of it.  Round 3: the fused one-launch forward against the five-launch form, 16- against 32-bit tile keys, the single-launch
+    small sort against the general one, the range sort on the key span against all 31 bits (the third scene is small enough for the
+    small sort and sits closer than 2 m to the sensor in places, so that the key span is not the usual 26 bits)."""
     import os, subprocess, sys
     code = r"""
 import sys, numpy as np
 sys.path[:0] = [%r, %r, %r]
 import lidargs_scenes as sc
 from util import hip_forward_backward, oracle_forward_backward, parity, GRAD_KEYS_SR
-for kind, P, H, W, seed in (("street", 60000, 32, 800, 11), ("shell", 20000, 16, 512, 12)):
+for kind, P, H, W, seed in (("street", 60000, 32, 800, 11), ("shell", 20000, 16, 512, 12), ("near", 9000, 16, 400, 13)):
+    if kind == "near":
+        scene = sc.make_scene("shell", P, H, seed, random_view=True)
+        scene["means3D"] = (scene["means3D"] * np.float32(0.08)).astype(np.float32)      # ranges 0.4 .. 4.8 m
+        scene["scales"] = (scene["scales"] * np.float32(0.1)).astype(np.float32)
+        grads = sc.upstream_grads(H, W, seed)
+        ref = oracle_forward_backward(scene, W, H, grads)
+        hip = hip_forward_backward(scene, W, H, grads)
+        assert int((hip["radii"] != ref["radii"]).sum()) <= 1
+        for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+            parity(kind + "." + k, hip[k], ref[k])
+        continue
     scene = sc.make_scene(kind, P, H, seed, random_view=True)
     grads = sc.upstream_grads(H, W, seed)
     ref = oracle_forward_backward(scene, W, H, grads)

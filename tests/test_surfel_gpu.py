@@ -124,6 +124,45 @@ def test_surfel_missing_colors_raises():
                                torch.eye(4).cuda(), t["beams"], 16, 512, e, 1, torch.zeros(3).cuda(), False, 80, 0, False)
 
 
+def test_surfel_transmat_precomp_drives_the_blend():
+    """transMat_precomp next to scales / rotations (the functional entry point): the preprocess -- rect, normal, sort depth, pixel
+    centre -- still runs on scales / rotations, the blend (forward and backward) on the precomputed rows
+    (R2/cr/rasterizer_impl.cu:332, :408), and the rows' own gradient is dL_dtransMat (R2/__init__.py:74-86)."""
+    from oracle import lgo_surfel
+    W, H, seed = 512, 16, 11
+    scene = surfel_scene("shell", 3000, H, seed)
+    plain = lgo_surfel.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
+                               scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"])
+    tm = plain.array("transMat").reshape(-1, 9).copy()
+    # the rows the preprocess would have built, unchanged: nothing may move
+    same = dict(scene); same["transMat"] = tm
+    h_same = hip_surfel_forward_backward(same, W, H, None)
+    h_plain = hip_surfel_forward_backward(scene, W, H, None)
+    live = h_plain["radii"] > 0
+    assert np.array_equal(h_same["radii"], h_plain["radii"])
+    # (rows of culled surfels are zero in the oracle's state and never read; the live rows are the preprocess's own up to fp32 rounding)
+    parity("color (identity rows)", h_same["color"], h_plain["color"])
+    # perturbed rows: axes scaled and tilted, centres moved by a few per cent
+    rng = np.random.default_rng(seed)
+    tm2 = (tm * (1.0 + 0.05 * rng.normal(size=tm.shape)) + 0.01 * rng.normal(size=tm.shape) * live[:, None]).astype(np.float32)
+    pert = dict(scene); pert["transMat"] = tm2
+    hip, ref = _check(pert, W, H, seed)
+    assert np.array_equal(hip["radii"], h_plain["radii"])               # the rect does not look at the rows
+    assert np.abs(hip["color"] - h_plain["color"]).max() > 1e-3         # ... and the image does
+    parity("dL_dtransMat", hip["dL_dtransMat"], ref["dL_dtransMat"])
+
+
+def test_surfel_transmat_precomp_alone_is_refused():
+    import torch
+    from diff_lidargs_surfel_rasterization import _C
+    sc = surfel_scene("shell", 100, 16, 1)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sc.items()}
+    e = torch.empty(0, device="cuda")
+    with pytest.raises(RuntimeError, match="without scales and rotations"):
+        _C.rasterize_gaussians(t["bg"], t["means3D"], t["colors"], t["opacities"], e, e, 1.0, torch.zeros((100, 9), device="cuda"),
+                               t["viewmatrix"], torch.eye(4).cuda(), t["beams"], 16, 512, e, 1, torch.zeros(3).cuda(), False, 80, 0, False)
+
+
 def test_surfel_config5_fullsize_properties():
     """BASELINE config 5 at full size (2 M surfels, 64 x 2650): size-independent properties of the blend."""
     import torch

@@ -91,6 +91,31 @@ def test_backward_matches_finite_differences():
     assert checked == 24
 
 
+def test_transmat_precomp_replaces_the_blend_rows(shell):
+    """transMat_precomp (R2/cr/rasterizer_impl.cu:332, :408): the rows the preprocess builds, handed back in, change nothing; other rows
+    change the image but not the rects, and the backward's per-pair terms with it (no finite-difference check on the rows: central
+    differences of the colour loss on a Tu component gave 0.09 against an analytic 0.55 -- the restated backward carries the reference's
+    detached weights and its 2-D / 3-D branch selection, so, as in the test above, only inputs that enter linearly are checked that way)."""
+    sc, f = shell
+    tm = f.array("transMat").reshape(-1, 9)
+    same = _fwd(sc, transMat_precomp=tm)
+    assert np.array_equal(same.color, f.color) and np.array_equal(same.others, f.others) and np.array_equal(same.radii, f.radii)
+    rng = np.random.default_rng(5)
+    tm2 = (tm * (1.0 + 0.05 * rng.normal(size=tm.shape))).astype(np.float32)
+    pert = _fwd(sc, transMat_precomp=tm2)
+    assert np.array_equal(pert.radii, f.radii) and pert.num_rendered == f.num_rendered
+    assert np.abs(pert.color - f.color).max() > 1e-3
+    # the backward reads the same rows: with the preprocess's own rows handed back in, every gradient is the plain one, bit for bit
+    gc, go = surfel_upstream_grads(H, W, 12)
+    g0, g1 = lgo_surfel.backward(f, gc, go), lgo_surfel.backward(same, gc, go)
+    for k in GRAD_KEYS_SURFEL + ("dL_dtransMat",):
+        assert np.array_equal(g0[k], g1[k]), k
+    # ... and with other rows the per-pair gradients move while culled surfels keep zero rows
+    g2 = lgo_surfel.backward(pert, gc, go)
+    assert np.abs(g2["dL_dtransMat"] - g0["dL_dtransMat"]).max() > 1e-3
+    assert (g2["dL_dtransMat"][f.radii == 0] == 0).all()
+
+
 def test_summation_order_band(shell):
     sc, f = shell
     g = surfel_upstream_grads(H, W, SEED)

@@ -147,8 +147,17 @@ def hip_surfel_forward_backward(scene, W, H, grads=None, far=80, near=0, scale_m
         viewmatrix=st["viewmatrix"], projmatrix=torch.eye(4, device=device), sh_degree=1, campos=torch.zeros(3, device=device),
         prefiltered=False, beam_inclinations=st["beams"], lidar_far=int(far), lidar_near=int(near), debug=False)
     rast = GaussianRasterizer(settings)
-    color, radii, others, pixels = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=None,
-                                        colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+    tm = None
+    if scene.get("transMat") is not None:
+        # precomputed blend rows next to scales / rotations: only the functional entry point takes both (the module's forward insists
+        # on exactly one, as the reference's does, R2/diff_lidargs_surfel_rasterization/__init__.py:236-240)
+        from diff_lidargs_surfel_rasterization import rasterize_gaussians
+        tm = st["transMat"].reshape(P, 9).clone().requires_grad_(True)
+        color, radii, others, pixels = rasterize_gaussians(leaves["means3D"], means2D, torch.empty(0, device=device), leaves["colors"],
+                                                           leaves["opacities"], leaves["scales"], leaves["rotations"], tm, settings)
+    else:
+        color, radii, others, pixels = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=None,
+                                            colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
     out = dict(color=color.detach().cpu().numpy(), others=others.detach().cpu().numpy(), radii=radii.cpu().numpy(),
                pixels=pixels.cpu().numpy(), rasterizer=rast)
     if grads is not None:
@@ -157,13 +166,16 @@ def hip_surfel_forward_backward(scene, W, H, grads=None, far=80, near=0, scale_m
         out.update(dL_dmeans3D=leaves["means3D"].grad.cpu().numpy(), dL_dmeans2D=means2D.grad.cpu().numpy(),
                    dL_dcolors=leaves["colors"].grad.cpu().numpy(), dL_dopacity=leaves["opacities"].grad.cpu().numpy(),
                    dL_dscales=leaves["scales"].grad.cpu().numpy(), dL_drotations=leaves["rotations"].grad.cpu().numpy())
+        if tm is not None:
+            out["dL_dtransMat"] = tm.grad.cpu().numpy()
     return out
 
 
 def oracle_surfel_forward_backward(scene, W, H, grads=None, far=80, near=0, scale_modifier=1.0):
     from oracle import lgo_surfel
     f = lgo_surfel.forward(scene["means3D"], scene["colors"], scene["opacities"], scene["scales"], scene["rotations"],
-                           scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"], scale_modifier=scale_modifier, far=far, near=near)
+                           scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"], scale_modifier=scale_modifier, far=far, near=near,
+                           transMat_precomp=scene.get("transMat"))
     out = dict(color=f.color, others=f.others, radii=f.radii, fwd=f)
     if grads is not None:
         out.update(lgo_surfel.backward(f, *grads))
