@@ -178,6 +178,13 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel, size_t patches =
 }
 bool pass1_gated(const SegPlan& p, int S) { return p.n_rounds > 0 && p.rounds[0] < S; }
 
+// The backward blend walks the work list k_render_combine filled (lidargs_common.h WorkList) on every plain or column-wedge frame that
+// runs the segmented launches; forward_impl and backward_impl both decide with this.  LIDARGS_WORK_LISTS=0: the slot grid again (A/B, tests).
+bool backward_list(int S, size_t patches, bool fused) {
+    static const bool on = [] { const char* e = getenv("LIDARGS_WORK_LISTS"); return !e || atoi(e) != 0; }();
+    return on && lg::work_lists_fit(patches, S) && !fused && S > 1;
+}
+
 // Pass 1 in rounds of growing depth: the first segments of every list, then -- only for the patches some pixel of which is
 // still unsaturated -- the next ones, and so on.  In a street scene most patches saturate within a few hundred entries,
 // and pass 1 (which restarts from T = 1 in every segment) would otherwise walk every entry behind that point for nothing.
@@ -482,11 +489,12 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         LG_STAGE_CHECK("tile bin");
         g_prof.mark("tile_bin", stream);
     }
-    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev, key16);
+    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev, key16, bin.work, LG_WORK_REGIONS * LG_WORK_CNT_STRIDE);
     LG_STAGE_CHECK("tile ranges");
     g_prof.mark("ranges", stream);
 
     lg::RenderFwdArgs ra;
+    ra.fill.cnt = nullptr;
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = point_list; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
     ra.final_T = img.final_T; ra.T_pass = T_out;
@@ -515,6 +523,8 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         LG_STAGE_CHECK("render pass 2");
         g_prof.mark("render_pass2", stream);
     }
+    // not in a range shell's phases: their backward (lidargs_backward_shell) keeps the slot grid
+    if (!transmittance_pass && !T_in && !T_out && backward_list(S, patches, false)) ra.fill = lg::work_list(bin);
     lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render combine");
     g_prof.mark("render_combine", stream);
@@ -566,6 +576,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     g_prof.mark("bwd_zero", stream);
 
     lg::RenderBwdArgs rb;
+    rb.walk.cnt = nullptr;
     rb.grid = grid; rb.ranges = img.ranges; rb.point_list = bin.val_a; rb.rec = geom.rec; rb.rowspan = geom.rowspan;
     rb.coltab = img.coltab; rb.rowtab = img.rowtab; rb.bg = background; rb.final_T = img.final_T;
     rb.seg = bin.seg; rb.S = S; rb.seg_len = plan.seg_len;
@@ -574,6 +585,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     rb.flags = (fused || S > 1 || shell_mode) ? bin.flags : nullptr; rb.R = Rp;
     rb.T_final_global = T_final_global; rb.behind = behind;
     rb.dL_dpix = dL_dpix; rb.dL_ddepth = dL_dout_depth; rb.dL_docc = dL_dout_occ; rb.gacc = geom.gacc;
+    if (!shell_mode && backward_list(S, patches, fused)) rb.walk = lg::work_list(bin);          // as forward_impl decided
     lg::launch_render_backward(rb, stream);
     LG_STAGE_CHECK("render backward");
     g_prof.mark("render_bwd", stream);
@@ -797,6 +809,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     lg::BinView bin; lg::bin_carve(binning_buffer, Rp, patches, grid.waves_per_tile, S, &bin);
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     lg::RenderFwdArgs ra;
+    ra.fill.cnt = nullptr;                       // a shell's backward keeps the slot grid
     ra.grid = grid; ra.ranges = img.ranges; ra.point_list = bin.val_a; ra.rec = geom.rec; ra.rowspan = geom.rowspan;
     ra.coltab = img.coltab; ra.rowtab = img.rowtab; ra.bg = background; ra.T_in = T_in;
     ra.final_T = img.final_T; ra.T_pass = T_out;

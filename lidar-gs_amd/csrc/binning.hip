@@ -399,13 +399,35 @@ static void radix_pass_items(const KT* kin, const uint32_t* vin, KT* kout, uint3
 // digit-major scan in LDS, scatter through global memory (the ping-pong buffers are L2-resident); a workgroup barrier separates the
 // passes (workgroup-scope release: the waves of one workgroup share their CU's L1, which is coherent for them -- an agent-scope fence
 // by 1024 threads cost ~20 us per pass).
+// One workgroup has nothing to hide a memory round trip (~1.2 us from L2 here) behind but its own loads: every dependent
+// load-then-use step of a loop costs that much (a plain 14-iteration copy loop: 17 us).  So the rounds run in groups of four, the next
+// group's keys (and values) in flight while this one is ranked, with plain unconditional loads the compiler can count (the first forms
+// -- all rounds in registers behind workgroup-scope atomic loads, then one round ahead -- waited for every load: 30 us per pass).
 constexpr int SMALL_SORT_WAVES = 16;
-constexpr int SMALL_SORT_ROUNDS = 16;                                  // rounds of 64 keys a wave holds in registers
-constexpr size_t SMALL_SORT_MAX = (size_t)SMALL_SORT_WAVES * SMALL_SORT_ROUNDS * 64;   // 16384 pairs
+constexpr size_t SMALL_SORT_MAX = 16384;                               // pairs (a size choice: 16 rounds per wave)
+// ... and up to where it is used (LIDARGS_SMALL_SORT_MAX): one CU ranks ~0.5 pairs per ns (16 waves x ~100 instructions per 64 pairs and
+// phase on four SIMDs: issue-bound, tools/micro/small_sort_bench.cpp), so at 14 k pairs a pass takes 25-30 us against ~15 us for the
+// three launches of the general form; below ~4 k pairs the single launch wins (4000 pairs: 12 us per pass)
+constexpr size_t SMALL_SORT_DEFAULT = 4096;
+constexpr int SMALL_SORT_GROUP = 4;                                    // rounds ranked per set of loads in flight
 __device__ __forceinline__ uint32_t load_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <typename KT>
 __device__ __forceinline__ uint32_t load_key_l2(const KT* p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the lanes of the wave that hold the digit d (valid lanes only): eight independent ballots, each folded with one v_bitop3_b32 per half
+// (a & ~(b ^ c), as in k_radix_scatter); bits above the pass's width are 0 in every lane and change nothing
+__device__ __forceinline__ unsigned long long small_sort_peers(uint32_t d, bool valid) {
+    const unsigned long long v0 = __ballot(valid);
+    uint32_t plo = (uint32_t)v0, phi = (uint32_t)(v0 >> 32);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint32_t mine = (uint32_t)(((int)(d << (31 - q))) >> 31);
+        const unsigned long long m = __ballot(mine != 0u);
+        plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, mine, 0x90);
+        phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), mine, 0x90);
+    }
+    return ((unsigned long long)phi << 32) | plo;
+}
 template <typename KT = uint32_t>
 __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n,
                                                                             const uint32_t* __restrict__ n_dev, int begin_bit, int end_bit, int max_bits,
@@ -417,49 +439,51 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t per = ((n + W - 1) / W + 63u) & ~63u;               // keys per wave, whole rounds
     const uint32_t lo = min(n, (uint32_t)w * per), hi = min(n, lo + per);
+    const uint32_t rounds = (hi - lo + 63u) >> 6;                      // wave-uniform
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cur = 0, shift = begin_bit;
+#pragma clang loop unroll(disable)
     while (shift < end_bit) {
         const int left = end_bit - shift;
         const int passes_left = (left + max_bits - 1) / max_bits;
         const int bits = (left + passes_left - 1) / passes_left;
         const uint32_t mask = (1u << bits) - 1u;
-        const bool last = shift + bits >= end_bit;
         const KT* kin = cur ? key_b : key_a; const uint32_t* vin = cur ? val_b : val_a;
         KT* kout = cur ? key_a : key_b; uint32_t* vout = cur ? val_a : val_b;
         const bool positions = shift == 0 && vals_are_positions;
         for (int i = tid; i < BINS * (W + 1); i += 64 * W) (&cnt[0][0])[i] = 0u;
         __syncthreads();
-        // the wave's slice -> registers, every load in flight at once (a load per round inside the loops below is an L2 round trip per
-        // round: measured 25 us per pass at 10 k keys)
-        uint32_t kreg[SMALL_SORT_ROUNDS], vreg[SMALL_SORT_ROUNDS];
+        // rounds in groups of SMALL_SORT_GROUP, the next group's keys (and values) in flight while this one is ranked; the loads are
+        // unconditional (index clamped into the array) so that the compiler counts them and waits for exactly the older group
+        constexpr int G = SMALL_SORT_GROUP;
+        const uint32_t last_i = n - 1u;                                // n > 0 here
+        auto load_keys = [&](uint32_t base, uint32_t (&k)[G]) {
 #pragma unroll
-        for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
-            const uint32_t i = lo + (uint32_t)r * 64u + lane;
-            kreg[r] = i < hi ? load_key_l2(kin + i) : 0u;
-            vreg[r] = i < hi ? (positions ? i : load_l2(vin + i)) : 0u;
-        }
+            for (int q = 0; q < G; q++) k[q] = (uint32_t)kin[min(base + (uint32_t)q * 64u + lane, last_i)];
+        };
+        auto load_vals = [&](uint32_t base, uint32_t (&v)[G]) {
+#pragma unroll
+            for (int q = 0; q < G; q++) { const uint32_t i = min(base + (uint32_t)q * 64u + lane, last_i); v[q] = positions ? i : vin[i]; }
+        };
         // 1. per-(digit, wave) counts (one wave owns its column: plain LDS read-modify-writes in program order, through the peers' leader)
+        {
+            uint32_t ka[G], kb[G];
+            load_keys(lo, ka);
+#pragma clang loop unroll(disable)
+            for (uint32_t g = 0; g < rounds; g += G) {
+                load_keys(lo + (g + G) * 64u, kb);
 #pragma unroll
-        for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
-            const uint32_t i = lo + (uint32_t)r * 64u + lane;
-            if (lo + (uint32_t)r * 64u >= hi) break;                   // wave-uniform
-            const bool valid = i < hi;
-            const uint32_t d = valid ? (km(kreg[r]) >> shift) & mask : 0u;
-            // all MAXB digit bits, unrolled (bits above the pass's width are 0 in every lane and change nothing): the eight ballots are
-            // independent, only the folds are a chain -- and each fold is one v_bitop3_b32 per half (a & ~(b ^ c), as in k_radix_scatter)
-            const unsigned long long v0 = __ballot(valid);
-            uint32_t plo = (uint32_t)v0, phi = (uint32_t)(v0 >> 32);
+                for (int q = 0; q < G; q++) {
+                    const uint32_t i = lo + (g + (uint32_t)q) * 64u + lane;
+                    const bool valid = i < hi;
+                    const uint32_t d = valid ? (km(ka[q]) >> shift) & mask : 0u;
+                    const unsigned long long peers = small_sort_peers(d, valid);
+                    if (valid && (peers & lt) == 0ull) cnt[d][w] += (uint32_t)__popcll(peers);
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
-            for (int q = 0; q < MAXB; q++) {
-                const uint32_t mine = (uint32_t)(((int)(d << (31 - q))) >> 31);
-                const unsigned long long m = __ballot(mine != 0u);
-                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, mine, 0x90);
-                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), mine, 0x90);
+                for (int q = 0; q < G; q++) ka[q] = kb[q];
             }
-            const unsigned long long peers = ((unsigned long long)phi << 32) | plo;
-            if (valid && (peers & lt) == 0ull) cnt[d][w] += (uint32_t)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         // 2. exclusive scan, digit-major then wave-major: thread t owns BINS * W / 1024 = 4 consecutive (digit, wave) cells
@@ -478,44 +502,73 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* 
         }
         __syncthreads();
         // 3. scatter in key order
+        {
+            uint32_t ka[G], kb[G], va[G], vb[G];
+            load_keys(lo, ka); load_vals(lo, va);
+#pragma clang loop unroll(disable)
+            for (uint32_t g = 0; g < rounds; g += G) {
+                load_keys(lo + (g + G) * 64u, kb); load_vals(lo + (g + G) * 64u, vb);
 #pragma unroll
-        for (int r = 0; r < SMALL_SORT_ROUNDS; r++) {
-            const uint32_t i = lo + (uint32_t)r * 64u + lane;
-            if (lo + (uint32_t)r * 64u >= hi) break;
-            const bool valid = i < hi;
-            const uint32_t k = kreg[r], v = vreg[r];
-            const uint32_t d = (km(k) >> shift) & mask;
-            // all MAXB digit bits, unrolled (bits above the pass's width are 0 in every lane and change nothing): the eight ballots are
-            // independent, only the folds are a chain -- and each fold is one v_bitop3_b32 per half (a & ~(b ^ c), as in k_radix_scatter)
-            const unsigned long long v0 = __ballot(valid);
-            uint32_t plo = (uint32_t)v0, phi = (uint32_t)(v0 >> 32);
-#pragma unroll
-            for (int q = 0; q < MAXB; q++) {
-                const uint32_t mine = (uint32_t)(((int)(d << (31 - q))) >> 31);
-                const unsigned long long m = __ballot(mine != 0u);
-                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, mine, 0x90);
-                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), mine, 0x90);
-            }
-            const unsigned long long peers = ((unsigned long long)phi << 32) | plo;
-            const uint32_t rank = (uint32_t)__popcll(peers & lt);
-            const uint32_t pos = valid ? cnt[d][w] + rank : 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (valid && rank == 0) cnt[d][w] += (uint32_t)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                if (last && tail.mode != 0) {                          // the sorted keys are not needed: the value's record goes to its final place
-                    vout[pos] = v;
-                    if (tail.mode == 1) static_cast<uint32_t*>(tail.dst)[pos] = static_cast<const uint32_t*>(tail.src)[v];
-                    else { const uint4 sp = static_cast<const uint4*>(tail.src)[v]; static_cast<uint2*>(tail.dst)[pos] = make_uint2(sp.y, sp.x); }
-                } else {
-                    kout[pos] = (KT)k; vout[pos] = v;
+                for (int q = 0; q < G; q++) {
+                    const uint32_t i = lo + (g + (uint32_t)q) * 64u + lane;
+                    const bool valid = i < hi;
+                    const uint32_t k = ka[q], v = va[q];
+                    const uint32_t d = valid ? (km(k) >> shift) & mask : 0u;
+                    const unsigned long long peers = small_sort_peers(d, valid);
+                    const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                    const uint32_t pos = valid ? cnt[d][w] + rank : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && rank == 0) cnt[d][w] += (uint32_t)__popcll(peers);
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid) { kout[pos] = (KT)k; vout[pos] = v; }
                 }
+#pragma unroll
+                for (int q = 0; q < G; q++) { ka[q] = kb[q]; va[q] = vb[q]; }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the pass's stores are visible to the workgroup's waves before the next pass reads them
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");         // (plain loads behind it: a workgroup's waves share their CU's L1)
         shift += bits;
         cur ^= 1;
+    }
+    // an odd number of passes left the pairs on the b side: bring them home here (the host then always finds them on the a side; two
+    // device-to-device copy launches cost a 10 k-Gaussian frame 20 us).  Not with a tail: its last pass wrote to the tail's own arrays.
+    if (n == 0) return;
+    constexpr int CG = 4;                                              // loads in flight per thread in the two loops below
+    const uint32_t last_n = n - 1u;
+    if (cur && tail.mode == 0) {
+#pragma clang loop unroll(disable)
+        for (uint32_t i0 = tid; i0 < n; i0 += CG * 64 * W) {
+            uint32_t k[CG], v[CG];
+#pragma unroll
+            for (int q = 0; q < CG; q++) { const uint32_t i = min(i0 + (uint32_t)q * 64u * W, last_n); k[q] = (uint32_t)key_b[i]; v[q] = val_b[i]; }
+#pragma unroll
+            for (int q = 0; q < CG; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) { key_a[i] = (KT)k[q]; val_a[i] = v[q]; } }
+        }
+    }
+    // the tail (a gather by the sorted values: each value's record to its final place) as its own loop behind the last pass
+    if (tail.mode != 0) {
+        const uint32_t* vfin = cur ? val_b : val_a;
+#pragma clang loop unroll(disable)
+        for (uint32_t i0 = tid; i0 < n; i0 += CG * 64 * W) {
+            uint32_t v[CG];
+#pragma unroll
+            for (int q = 0; q < CG; q++) v[q] = vfin[min(i0 + (uint32_t)q * 64u * W, last_n)];
+            if (tail.mode == 1) {
+                uint32_t x[CG];
+#pragma unroll
+                for (int q = 0; q < CG; q++) x[q] = static_cast<const uint32_t*>(tail.src)[v[q]];
+#pragma unroll
+                for (int q = 0; q < CG; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) static_cast<uint32_t*>(tail.dst)[i] = x[q]; }
+            } else {
+                uint4 x[CG];
+#pragma unroll
+                for (int q = 0; q < CG; q++) x[q] = static_cast<const uint4*>(tail.src)[v[q]];
+#pragma unroll
+                for (int q = 0; q < CG; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) static_cast<uint2*>(tail.dst)[i] = make_uint2(x[q].y, x[q].x); }
+            }
+        }
     }
 }
 
@@ -538,13 +591,15 @@ static int radix_sort_pairs_t(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* v
     if (n == 0 || end_bit <= begin_bit) return 0;
     if (max_bits < 1 || max_bits > SORT_MAX_RADIX_BITS) max_bits = SORT_RADIX_BITS;
     static const int small_off = [] { const char* e = getenv("LIDARGS_NO_SMALL_SORT"); return e ? atoi(e) : 0; }();
-    if (n <= SMALL_SORT_MAX && !small_off) {                           // the whole sort in one launch (k_radix_sort_small)
+    static const size_t small_max = [] { const char* e = getenv("LIDARGS_SMALL_SORT_MAX"); const long v = e ? atol(e) : (long)SMALL_SORT_DEFAULT;
+                                         return (size_t)(v < 0 ? 0 : (v > (long)SMALL_SORT_MAX ? (long)SMALL_SORT_MAX : v)); }();
+    if (n <= small_max && !small_off) {                                // the whole sort in one launch (k_radix_sort_small)
         const int mb = max_bits > 8 ? 8 : max_bits;
         int passes = 0;
         for (int sh = begin_bit; sh < end_bit;) { const int left = end_bit - sh, pl = (left + mb - 1) / mb; sh += (left + pl - 1) / pl; passes++; }
         hipLaunchKernelGGL(k_radix_sort_small<KT>, dim3(1), dim3(64 * SMALL_SORT_WAVES), 0, s, key_a, key_b, val_a, val_b, (uint32_t)n, n_dev, begin_bit, end_bit,
                            mb, vals_are_positions ? 1 : 0, tail, key_map(bias));
-        return passes & 1;
+        return tail.mode == 0 ? 0 : (passes & 1);                       // without a tail the kernel brings the pairs home itself
     }
     if (scratch_bits < max_bits) scratch_bits = max_bits;
     int cur = 0;
@@ -728,8 +783,9 @@ void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off
 // first / last thread those before the first / behind the last key): every entry is written, no separate fill launch.
 template <typename KT = uint32_t>
 __global__ void __launch_bounds__(256) k_tile_ranges(const KT* __restrict__ tile_sorted, size_t R, const uint32_t* __restrict__ R_dev,
-                                                     uint2* __restrict__ ranges, uint32_t tiles) {
+                                                     uint2* __restrict__ ranges, uint32_t tiles, uint32_t* __restrict__ zero, int n_zero) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) for (int q = threadIdx.x; q < n_zero; q += 256) zero[q] = 0u;    // the work lists' counters (lidargs_common.h WorkList)
     if (R_dev) R = min(R, (size_t)*R_dev);                             // enqueue-only forward: the count lives on the device
     if (R == 0) {                                                      // nothing binned: every tile is empty
         if (blockIdx.x == 0) for (uint32_t t = threadIdx.x; t < tiles; t += 256) ranges[t] = make_uint2(0u, 0u);
@@ -753,11 +809,16 @@ __global__ void __launch_bounds__(256) k_tile_ranges(const KT* __restrict__ tile
     }
 }
 
-void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev, bool key16) {
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev, bool key16,
+                        uint32_t* zero, int n_zero) {
+    if (!zero) n_zero = 0;
     if (R && key16) hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(tile_sorted), R, R_dev,
-                                       ranges, (uint32_t)tiles);
-    else if (R) hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, R_dev, ranges, (uint32_t)tiles);
-    else hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
+                                       ranges, (uint32_t)tiles, zero, n_zero);
+    else if (R) hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, R_dev, ranges, (uint32_t)tiles, zero, n_zero);
+    else {
+        hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
+        if (n_zero) hipMemsetAsync(zero, 0, sizeof(uint32_t) * (size_t)n_zero, s);
+    }
 }
 
 // Enqueue-only forward: what the host would have read, folded on the device.  status[0] = instances the frame needs at the chosen

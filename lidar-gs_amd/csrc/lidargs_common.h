@@ -157,7 +157,30 @@ struct BinView {
     float* seg;                          // [patches][S][LG_SEG_PLANES][64]
     uint8_t* flags;                      // [waves_per_tile][R]: pass 1 saw >= 1 pixel of the patch take this entry
     uint8_t* alive;                      // [patches]: number of list segments pass 1 walked (255 = all)
+    uint32_t* work;                      // the backward's work list (see WorkList): counters, then items [LG_WORK_REGIONS][cap]
+    uint32_t work_cap;                   // items per region
 };
+
+// Work list of the backward blend.  A blend launch over (patch, segment) slots carries patches x S single-wave workgroups of which,
+// on the BASELINE frames, five in six (cfg4: 49 in 50) have nothing to walk (behind the list's end or the patch's saturation point): each
+// costs a dispatch (~0.22 ns, tools/micro/empty_wg.hip) and a wave slot for the round trip of the three loads it decides on.  The
+// backward knows its live slots beforehand -- k_render_combine sees, per patch, how many segments some pixel walked through -- so it walks
+// a LIST of them: item b / R of region b % R, the workgroups behind a region's count leaving on one scalar load at the END of the grid,
+// where their dispatch hides behind the live ones.  The combine appends a patch's slots with ONE atomic on the counter of region
+// patch % LG_WORK_REGIONS; the counters sit 128 bytes apart (same-line atomics serialise at ~11 ns each: 64 counters in two lines cost
+// cfg4's combine 22 us).  A region's items are in patch order up to the arrival order of the atomics: which workgroup walks which slot
+// changes nothing in what is computed.  (Lists for the forward launches -- the tail of pass 1, pass 2 -- were built and measured too:
+// no gain, those launches are as long as their longest segment walk)
+#define LG_WORK_REGIONS 64
+#define LG_WORK_CNT_STRIDE 32            // words between two regions' counters (one 128-byte line each)
+struct WorkList {
+    uint32_t* cnt;                       // [LG_WORK_REGIONS] at stride LG_WORK_CNT_STRIDE
+    uint32_t* items;                     // [LG_WORK_REGIONS][cap]: (patch << 8) | segment
+    uint32_t cap;
+};
+inline uint32_t work_cap(size_t patches, int S) { return (uint32_t)(((patches + LG_WORK_REGIONS - 1) / LG_WORK_REGIONS) * (size_t)S); }
+inline size_t work_words(size_t patches, int S) { return (size_t)LG_WORK_REGIONS * (LG_WORK_CNT_STRIDE + (size_t)work_cap(patches, S)); }
+inline bool work_lists_fit(size_t patches, int S) { return S <= 255 && patches < ((size_t)1 << 24); }
 
 // List segments: the launch provides `max_segments` workgroups per patch; each tile uses ceil(len / seg_len) of them
 // (render.hip segment_count), so long lists of a skewed frame (far range shells, street canyons) are split as finely as
@@ -179,8 +202,18 @@ inline size_t bin_carve(char* base, size_t R, size_t patches, int waves_per_tile
     b.seg = c.take<float>(patches * (size_t)S * LG_SEG_PLANES * 64);
     b.flags = c.take<uint8_t>((size_t)waves_per_tile * n + 64);
     b.alive = c.take<uint8_t>(patches + 64);
+    b.work_cap = work_cap(patches, S);
+    b.work = c.take<uint32_t>(work_words(patches, S));
     if (v) *v = b;
     return (size_t)(c.p - base) + 128;
+}
+
+inline WorkList work_list(const BinView& b) {
+    WorkList w;
+    w.cnt = b.work;
+    w.items = b.work + (size_t)LG_WORK_REGIONS * LG_WORK_CNT_STRIDE;
+    w.cap = b.work_cap;
+    return w;
 }
 
 struct ImgView {
@@ -325,7 +358,9 @@ void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint
 // key16: the tile keys are 16-bit (the array is the same allocation, half used): every image with at most 65536 list tiles
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, bool key16 = false);
-void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr, bool key16 = false);
+// zero / n_zero: words this launch also clears (the work lists' counters: nothing before the blends touches them)
+void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr, bool key16 = false,
+                        uint32_t* zero = nullptr, int n_zero = 0);
 int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit, uint32_t* scratch, hipStream_t s,
                               const uint32_t* n_dev = nullptr);
 
@@ -341,6 +376,7 @@ __device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int
     return patch < patches;
 }
 inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * (unsigned)S; }
+
 
 // Segments of a tile list: ceil(L / seg_len) of them, at most S (the launch provides S workgroups per patch; the
 // surplus ones retire at once and never touch the segment planes).  A pure function of the tile's range, so every
@@ -377,6 +413,7 @@ struct RenderFwdArgs {
     uint8_t* alive;           // [patches] (nullptr = no gating): number of segments pass 1 walked (255 = all of them)
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
+    WorkList fill;            // k_render_combine: the backward's work list (cnt == nullptr: none)
 };
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s);     // T-only walk of every segment
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s);
@@ -399,6 +436,7 @@ struct RenderBwdArgs {
     const float* dL_dpix; const float* dL_ddepth; const float* dL_docc;
     float* gacc;                   // [16P], zeroed: slots 0-2 mean2D.xyz, 3-5 conic A,B,C, 6 opacity, 7-8 colour,
                                    //               9 range, 10-12 G1 = sum gx delta, 13-15 G2 = sum gy delta (moments of dL/du1, dL/du2)
+    WorkList walk;                 // the list k_render_combine filled; cnt == nullptr: the slot grid
 };
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s);
 

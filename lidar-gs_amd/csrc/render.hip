@@ -614,6 +614,7 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     float C0 = 0.f, C1 = 0.f, D = 0.f;
     float T_final = a.T_in ? a.T_in[pix] : 1.f, T_hand = T_final;
     bool stopped = false;
+    int taken = 0, kend = 0;                                           // segments this pixel's walk went through | segments the patch's loop loaded
     // four segments per step: their twenty loads are issued together (every plane below St was written by pass 2), and a pixel
     // whose walk has ended simply stops taking them; the patch leaves once all of its pixels have
     for (int k0 = 0; k0 < St; k0 += 4) {
@@ -629,9 +630,28 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
             const bool use = !stopped && (k0 + i < St);
             C0 += use ? c0[i] : 0.f; C1 += use ? c1[i] : 0.f; D += use ? dd[i] : 0.f;
             T_final = use ? te[i] : T_final; T_hand = use ? tb[i] : T_hand;
+            taken += use ? 1 : 0;
             stopped = stopped || (use && tb[i] < 0.0001f);             // the walk ended inside segment k
         }
+        kend = min(St, k0 + 4);
         if (__ballot(!stopped) == 0ull) break;
+    }
+    if (a.fill.cnt) {
+        // the backward's work list: the segments some pixel of the patch walked through (nothing was blended behind them).  Some pixel
+        // was still walking when the last step began, so the count lies in that step; one atomic per patch, by the first lane that is
+        // inside the image (the others left above)
+        int n = 0;
+        for (int k = kend; k > kend - 4 && k > 0 && n == 0; k--) if (__ballot(taken >= k) != 0ull) n = k;
+        if (n > 0) {
+            const unsigned long long act = __ballot(true);
+            const int leader = __ffsll((long long)act) - 1;
+            const uint32_t r = (uint32_t)patch % LG_WORK_REGIONS;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(a.fill.cnt + r * LG_WORK_CNT_STRIDE, (uint32_t)n);
+            base = (uint32_t)__shfl((int)base, leader);
+            const int rank = __popcll(act & ((1ull << lane) - 1ull)), nact = __popcll(act);
+            for (int k = rank; k < n; k += nact) a.fill.items[(size_t)r * a.fill.cap + base + (uint32_t)k] = ((uint32_t)patch << 8) | (uint32_t)k;
+        }
     }
     const size_t N = (size_t)g.W * g.H;
     a.final_T[pix] = T_final;
@@ -737,8 +757,17 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
     int patch, seg;
-    if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), S, patch, seg)) return;
-    patch = a.grid.global_patch(patch);
+    if (a.walk.cnt) {
+        // item blockIdx / R of region blockIdx % R of the list k_render_combine filled (lidargs_common.h WorkList); the workgroups behind a
+        // region's count -- the tail of the grid -- leave on one scalar load
+        const unsigned r = blockIdx.x % LG_WORK_REGIONS, i = blockIdx.x / LG_WORK_REGIONS;
+        if (i >= a.walk.cnt[r * LG_WORK_CNT_STRIDE]) return;
+        const uint32_t it = a.walk.items[(size_t)r * a.walk.cap + i];
+        patch = (int)(it >> 8); seg = (int)(it & 255u);
+    } else {
+        if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), S, patch, seg)) return;
+        patch = a.grid.global_patch(patch);
+    }
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const size_t stride = LG_SEG_PLANES * 64;
     // the three things every workgroup decides on are fetched together (the plane address is valid for any slot; what an unwalked
@@ -920,7 +949,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
 }
 
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
-    const unsigned blocks = segment_grid(a.grid.window_patches(), a.S);
+    const unsigned blocks = a.walk.cnt ? (unsigned)LG_WORK_REGIONS * a.walk.cap : segment_grid(a.grid.window_patches(), a.S);
     hipLaunchKernelGGL(k_render_backward, dim3(blocks), dim3(64), 0, s, a);
 }
 

@@ -167,17 +167,20 @@ print("OK")
                                  {"LIDARGS_P2_GROUP": "3"}, {"LIDARGS_SORT_ITEMS": "16"}, {"LIDARGS_RANGE_SORT_BITS": "11"},
                                  {"LIDARGS_FUSED": "0"}, {"LIDARGS_FUSED_WAVES": "4"}, {"LIDARGS_FUSED_WAVES": "16"},
                                  {"LIDARGS_FUSED": "1", "LIDARGS_SEG_LEN": "128", "LIDARGS_MAX_SEGMENTS": "33"}, {"LIDARGS_FUSED": "0", "LIDARGS_HEAD": "1"},
-                                 {"LIDARGS_TILE_KEY32": "1"}, {"LIDARGS_NO_SMALL_SORT": "1"}, {"LIDARGS_RANGE_SORT_FULL": "1"}, {}],
+                                 {"LIDARGS_TILE_KEY32": "1"}, {"LIDARGS_NO_SMALL_SORT": "1"}, {"LIDARGS_RANGE_SORT_FULL": "1"},
+                                 {"LIDARGS_FUSED": "0", "LIDARGS_WORK_LISTS": "0"}, {"LIDARGS_SMALL_SORT_MAX": "16384"}, {}],
                          ids=["head5", "head2_rounds26", "nohead_seg128", "pass2_groups_of_3", "sort_blocks_4096", "sort_digits_11",
                               "five_launch_forward", "fused_4_waves", "fused_16_waves", "fused_on_128_entry_segments", "unfused_head",
-                              "tile_keys_32_bit", "no_single_launch_sort", "range_sort_all_31_bits", "defaults"])
+                              "tile_keys_32_bit", "no_single_launch_sort", "range_sort_all_31_bits", "backward_on_the_slot_grid", "single_launch_sort_up_to_16k", "defaults"])
 def test_plan_variants_are_invisible(env, hip_lib_built):
     """The segment plan is an internal choice too: round 1 as the complete walk of the list heads (what the big frames take by default:
     k_render_pass2_grouped<true>, here forced onto the 64-entry plan with heads of 5 and 2 segments), pass 2 over groups of segments
     behind a head, no head on 128-entry segments, the sort's block size and digit width -- the image and the gradients must not
     depend on any of it.  Round 3: the fused one-launch forward against the five-launch form, 16- against 32-bit tile keys, the single-launch
-    small sort against the general one, the range sort on the key span against all 31 bits (the third scene is small enough for the
-    small sort and sits closer than 2 m to the sensor in places, so that the key span is not the usual 26 bits)."""
+    small sort against the general one (by default up to 4096 pairs; with `LIDARGS_SMALL_SORT_MAX=16384` the third scene's 9000 Gaussians
+    go through it too), the range sort on the key span against all 31 bits (the third scene sits closer than 2 m to the sensor in places,
+    so that the key span is not the usual 26 bits); the backward blend over
+    the slot grid against the work list the combine fills (the default whenever the five-launch forward runs: `five_launch_forward`)."""
     import os, subprocess, sys
     code = r"""
 import sys, numpy as np
