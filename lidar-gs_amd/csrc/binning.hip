@@ -781,40 +781,59 @@ void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles
 // without instances read (0, 0); here the thread at a boundary writes the empty ranges of the tiles it skips over (and the
 // first / last thread those before the first / behind the last key): every entry is written, no separate fill launch.
+// Eight consecutive keys per thread (one or two 16-byte loads; one key per thread made cfg4's 35 M instances a 43-us launch).
+constexpr int RANGES_ITEMS = 8;
 template <typename KT = uint32_t>
 __global__ void __launch_bounds__(256) k_tile_ranges(const KT* __restrict__ tile_sorted, size_t R, const uint32_t* __restrict__ R_dev,
                                                      uint2* __restrict__ ranges, uint32_t tiles, uint32_t* __restrict__ zero, int n_zero) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0) for (int q = threadIdx.x; q < n_zero; q += 256) zero[q] = 0u;    // the work lists' counters (lidargs_common.h WorkList)
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * RANGES_ITEMS;
+    if (blockIdx.x == 0) for (int q = threadIdx.x; q < n_zero; q += 256) zero[q] = 0u;    // the work list's counters (lidargs_common.h WorkList)
     if (R_dev) R = min(R, (size_t)*R_dev);                             // enqueue-only forward: the count lives on the device
     if (R == 0) {                                                      // nothing binned: every tile is empty
         if (blockIdx.x == 0) for (uint32_t t = threadIdx.x; t < tiles; t += 256) ranges[t] = make_uint2(0u, 0u);
         return;
     }
-    if (i >= R) return;
-    const uint32_t cur = tile_sorted[i];
-    if (i == 0) {
-        for (uint32_t t = 0; t < cur && t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
-        ranges[cur].x = 0;
+    if (i0 >= R) return;
+    // the arrays are carved with room behind their last element (the next array of the binning buffer at worst): the vector loads may
+    // read past R, what they bring is not looked at
+    uint32_t key[RANGES_ITEMS];
+    if constexpr (sizeof(KT) == 2) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile_sorted + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) { key[2 * q] = w[q] & 0xFFFFu; key[2 * q + 1] = w[q] >> 16; }
     } else {
-        const uint32_t prev = tile_sorted[i - 1];
-        if (cur != prev) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(tile_sorted + i0), v1 = *reinterpret_cast<const uint4*>(tile_sorted + i0 + 4);
+        key[0] = v0.x; key[1] = v0.y; key[2] = v0.z; key[3] = v0.w; key[4] = v1.x; key[5] = v1.y; key[6] = v1.z; key[7] = v1.w;
+    }
+    uint32_t prev = i0 ? (uint32_t)tile_sorted[i0 - 1] : 0u;
+#pragma unroll
+    for (int q = 0; q < RANGES_ITEMS; q++) {
+        const size_t i = i0 + (size_t)q;
+        if (i >= R) break;
+        const uint32_t cur = key[q];
+        if (i == 0) {
+            for (uint32_t t = 0; t < cur && t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+            ranges[cur].x = 0;
+        } else if (cur != prev) {
             ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i;
             for (uint32_t t = prev + 1; t < cur; t++) ranges[t] = make_uint2(0u, 0u);
         }
-    }
-    if (i == R - 1) {
-        ranges[cur].y = (uint32_t)R;
-        for (uint32_t t = cur + 1; t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+        if (i == R - 1) {
+            ranges[cur].y = (uint32_t)R;
+            for (uint32_t t = cur + 1; t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+        }
+        prev = cur;
     }
 }
 
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev, bool key16,
                         uint32_t* zero, int n_zero) {
     if (!zero) n_zero = 0;
-    if (R && key16) hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(tile_sorted), R, R_dev,
-                                       ranges, (uint32_t)tiles, zero, n_zero);
-    else if (R) hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_sorted, R, R_dev, ranges, (uint32_t)tiles, zero, n_zero);
+    if (R && key16) hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)((R + 256 * RANGES_ITEMS - 1) / (256 * RANGES_ITEMS))), dim3(256), 0, s,
+                                       reinterpret_cast<const uint16_t*>(tile_sorted), R, R_dev, ranges, (uint32_t)tiles, zero, n_zero);
+    else if (R) hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)((R + 256 * RANGES_ITEMS - 1) / (256 * RANGES_ITEMS))), dim3(256), 0, s, tile_sorted, R, R_dev,
+                                   ranges, (uint32_t)tiles, zero, n_zero);
     else {
         hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
         if (n_zero) hipMemsetAsync(zero, 0, sizeof(uint32_t) * (size_t)n_zero, s);
