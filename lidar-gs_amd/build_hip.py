@@ -41,10 +41,25 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Up-to-date check and build under an exclusive file lock: the ranks of `bench.py --gpus N` (one process per GPU) all call this
+    at start-up, and only the first may compile -- the others wait and then find the library up to date.  The link goes to a
+    temporary name and is moved into place, so a process that loaded the library earlier never sees a half-written file."""
     if not force and not needs_build():
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return OUT
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
     def compile_one(item):
         src, extra = item
@@ -57,10 +72,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES.items()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", OUT]
+    tmp = OUT + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, OUT)
     return OUT
 
 
