@@ -1032,14 +1032,22 @@ def main():
                                                 colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
                 torch.autograd.backward([color, depth, occ], [gc, gd, go])
         eager_step = step
-        if args.graph:
-            assert not fwd_only, "--graph captures forward + backward"
-            rast.enqueue_only = True
+
+        def capture(r):
+            """forward + backward of rasterizer `r` (enqueue-only path) as a HIP graph; returns the replay callable"""
+            r.enqueue_only = True
+
+            def one():
+                for t in list(leaves.values()) + [means2D]:
+                    t.grad = None
+                color, depth, occ, radii = r(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                             colors_precomp=leaves["colors"], scales=leaves["scales"], rotations=leaves["rotations"])
+                torch.autograd.backward([color, depth, occ], [gc, gd, go])
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                 # learn capacity / tile height and warm up off the default stream, as capture asks
                 for _ in range(4):
-                    eager_step()
+                    one()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             for t in list(leaves.values()) + [means2D]:
@@ -1048,9 +1056,29 @@ def main():
             _gc.collect()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                eager_step()
-            step = graph.replay
+                one()
+            return graph.replay
+        if args.graph:
+            assert not fwd_only, "--graph captures forward + backward"
+            step = capture(rast)
         res = timed_region(step)
+        graph_leg = None
+        if args.workload == "cfg1" and not args.graph and not fwd_only:
+            # a 10 k-Gaussian frame is ~0.15 ms of device time behind ~0.2-0.35 ms of per-frame host work (Python, ctypes, one host read):
+            # the eager number measures the box's CPU.  The same frame as a HIP-graph replay rides along in the line.
+            rast_g = GaussianRasterizer(settings)
+            replay = capture(rast_g)
+            for _ in range(args.warmup):
+                replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                replay()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t0) / args.steps
+            assert not rast_g.enqueue_status()["overflow"], "the captured binning capacity was too small"
+            graph_leg = {"ms_per_step": tg * 1e3, "value": 1.0 / tg, "unit": "frames/s",
+                         "what": "the same forward + backward captured once in a HIP graph (enqueue-only path: no host read) and replayed"}
         if args.graph:
             assert not rast.enqueue_status()["overflow"], "the captured binning capacity was too small"
             _C.profile_enable(True)                       # a replay makes no library calls: the stage events come from eager frames, after the timed region
@@ -1145,6 +1173,8 @@ def main():
                        "sharding": "single GPU" if world == 1 and not force_shells else
                                    (f"{world} range shells" if args.shard == "shells" else f"{world} column wedges")},
         }
+        if not sharded and graph_leg is not None:
+            out["graph_replay"] = graph_leg
         if world == 1 and not force_shells:
             # roofline: every launch (group) priced on what IT processes (R' = the instances this frame binned), the longest single
             # launch on top; the reference data flow's bytes (R_ref 16x1 instances) against our time are kept apart, they are a
