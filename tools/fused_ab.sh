@@ -1,7 +1,7 @@
 # scratch A/B script (edit per experiment)
 R=$GRAFT_REPO_ROOT
-for wl in cfg3 cfg2; do
-  for v in "LIDARGS_MIX_FRONT=0 LIDARGS_TAIL_LIST=0" "LIDARGS_MIX_FRONT=1 LIDARGS_TAIL_LIST=0" "LIDARGS_MIX_FRONT=0 LIDARGS_TAIL_LIST=1" "LIDARGS_MIX_FRONT=1 LIDARGS_TAIL_LIST=1" "LIDARGS_MIX_FRONT=0 LIDARGS_TAIL_LIST=0" "LIDARGS_MIX_FRONT=1 LIDARGS_TAIL_LIST=1"; do
-    echo "== $wl $v"; env $v python $R/tools/time_cfg.py $wl 2>&1 | tail -1 | cut -c1-330
-  done
+for v in "LIDARGS_NG_ROWS=2" "LIDARGS_NG_ROWS=1" "LIDARGS_NG_ROWS=2" "LIDARGS_NG_ROWS=1"; do
+  echo "== $v"
+  env $v python $R/bench.py --workload decode --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('decode', round(d['ms_per_step'],4), d.get('parts') or d.get('stage_ms') or '')"
+  env $v python $R/bench.py --workload train_step --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('train_step', round(d['ms_per_step'],4), d.get('parts') or d.get('stage_ms') or '')"
 done
