@@ -1,5 +1,7 @@
 # scratch A/B script (edit per experiment)
 R=$GRAFT_REPO_ROOT
-for v in "LIDARGS_WORK_LISTS=0" "LIDARGS_WORK_LISTS=1" "LIDARGS_WORK_LISTS=0" "LIDARGS_WORK_LISTS=1"; do
-  echo "== cfg5 $v"; env $v python $R/bench.py --workload cfg5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],4), d['stage_ms'])"
+for wl in cfg3 cfg2 cfg4; do
+  for v in "LG_REGION_MODE=0" "LG_REGION_MODE=1" "LG_REGION_MODE=2" "LIDARGS_WORK_LISTS=0" "LG_REGION_MODE=0" "LG_REGION_MODE=1"; do
+    echo "== $wl $v"; env $v python $R/tools/time_cfg.py $wl 2>&1 | tail -1 | grep -o "ms/frame [0-9.]*\|'render_bwd': [0-9.]*"  | tr '\n' ' '; echo
+  done
 done
