@@ -262,8 +262,16 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // are dropped from the lists without changing any pixel; the margins cover float rounding.
         int tx0 = xmin, tx1 = xmax, ty_lo = ymin, ty_hi = ymax;
         const float op = a.opacities[idx];
+        // The bounds below turn |sin(dbeta)| <= sb into |dbeta| <= asin(sb), which holds on [0, pi/2] only.  The reference evaluates the
+        // Gaussian at EVERY pixel of the 16-column tiles its rect touches, and a pixel looking the other way (dbeta near pi) has
+        // sin(dbeta) near 0 again: delta = pixel_dir - dir projects onto the tangent plane as (0, 0) at the antipode, so the reference
+        // blends the Gaussian there at full weight.  With W <= 32 a single tile spans that far (found by tools/parity_sweep.py on W = 25:
+        // a Gaussian at column 12.5 contributing at column 0), with a footprint wider than a quarter of the panorama the rect does.  Such
+        // Gaussians keep their whole reference rect; so does every Gaussian of a beam fan wider than pi/2 (same argument for the rows).
+        const float reach = fmaxf(p_c - 16.f * (float)xmin, 16.f * (float)xmax - p_c) * pp.col_step;
+        const bool small_angles = reach < 1.5f && (beam(H - 1) - beam(0)) < 1.5f;
         if (!(op * 255.f >= 1.f)) { tx1 = tx0; }                       // can never reach 1/255
-        else if (pp.prune) {
+        else if (pp.prune && small_angles) {
             // Everything here is a bound from above, so the cheap forms are as safe as the exact ones: the hardware log (the
             // 0.02 covers its error), asin(x) <= x + 0.23 x^3 on [0, 0.7], 1 - cos(t) <= t^2 / 2, |sin(alpha)| = |dir.z|.
             const float tau2 = 2.f * (__logf(255.f * op) + 0.02f);

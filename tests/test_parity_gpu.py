@@ -262,6 +262,26 @@ def test_random_small_scenes(seed, hip_lib_built):
         parity(k, hip[k], ref[k])
 
 
+@pytest.mark.parametrize("H,W,P,kind,seed,kw", [(2, 25, 2033, "street", 17, dict(far=30, near=0, scale_modifier=0.5)),
+                                                 (40, 6, 4305, "shell", 70, dict(far=30, near=2, scale_modifier=1.0)),
+                                                 (17, 22, 3070, "street", 130, dict(far=80, near=2, scale_modifier=1.0)),
+                                                 (16, 31, 5000, "shell", 5, dict(far=80, near=0, scale_modifier=1.0))],
+                         ids=["2x25", "40x6", "17x22", "16x31"])
+def test_narrow_images_where_a_tile_spans_half_the_panorama(H, W, P, kind, seed, kw, hip_lib_built):
+    """The reference evaluates a Gaussian at every pixel of the 16-column tiles its rect touches, and a pixel that looks the OTHER way
+    (azimuth difference near pi) projects onto the Gaussian's tangent plane at (0, 0): it is blended at full weight there
+    (R3/cr/forward.cu:593-606).  With W <= 32 one tile spans that far.  The footprint pruning of the preprocess (a small-angle argument)
+    dropped those pixels' entries until tools/parity_sweep.py found it (round 3): 4 of 100 colour entries off by their whole value on
+    the first of these scenes."""
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads, **kw)
+    hip = hip_forward_backward(scene, W, H, grads, **kw)
+    assert np.array_equal(hip["radii"], ref["radii"])
+    for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+        parity(k, hip[k], ref[k])
+
+
 def test_backward_twice_on_one_forward(hip_lib_built):
     """retain_graph: the forward pre-zeroes the per-Gaussian gradient lines for ONE backward; a second backward on the same
     buffers has to start from zero as well (same gradients, not doubled), also when another forward ran in between."""

@@ -1,0 +1,93 @@
+"""A wide randomized parity sweep of the HIP rasterizer against the CPU oracle (tests/util.py's metric and budgets), beyond what the
+suite runs every time: random image sizes, Gaussian counts, scene kinds, views, near / far culls, scale modifiers and BEAM TABLES
+(uniform, Waymo-like, near-tie), the 3-D variant and -- every fourth scene -- the surfel variant.
+
+    python tools/parity_sweep.py [first_seed] [n_small] [n_mid] > profiles/rNN_parity_sweep.json
+
+Small scenes: P < 6000, W < 700 (the oracle takes a fraction of a second); mid scenes: P up to 60 k at up to 64 x 2650.
+The JSON: scenes run, entries compared, radii mismatches, soft / flip entries against what the budgets allow, and every scene whose
+parity() assertion failed (none is expected: a failure is a finding, not a crash of the sweep)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import lidargs_scenes as sc
+import util
+from util import (GRAD_KEYS_SR, GRAD_KEYS_SURFEL, hip_forward_backward, hip_surfel_forward_backward, oracle_forward_backward,
+                  oracle_surfel_forward_backward, parity, surfel_scene, surfel_upstream_grads)
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+n_small = int(sys.argv[2]) if len(sys.argv) > 2 else 240
+n_mid = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+failed, radii_total, radii_bad, scenes = [], 0, 0, []
+t0 = time.time()
+
+
+def one(seed, mid):
+    global radii_total, radii_bad
+    rng = np.random.default_rng(seed)
+    if mid:
+        H = int(rng.choice([16, 32, 64])); W = int(rng.choice([900, 1800, 2650])); P = int(rng.integers(20000, 60000))
+    else:
+        H = int(rng.choice([2, 3, 5, 16, 17, 32, 40, 64])); W = int(rng.integers(1, 700)); P = int(rng.integers(1, 6000))
+    kind = "shell" if rng.random() < 0.5 else "street"
+    beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
+    surfel = (seed % 4 == 3) and H >= 4
+    kw = dict(far=int(rng.choice([80, 30])), near=int(rng.choice([0, 2])), scale_modifier=float(rng.choice([1.0, 0.5, 2.5])))
+    desc = dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, variant="surfel" if surfel else "3d", **kw)
+    n0 = len(util.PARITY_LOG)
+    try:
+        if surfel:
+            scene = surfel_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)))
+            scene["beams"] = sc.beam_table(H, beams)
+            grads = surfel_upstream_grads(H, W, seed % 1000)
+            grads[1][5] = 0.0        # no gradient through the median depth (a selection: the suite bounds its near-tie pixels by count, tests/test_surfel_gpu.py)
+            hip = hip_surfel_forward_backward(scene, W, H, grads, **kw)
+            ref = oracle_surfel_forward_backward(scene, W, H, grads, **kw)
+            parity("color", hip["color"], ref["color"], verbose=False)
+            for k, name in enumerate(("depth", "alpha", "normal_x", "normal_y", "normal_z")):          # median / distortion: own rules in the suite
+                parity("others." + name, hip["others"][k], ref["others"][k], verbose=False)
+            keys = GRAD_KEYS_SURFEL
+        else:
+            scene = sc.make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)), beams=beams)
+            grads = sc.upstream_grads(H, W, seed % 1000)
+            hip = hip_forward_backward(scene, W, H, grads, **kw)
+            ref = oracle_forward_backward(scene, W, H, grads, **kw)
+            for k in ("color", "depth", "occ"):
+                parity(k, hip[k], ref[k], verbose=False)
+            keys = GRAD_KEYS_SR
+        nb = int((hip["radii"] != ref["radii"]).sum())
+        radii_total += int(ref["radii"].size); radii_bad += nb
+        desc["radii_mismatches"] = nb
+        for k in keys:
+            parity(k, hip[k], ref[k], verbose=False)
+    except AssertionError as e:
+        desc["failed"] = str(e)[:300]
+        failed.append(desc)
+    log = util.PARITY_LOG[n0:]
+    desc["entries"] = int(sum(s["n"] for s in log)); desc["soft"] = int(sum(s.get("soft", 0) for s in log)); desc["flips"] = int(sum(s.get("flips", 0) for s in log))
+    scenes.append(desc)
+
+
+for i in range(n_small):
+    one(first + i, False)
+for i in range(n_mid):
+    one(first + 100000 + i, True)
+log = util.PARITY_LOG
+out = {
+    "what": "tools/parity_sweep.py: HIP rasterizer (3-D and surfel variants, through the drop-in packages and the C ABI) against the CPU oracle on random scenes",
+    "scenes": len(scenes), "small": n_small, "mid": n_mid, "first_seed": first, "seconds": round(time.time() - t0, 1),
+    "by_beam_table": {b: sum(1 for s in scenes if s["beams"] == b) for b in ("uniform", "waymo", "neartie")},
+    "surfel_scenes": sum(1 for s in scenes if s["variant"] == "surfel"),
+    "parity_calls": len(log), "entries_compared": int(sum(s["n"] for s in log)),
+    "radii_compared": radii_total, "radii_mismatches": radii_bad,
+    "soft_entries": int(sum(s.get("soft", 0) for s in log)), "soft_allowed": int(sum(s.get("allowed", 0) for s in log)),
+    "flip_entries": int(sum(s.get("flips", 0) for s in log)), "flips_allowed": int(sum(s.get("allowed_flips", 0) for s in log)),
+    "worst_soft_fraction": max((s["soft_frac_used"] for s in log if s["n"] >= 4000), default=0.0),
+    "worst_flip_fraction": max((s["flip_frac_used"] for s in log if s["n"] >= 10000), default=0.0),
+    "budgets": {"rtol": util.RTOL, "soft_max": util.SOFT_MAX, "soft_frac": util.SOFT_FRAC, "flip_frac": util.FLIP_FRAC, "min_count": util.MIN_COUNT},
+    "failed_scenes": failed,
+    "scenes_with_radii_mismatches": [s for s in scenes if s.get("radii_mismatches")],
+}
+print(json.dumps(out, indent=1))
