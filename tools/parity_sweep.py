@@ -31,6 +31,10 @@ def one(seed, mid):
         H = int(rng.choice([16, 32, 64])); W = int(rng.choice([900, 1800, 2650])); P = int(rng.integers(20000, 60000))
     else:
         H = int(rng.choice([2, 3, 5, 16, 17, 32, 40, 64])); W = int(rng.integers(1, 700)); P = int(rng.integers(1, 6000))
+    if not mid and seed % 7 == 5:                                      # more than 256 tile columns: the 16-byte span records
+        W = int(rng.integers(4100, 4300)); H = int(rng.choice([2, 3, 16])); P = int(rng.integers(1, 3000))
+    if not mid and seed % 11 == 7:                                     # more than 256 rows: likewise
+        H = int(rng.choice([130, 272])); W = int(rng.integers(1, 200)); P = int(rng.integers(1, 3000))
     kind = "shell" if rng.random() < 0.5 else "street"
     beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
     surfel = (seed % 4 == 3) and H >= 4
@@ -52,11 +56,17 @@ def one(seed, mid):
         else:
             scene = sc.make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)), beams=beams)
             grads = sc.upstream_grads(H, W, seed % 1000)
-            hip = hip_forward_backward(scene, W, H, grads, **kw)
-            ref = oracle_forward_backward(scene, W, H, grads, **kw)
+            cov = None
+            if seed % 5 == 1:                                          # a precomputed 3-D covariance instead of scales / rotations
+                A = rng.normal(size=(P, 3, 3)) * float(scene["scales"].mean())
+                S = A @ np.transpose(A, (0, 2, 1)) + 1e-4 * np.eye(3)
+                cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1).astype(np.float32)
+                desc["cov3D_precomp"] = True
+            hip = hip_forward_backward(scene, W, H, grads, cov3D_precomp=cov, **kw)
+            ref = oracle_forward_backward(scene, W, H, grads, cov3D_precomp=cov, **kw)
             for k in ("color", "depth", "occ"):
                 parity(k, hip[k], ref[k], verbose=False)
-            keys = GRAD_KEYS_SR
+            keys = GRAD_KEYS_SR if cov is None else ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D")
         nb = int((hip["radii"] != ref["radii"]).sum())
         radii_total += int(ref["radii"].size); radii_bad += nb
         desc["radii_mismatches"] = nb
@@ -79,7 +89,8 @@ out = {
     "what": "tools/parity_sweep.py: HIP rasterizer (3-D and surfel variants, through the drop-in packages and the C ABI) against the CPU oracle on random scenes",
     "scenes": len(scenes), "small": n_small, "mid": n_mid, "first_seed": first, "seconds": round(time.time() - t0, 1),
     "by_beam_table": {b: sum(1 for s in scenes if s["beams"] == b) for b in ("uniform", "waymo", "neartie")},
-    "surfel_scenes": sum(1 for s in scenes if s["variant"] == "surfel"),
+    "surfel_scenes": sum(1 for s in scenes if s["variant"] == "surfel"), "cov3D_precomp_scenes": sum(1 for s in scenes if s.get("cov3D_precomp")),
+    "scenes_wider_than_4096": sum(1 for s in scenes if s["W"] > 4096), "scenes_taller_than_128": sum(1 for s in scenes if s["H"] > 128),
     "parity_calls": len(log), "entries_compared": int(sum(s["n"] for s in log)),
     "radii_compared": radii_total, "radii_mismatches": radii_bad,
     "soft_entries": int(sum(s.get("soft", 0) for s in log)), "soft_allowed": int(sum(s.get("allowed", 0) for s in log)),

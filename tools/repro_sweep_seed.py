@@ -25,3 +25,9 @@ for k in ("color", "depth", "occ"):
     d = np.abs(hip[k] - ref[k]); bad = np.argwhere(d > 1e-3 * (np.abs(ref[k]) + 1e-3 * np.abs(ref[k]).max()))
     print(k, "bad", len(bad), "of", d.size, "max", d.max(), "first", [tuple(b) for b in bad[:6]], [float(hip[k][tuple(b)]) for b in bad[:3]], [float(ref[k][tuple(b)]) for b in bad[:3]])
 print("radii mismatches", int((hip["radii"] != ref["radii"]).sum()), "visible", int((ref["radii"] > 0).sum()))
+from util import GRAD_KEYS_SR
+for k in GRAD_KEYS_SR:
+    r = ref[k].astype(np.float64); h = hip[k].astype(np.float64)
+    err = np.abs(h - r) / (np.abs(r) + 1e-3 * np.abs(r).max() + 1e-30)
+    rows = np.unique(np.argwhere(err > 1e-4)[:, 0])
+    print(f"{k:14s} n={r.size:8d} soft={(int(((err > 1e-4) & (err <= 1e-3)).sum())):5d} flips={int((err > 1e-3).sum()):4d} max={err.max():.2e} rows affected={len(rows)}")
