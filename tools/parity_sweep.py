@@ -35,10 +35,17 @@ def one(seed, mid):
         W = int(rng.integers(4100, 4300)); H = int(rng.choice([2, 3, 16])); P = int(rng.integers(1, 3000))
     if not mid and seed % 11 == 7:                                     # more than 256 rows: likewise
         H = int(rng.choice([130, 272])); W = int(rng.integers(1, 200)); P = int(rng.integers(1, 3000))
+    if not mid and seed % 17 == 4:                                     # more than 1024 beams: the preprocess reads the table from memory, not LDS
+        H = int(rng.choice([1025, 1100])); W = int(rng.integers(64, 200)); P = int(rng.integers(1, 3000))
+    if not mid and seed % 19 == 6:                                     # more than 65536 list tiles: 32-bit tile keys
+        H = 1100; W = 4800; P = int(rng.integers(1, 2000))
     kind = "shell" if rng.random() < 0.5 else "street"
     beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
     surfel = (seed % 4 == 3) and H >= 4
     kw = dict(far=int(rng.choice([80, 30])), near=int(rng.choice([0, 2])), scale_modifier=float(rng.choice([1.0, 0.5, 2.5])))
+    if not mid and seed % 13 == 3:                                     # footprints spanning a good part of the panorama
+        kw["scale_modifier"] = float(rng.choice([6.0, 12.0, 30.0]))
+    faint = (seed % 23 == 8)                                           # opacities around the 1/255 contribution threshold
     desc = dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, variant="surfel" if surfel else "3d", **kw)
     n0 = len(util.PARITY_LOG)
     try:
@@ -55,6 +62,9 @@ def one(seed, mid):
             keys = GRAD_KEYS_SURFEL
         else:
             scene = sc.make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)), beams=beams)
+            if faint:
+                scene["opacities"] = (scene["opacities"] * np.float32(0.008)).astype(np.float32)
+                desc["faint"] = True
             grads = sc.upstream_grads(H, W, seed % 1000)
             cov = None
             if seed % 5 == 1:                                          # a precomputed 3-D covariance instead of scales / rotations
@@ -91,6 +101,8 @@ out = {
     "by_beam_table": {b: sum(1 for s in scenes if s["beams"] == b) for b in ("uniform", "waymo", "neartie")},
     "surfel_scenes": sum(1 for s in scenes if s["variant"] == "surfel"), "cov3D_precomp_scenes": sum(1 for s in scenes if s.get("cov3D_precomp")),
     "scenes_wider_than_4096": sum(1 for s in scenes if s["W"] > 4096), "scenes_taller_than_128": sum(1 for s in scenes if s["H"] > 128),
+    "scenes_with_more_than_1024_beams": sum(1 for s in scenes if s["H"] > 1024), "scenes_with_more_than_65536_tiles": sum(1 for s in scenes if s["H"] * ((s["W"] + 15) // 16) // 4 > 65536),
+    "scenes_with_scale_modifier_6_or_more": sum(1 for s in scenes if s["scale_modifier"] >= 6), "scenes_with_faint_opacities": sum(1 for s in scenes if s.get("faint")),
     "parity_calls": len(log), "entries_compared": int(sum(s["n"] for s in log)),
     "radii_compared": radii_total, "radii_mismatches": radii_bad,
     "soft_entries": int(sum(s.get("soft", 0) for s in log)), "soft_allowed": int(sum(s.get("allowed", 0) for s in log)),
