@@ -21,6 +21,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 n_small = int(sys.argv[2]) if len(sys.argv) > 2 else 240
 n_mid = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 failed, radii_total, radii_bad, scenes = [], 0, 0, []
+filter_stats = [0, 0, 0]      # K2 radii compared, K2 radii that differ, markVisible flags that differ
 t0 = time.time()
 
 
@@ -77,6 +78,17 @@ def one(seed, mid):
             for k in ("color", "depth", "occ"):
                 parity(k, hip[k], ref[k], verbose=False)
             keys = GRAD_KEYS_SR if cov is None else ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D")
+            if cov is None:                                            # K2 (visible_filter) and markVisible on the same scene: radii / flags bit for bit
+                from diff_lidargs_rasterization import GaussianRasterizer
+                from oracle import lgo
+                st = util.to_torch(scene)
+                rast = GaussianRasterizer(util.make_settings(st, W, H, kw["far"], kw["near"], kw["scale_modifier"]))
+                fr = rast.visible_filter(means3D=st["means3D"], scales=st["scales"], rotations=st["rotations"]).cpu().numpy()
+                fref = lgo.visible_filter(scene["means3D"], scene["scales"], scene["rotations"], scene["viewmatrix"], scene["beams"], W, H,
+                                          scale_modifier=kw["scale_modifier"], far=kw["far"], near=kw["near"])
+                filter_stats[0] += int(fref.size); filter_stats[1] += int((fr != fref).sum())
+                mv = rast.markVisible(st["means3D"]).cpu().numpy()
+                filter_stats[2] += int((mv != lgo.mark_visible(scene["means3D"], scene["viewmatrix"])).sum())
         nb = int((hip["radii"] != ref["radii"]).sum())
         radii_total += int(ref["radii"].size); radii_bad += nb
         desc["radii_mismatches"] = nb
@@ -105,6 +117,7 @@ out = {
     "scenes_with_scale_modifier_6_or_more": sum(1 for s in scenes if s["scale_modifier"] >= 6), "scenes_with_faint_opacities": sum(1 for s in scenes if s.get("faint")),
     "parity_calls": len(log), "entries_compared": int(sum(s["n"] for s in log)),
     "radii_compared": radii_total, "radii_mismatches": radii_bad,
+    "visible_filter_radii_compared": filter_stats[0], "visible_filter_radii_mismatches": filter_stats[1], "mark_visible_mismatches": filter_stats[2],
     "soft_entries": int(sum(s.get("soft", 0) for s in log)), "soft_allowed": int(sum(s.get("allowed", 0) for s in log)),
     "flip_entries": int(sum(s.get("flips", 0) for s in log)), "flips_allowed": int(sum(s.get("allowed_flips", 0) for s in log)),
     "worst_soft_fraction": max((s["soft_frac_used"] for s in log if s["n"] >= 4000), default=0.0),
