@@ -282,6 +282,45 @@ def test_narrow_images_where_a_tile_spans_half_the_panorama(H, W, P, kind, seed,
         parity(k, hip[k], ref[k])
 
 
+def test_non_contiguous_inputs_and_wrong_dtypes(hip_lib_built):
+    """The reference binding calls `.contiguous().data<float>()` on every input (R3/rasterize_points.cu:64-90): strided views are
+    accepted (same image bit for bit, gradients arrive in the views' own layout), anything but float32 is refused."""
+    import torch
+    from diff_lidargs_rasterization import GaussianRasterizer
+    from util import make_settings, to_torch
+    P, H, W, seed = 6000, 16, 512, 41
+    scene = sc.make_scene("street", P, H, seed, random_view=True)
+    st = to_torch(scene)
+    rast = GaussianRasterizer(make_settings(st, W, H))
+    gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, seed))
+
+    def run(m3, col, op, scl, rot):
+        m2 = torch.zeros((P, 4), device="cuda", requires_grad=True)
+        color, depth, occ, radii = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=scl, rotations=rot)
+        torch.autograd.backward([color, depth, occ], [gc, gd, go])
+        return color.detach(), depth.detach(), occ.detach(), radii
+
+    plain = [st[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")]
+    ref = run(*plain)
+    wide = torch.zeros((P, 9), device="cuda"); wide[:, 1:4] = st["means3D"]; wide[:, 5:8] = st["scales"]
+    wide.requires_grad_(True)
+    colT = st["colors"].t().contiguous().requires_grad_(True)                       # [2, P]: its transpose is a strided [P, 2] view
+    rot2 = torch.zeros((2 * P, 4), device="cuda"); rot2[::2] = st["rotations"]; rot2.requires_grad_(True)
+    op = st["opacities"].clone().requires_grad_(True)
+    got = run(wide[:, 1:4], colT.t(), op, wide[:, 5:8], rot2[::2])
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # float atomics order the sums differently from launch to launch: compare at the parity tolerance
+    parity("d means3D (strided view)", wide.grad[:, 1:4].cpu().numpy(), plain[0].grad.cpu().numpy())
+    parity("d scales (strided view)", wide.grad[:, 5:8].cpu().numpy(), plain[3].grad.cpu().numpy())
+    parity("d colors (transposed)", colT.grad.t().cpu().numpy(), plain[1].grad.cpu().numpy())
+    parity("d rotations (every other row)", rot2.grad[::2].cpu().numpy(), plain[4].grad.cpu().numpy())
+    assert float(rot2.grad[1::2].abs().max()) == 0.0 and float(wide.grad[:, 0].abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="Float"):
+        rast(means3D=st["means3D"].double(), means2D=torch.zeros((P, 4), device="cuda"), opacities=st["opacities"], colors_precomp=st["colors"],
+             scales=st["scales"], rotations=st["rotations"])
+
+
 def test_backward_twice_on_one_forward(hip_lib_built):
     """retain_graph: the forward pre-zeroes the per-Gaussian gradient lines for ONE backward; a second backward on the same
     buffers has to start from zero as well (same gradients, not doubled), also when another forward ran in between."""
