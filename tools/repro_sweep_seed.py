@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests"))
 import numpy as np
 import lidargs_scenes as sc
 from util import hip_forward_backward, oracle_forward_backward
-seed = int(sys.argv[1]); mid = seed >= 100000
+seed = int(sys.argv[1]); mid = (sys.argv[2] == "mid") if len(sys.argv) > 2 else seed >= 100000      # python tools/repro_sweep_seed.py <seed> [small|mid]
 rng = np.random.default_rng(seed)
 if mid:
     H = int(rng.choice([16, 32, 64])); W = int(rng.choice([900, 1800, 2650])); P = int(rng.integers(20000, 60000))
@@ -35,7 +35,8 @@ from diff_lidargs_rasterization import _C
 print(dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, **kw), _C.last_counters())
 for k in ("color", "depth", "occ"):
     d = np.abs(hip[k] - ref[k]); bad = np.argwhere(d > 1e-3 * (np.abs(ref[k]) + 1e-3 * np.abs(ref[k]).max()))
-    print(k, "bad", len(bad), "of", d.size, "max", d.max(), "first", [tuple(b) for b in bad[:6]], [float(hip[k][tuple(b)]) for b in bad[:3]], [float(ref[k][tuple(b)]) for b in bad[:3]])
+    print(k, "bad", len(bad), "of", d.size, "max", d.max(), "first", [tuple(int(x) for x in b) for b in bad[:6]], [float(hip[k][tuple(b)]) for b in bad[:3]], [float(ref[k][tuple(b)]) for b in bad[:3]],
+          "rows of the bad pixels:", sorted(set(int(b[1]) for b in bad)) if len(bad) else [])
 print("radii mismatches", int((hip["radii"] != ref["radii"]).sum()), "visible", int((ref["radii"] > 0).sum()))
 from util import GRAD_KEYS_SR
 for k in GRAD_KEYS_SR:
