@@ -1,14 +1,19 @@
 """bench.py -- LiDAR range-view frames/s (forward+backward) of the MI355X-native rasterizer.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--shard both|shells|wedges] [--graph] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts its own N ranks, one process per GPU, by re-executing
+itself under torch.distributed.run on 127.0.0.1; with fewer than N devices it says so ("needs N HIP devices, found M").
+
 One "step" = one frame: GaussianRasterizer.forward + .backward with non-zero upstream gradients on
 colour, depth and occupancy, inputs already resident in HBM (BASELINE.json metric).
-N = 1: the whole scene on one GPU.  N > 1: the SAME scene (strong scaling), Gaussians sharded by
-range shell across the ranks: RCCL all-gather of the per-shell transmittance plane, all-gather of the
-W x H x 5 partial planes, reduce-scatter of the packed per-Gaussian gradient rows (lidargs_dist.py).
+N = 1: the whole scene on one GPU.  N > 1: the SAME scene (strong scaling) cut BOTH ways, one after the other in the same job
+(lidargs_dist.py): range shells -- the north star's cut: RCCL all-gather of the per-shell transmittance plane, all-gather of the
+W x H x 5 partial planes, all-to-all of the packed per-Gaussian gradient rows -- and column wedges (every rank renders its own pixel
+columns: image all-gather + gradient all-to-all).  `value` is the faster cut's (named in config.sharding), `cuts` holds both.
+`--workload cfg1` (a 10 k-Gaussian frame, host-bound when run eagerly) carries the same frame as a HIP-graph replay in `graph_replay`.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     for the longest single launch of the frame (k_render_backward on the headline workload): ALGORITHMIC bytes of
