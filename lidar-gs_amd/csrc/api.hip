@@ -474,14 +474,20 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     const bool key16 = grid.num_tiles() <= 65536 && !key32;
     const uint32_t* point_list = bin.val_a;
     if (R) {
+        // the sorted lists are wanted on the a side (the backward finds them there whatever the pass count was): a sort that will end on
+        // the other side -- an odd number of passes: images of at most 256 list tiles -- gets its input there, instead of two copies behind it
+        const int bits = ceil_log2((uint32_t)grid.num_tiles());
+        const bool flip = lg::radix_sort_result_side(R, bits) != 0;
+        uint32_t* const k_in = flip ? bin.tile_b : bin.tile_a; uint32_t* const k_out = flip ? bin.tile_a : bin.tile_b;
+        uint32_t* const v_in = flip ? bin.val_b : bin.val_a; uint32_t* const v_out = flip ? bin.val_a : bin.val_b;
         lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, pp.compact != 0, (size_t)P, grid,
-                                  bin.tile_a, bin.val_a, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16);
+                                  k_in, v_in, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
-        const int bits = ceil_log2((uint32_t)grid.num_tiles());
-        const int bside = key16 ? lg::launch_radix_sort_pairs16(reinterpret_cast<uint16_t*>(bin.tile_a), reinterpret_cast<uint16_t*>(bin.tile_b), bin.val_a, bin.val_b, R,
-                                                                bits, bin.scratch, stream, R_dev)
-                                : lg::launch_radix_sort_pairs(bin.tile_a, bin.tile_b, bin.val_a, bin.val_b, R, bits, bin.scratch, stream, 0, R_dev);
+        const int side = key16 ? lg::launch_radix_sort_pairs16(reinterpret_cast<uint16_t*>(k_in), reinterpret_cast<uint16_t*>(k_out), v_in, v_out, R,
+                                                               bits, bin.scratch, stream, R_dev)
+                               : lg::launch_radix_sort_pairs(k_in, k_out, v_in, v_out, R, bits, bin.scratch, stream, 0, R_dev);
+        const int bside = side ^ (flip ? 1 : 0);                       // 1: the result is NOT on the a side after all (never, by radix_sort_result_side)
         if (bside) {   // keep the backward's view independent of the pass count: result always in (tile_a, val_a)
             LG_HIP(hipMemcpyAsync(bin.tile_a, bin.tile_b, R * (key16 ? sizeof(uint16_t) : sizeof(uint32_t)), hipMemcpyDeviceToDevice, stream));
             LG_HIP(hipMemcpyAsync(bin.val_a, bin.val_b, R * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));

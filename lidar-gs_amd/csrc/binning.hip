@@ -633,6 +633,17 @@ static int radix_sort_pairs_t(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* v
     return cur;
 }
 
+// Where launch_radix_sort_pairs[16](..., end_bit, max_bits = default) without a tail will leave the sorted pairs: 0 = the a side, 1 = the
+// b side (an odd number of passes of the general form; the single-launch form brings them home itself).  A caller that wants them
+// on a given side produces the input on the other one when this says 1 (api.hip: the emit of a one-pass tile sort writes to the b side).
+int radix_sort_result_side(size_t n, int end_bit) {
+    if (n == 0 || end_bit <= 0) return 0;
+    static const int small_off = [] { const char* e = getenv("LIDARGS_NO_SMALL_SORT"); return e ? atoi(e) : 0; }();
+    static const size_t small_max = [] { const char* e = getenv("LIDARGS_SMALL_SORT_MAX"); const long v = e ? atol(e) : (long)SMALL_SORT_DEFAULT;
+                                         return (size_t)(v < 0 ? 0 : (v > (long)SMALL_SORT_MAX ? (long)SMALL_SORT_MAX : v)); }();
+    if (n <= small_max && !small_off) return 0;
+    return ((end_bit + SORT_RADIX_BITS - 1) / SORT_RADIX_BITS) & 1;
+}
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s, int max_bits, const uint32_t* n_dev, int scratch_bits, bool vals_are_positions,
                             RadixTail tail, int begin_bit, const KeyBias* bias) {

@@ -363,6 +363,7 @@ void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, in
                         uint32_t* zero = nullptr, int n_zero = 0);
 int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit, uint32_t* scratch, hipStream_t s,
                               const uint32_t* n_dev = nullptr);
+int radix_sort_result_side(size_t n, int end_bit);   // side the two functions above (default digit width, no tail) leave the result on
 
 #ifdef __HIPCC__
 // blockIdx -> (patch, segment): segment-fastest, with S ODD.  Workgroups are dealt round-robin to the 8 XCDs (b % 8) and
