@@ -234,9 +234,11 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         rx = (int)ceilf(3.f * my_radius / pp.tan_col_step);            // :362
 
         // reference rect in 16x1 tiles (R3/cr/auxiliary.h:80-92); x truncates, y rounds
+        // xmax is "p.x + rx + BLOCK_X - 1" evaluated left to right in fp32: + 16 then - 1 are two roundings, and for p.x one ulp
+        // under a tile edge the first one ties up to the edge (p.x = 15.999998, rx = 1: 32.999998 -> 33), which + 15.f does not
         const int gx = pp.tiles_x, gy = H;
         const int xmin = min(gx, max(0, (int)((p_c - (float)rx) / 16.f)));
-        const int xmax = min(gx, max(0, (int)((p_c + (float)rx + 15.f) / 16.f)));
+        const int xmax = min(gx, max(0, (int)((((p_c + (float)rx) + 16.f) - 1.f) / 16.f)));
         const int ymin = min(gy, max(0, (int)roundf(p_r - (float)ry)));
         const int ymax = min(gy, max(0, (int)fmaxf(roundf(p_r + (float)ry), roundf(p_r) + 1.f)));
         if ((xmax - xmin) * (ymax - ymin) == 0) break;

@@ -282,6 +282,29 @@ def test_narrow_images_where_a_tile_spans_half_the_panorama(H, W, P, kind, seed,
         parity(k, hip[k], ref[k])
 
 
+def test_rect_upper_tile_edge_takes_two_roundings(hip_lib_built):
+    """`getRect_lidar`'s upper column bound is `(int)((p.x + rx + BLOCK_X - 1) / BLOCK_X)` (R3/cr/auxiliary.h:88), evaluated left to
+    right in fp32: `+ 16` and `- 1` are two roundings.  For p.x two ulps under column 16 with rx = 1 the first one ties up to 33
+    (32.999998 is not a float), so the rect reaches tile 1 and the Gaussian is blended into column 16, the pixel nearest to its centre;
+    `+ 15.f` in one step gives 31.999998 and leaves tile 1 out.  The same happens where p.x + rx + 16 crosses 64, 128, ...
+    tools/dist_sweep.py found it on one Gaussian of one frame in ~21 k random scenes (round 3, seed 500751); this scene puts a mean
+    there by construction."""
+    H, W = 16, 31
+    scene = sc.make_scene("shell", 4, H, 3, random_view=False)
+    scene["means3D"][2, 1] = np.float32(-4.874938011169434)
+    grads = sc.upstream_grads(H, W, 3)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    p_c, p_r = ref["fwd"].array("means2D").reshape(-1, 2)[2]
+    assert p_c == np.float32(15.999998092651367) and tuple(ref["fwd"].array("radii_xy").reshape(-1, 2)[2]) == (1, 1)
+    row = int(round(float(p_r)))
+    assert ref["occ"][0, row, 16] > 0.3, "the Gaussian must reach column 16 on the reference side"
+    hip = hip_forward_backward(scene, W, H, grads)
+    assert np.array_equal(hip["radii"], ref["radii"])
+    assert abs(hip["occ"][0, row, 16] - ref["occ"][0, row, 16]) < 1e-5      # one pixel: inside any outlier budget, so checked by name
+    for k in ("color", "depth", "occ") + GRAD_KEYS_SR:
+        parity(k, hip[k], ref[k])
+
+
 def test_non_contiguous_inputs_and_wrong_dtypes(hip_lib_built):
     """The reference binding calls `.contiguous().data<float>()` on every input (R3/rasterize_points.cu:64-90): strided views are
     accepted (same image bit for bit, gradients arrive in the views' own layout), anything but float32 is refused."""

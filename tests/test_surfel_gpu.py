@@ -77,6 +77,18 @@ def test_surfel_ragged_width_and_height():
     _check(surfel_scene("shell", 2500, 18, 9), 500, 18, 9)
 
 
+def test_surfel_rect_upper_tile_edge_takes_two_roundings():
+    """R2/cr/auxiliary.h:107 has the same `p.x + rx + BLOCK_X - 1` as the 3-D rasterizer: two fp32 roundings (see
+    test_parity_gpu.py::test_rect_upper_tile_edge_takes_two_roundings).  A surfel centred two ulps under column 16."""
+    H, W = 16, 31
+    scene = surfel_scene("shell", 4, H, 3, random_view=False)
+    scene["means3D"][2, 1] = np.float32(-4.874938011169434)
+    hip, ref = _check(scene, W, H, 3)
+    assert ref["fwd"].array("means2D").reshape(-1, 2)[2, 0] == np.float32(15.999998092651367)
+    assert np.array_equal(hip["radii"], ref["radii"])
+    assert ref["others"][1][9, 16] > 0.05 and abs(hip["others"][1][9, 16] - ref["others"][1][9, 16]) < 1e-5   # the one pixel it covers
+
+
 def test_surfel_config5_shape_crop():
     # config 5 geometry (64 x 2650) with a Gaussian count the oracle finishes in seconds
     _check(surfel_scene("shell", 20_000, 64, 11), 2650, 64, 11)
