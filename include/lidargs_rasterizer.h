@@ -440,6 +440,13 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
  * T-only pass did not run), [7]=segments per list.  Values [1], [3], [6] are read back on demand. */
 int lidargs_last_counters(long long* out, int n);
 
+/* Test hook (no reference counterpart as an entry point): the tile rect the two preprocess kernels give a Gaussian -- getRect_lidar,
+ * R3/cr/auxiliary.h:80-92 (surfel = 0) and R2/cr/auxiliary.h:99-112 (surfel = 1) -- evaluated by the SAME device function on n
+ * caller-supplied inputs: p_cr float[n][2] = (p.x, p.y), r_xy int[n][2] = (rx, ry), a tiles_x x tiles_y grid of 16x1 tiles;
+ * rects int[n][4] = (xmin, ymin, xmax, ymax).  All device pointers.  tests/ feed it inputs within a few ulps of every truncation and
+ * rounding boundary (which one random Gaussian in 1e8 hits) and require bit equality with the oracle's getRect. */
+int lidargs_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, int tiles_x, int tiles_y, int* rects, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -710,6 +710,17 @@ int lidargs_mark_visible(int P, const float* means3D, const float* viewmatrix, c
     return 0;
 }
 
+int lidargs_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, int tiles_x, int tiles_y, int* rects, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    if (n < 0 || tiles_x < 0 || tiles_y < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "debug_rects: bad size%s");
+    if (n == 0) return 0;
+    if (!p_cr || !r_xy || !rects) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "debug_rects: NULL required pointer%s");
+    lg::launch_debug_rects(n, surfel, p_cr, r_xy, tiles_x, tiles_y, rects, stream);
+    LG_STAGE_CHECK("debug rects");
+    return 0;
+}
+
 int lidargs_forward_shell(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
                           lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
                           const float* means3D, const float* colors_precomp, const float* opacities, const float* scales,

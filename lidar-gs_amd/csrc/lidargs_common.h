@@ -161,6 +161,25 @@ struct BinView {
     uint32_t work_cap;                   // items per region
 };
 
+// ---- the reference's tile rect of one Gaussian, in 16x1 tiles ------------------------------------------------------------------
+// R3/cr/auxiliary.h:80-92 getRect_lidar (3-D variant): x truncates, y rounds half away from zero.  Every operation in the order the
+// expression there is written: `p.x + rx + BLOCK_X - 1` is ((p.x + rx) + 16) - 1 in fp32, TWO roundings -- for p.x + rx an ulp
+// under 17, 49, 113, ... the first one ties up to the next integer (16.999998 + 16 -> 33) and the rect reaches one tile further than
+// with + 15.f in one step (round 3).  tests/ hold it bit for bit on adversarial inputs through lidargs_debug_rects.
+__device__ __forceinline__ void rect_lidar(float p_c, float p_r, int rx, int ry, int gx, int gy, int& xmin, int& ymin, int& xmax, int& ymax) {
+    xmin = min(gx, max(0, (int)((p_c - (float)rx) / 16.f)));
+    xmax = min(gx, max(0, (int)((((p_c + (float)rx) + 16.f) - 1.f) / 16.f)));
+    ymin = min(gy, max(0, (int)roundf(p_r - (float)ry)));
+    ymax = min(gy, max(0, (int)fmaxf(roundf(p_r + (float)ry), roundf(p_r) + 1.f)));
+}
+// R2/cr/auxiliary.h:99-112 (surfel variant): x and ymin truncate, ymax = round(p.y + ry)
+__device__ __forceinline__ void rect_surfel(float p_c, float p_r, int rx, int ry, int gx, int gy, int& xmin, int& ymin, int& xmax, int& ymax) {
+    xmin = min(gx, max(0, (int)((p_c - (float)rx) / 16.f)));
+    xmax = min(gx, max(0, (int)((((p_c + (float)rx) + 16.f) - 1.f) / 16.f)));
+    ymin = min(gy, max(0, (int)(p_r - (float)ry)));
+    ymax = min(gy, max(0, (int)roundf(p_r + (float)ry)));
+}
+
 // Work list of the backward blend.  A blend launch over (patch, segment) slots carries patches x S single-wave workgroups of which,
 // on the BASELINE frames, five in six (cfg4: 49 in 50) have nothing to walk (behind the list's end or the patch's saturation point): each
 // costs a dispatch (~0.22 ns, tools/micro/empty_wg.hip) and a wave slot for the round trip of the three loads it decides on.  The
@@ -314,6 +333,7 @@ void launch_preprocess(const PreprocessParams& pp, const float* means3D, const f
                        const float* opacities, const float* colors, const float* cov3D_precomp, const float* beams,
                        int* radii, int* radii_xy, GeomView g, const ImgView* tables, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
+void launch_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, int gx, int gy, int* rects, hipStream_t s);   // test hook
 
 void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const float* g_col, const float* g_op, const float* g_sc,
                             const float* g_rot, const int* idx, float* rows, hipStream_t s);

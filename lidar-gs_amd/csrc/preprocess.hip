@@ -234,13 +234,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         rx = (int)ceilf(3.f * my_radius / pp.tan_col_step);            // :362
 
         // reference rect in 16x1 tiles (R3/cr/auxiliary.h:80-92); x truncates, y rounds
-        // xmax is "p.x + rx + BLOCK_X - 1" evaluated left to right in fp32: + 16 then - 1 are two roundings, and for p.x one ulp
-        // under a tile edge the first one ties up to the edge (p.x = 15.999998, rx = 1: 32.999998 -> 33), which + 15.f does not
         const int gx = pp.tiles_x, gy = H;
-        const int xmin = min(gx, max(0, (int)((p_c - (float)rx) / 16.f)));
-        const int xmax = min(gx, max(0, (int)((((p_c + (float)rx) + 16.f) - 1.f) / 16.f)));
-        const int ymin = min(gy, max(0, (int)roundf(p_r - (float)ry)));
-        const int ymax = min(gy, max(0, (int)fmaxf(roundf(p_r + (float)ry), roundf(p_r) + 1.f)));
+        int xmin, ymin, xmax, ymax;
+        rect_lidar(p_c, p_r, rx, ry, gx, gy, xmin, ymin, xmax, ymax);
         if ((xmax - xmin) * (ymax - ymin) == 0) break;
 
         live = true;
@@ -421,6 +417,20 @@ __global__ void k_mark_visible(int P, const float* __restrict__ means3D, const f
 
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s) {
     hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
+
+// Test hook (lidargs_debug_rects): the rect arithmetic of the two preprocess kernels on caller-supplied (p_c, p_r, rx, ry), so that
+// tests can put millions of inputs within an ulp of every truncation / rounding boundary -- one random Gaussian in 1e8 lands there.
+__global__ void k_debug_rects(int n, int surfel, const float2* __restrict__ p, const int2* __restrict__ r, int gx, int gy, int4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int xmin, ymin, xmax, ymax;
+    if (surfel) rect_surfel(p[i].x, p[i].y, r[i].x, r[i].y, gx, gy, xmin, ymin, xmax, ymax);
+    else rect_lidar(p[i].x, p[i].y, r[i].x, r[i].y, gx, gy, xmin, ymin, xmax, ymax);
+    out[i] = make_int4(xmin, ymin, xmax, ymax);
+}
+void launch_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, int gx, int gy, int* rects, hipStream_t s) {
+    k_debug_rects<<<(n + 255) / 256, 256, 0, s>>>(n, surfel, (const float2*)p_cr, (const int2*)r_xy, gx, gy, (int4*)rects);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -152,12 +152,9 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         rx = (int)ceilf(fmaxf(fmaxf(ax, bx), 1.0f));
         ry = (int)ceilf(fmaxf(fmaxf(ay, by), 1.0f));
         // R2/cr/auxiliary.h:99-112: x and ymin truncate, ymax = round(p.y + ry)
-        // (xmax: + 16 then - 1, two fp32 roundings as in the expression there; see preprocess.hip)
         const int gx = a.tiles_x, gy = a.H;
-        const int xmin = min(gx, max(0, (int)((pim.x - (float)rx) / 16.f)));
-        const int xmax = min(gx, max(0, (int)((((pim.x + (float)rx) + 16.f) - 1.f) / 16.f)));
-        const int ymin = min(gy, max(0, (int)(pim.y - (float)ry)));
-        const int ymax = min(gy, max(0, (int)roundf(pim.y + (float)ry)));
+        int xmin, ymin, xmax, ymax;
+        rect_surfel(pim.x, pim.y, rx, ry, gx, gy, xmin, ymin, xmax, ymax);
         if ((xmax - xmin) * (ymax - ymin) == 0) break;
         live = true;
         out_radius = max(rx, ry);

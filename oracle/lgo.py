@@ -192,6 +192,17 @@ def visible_filter(means3D, scales, rotations, viewmatrix, beams, W, H, scale_mo
     return radii
 
 
+def rects(p_cr, r_xy, tiles_x, tiles_y, surfel=False):
+    """getRect_lidar of either variant on caller-supplied (p.x, p.y), (rx, ry): int32 [n, 4] = (xmin, ymin, xmax, ymax)."""
+    p = np.ascontiguousarray(p_cr, dtype=np.float32).reshape(-1, 2)
+    r = np.ascontiguousarray(r_xy, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((p.shape[0], 4), np.int32)
+    fn = lib().sfo_rects if surfel else lib().lgo_rects
+    fn(C.c_int(p.shape[0]), p.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.c_int(tiles_x), C.c_int(tiles_y),
+       out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def pixel_dirs(W, H, beams):
     """[H,W,3] unit ray of every pixel as the blend kernels evaluate it (R3/cr/forward.cu:589-591)."""
     beams = _f32(beams)

@@ -165,6 +165,15 @@ static void get_rect_lidar(float px, float py, int rx, int ry, unsigned gx, unsi
     *ymax = umin_u(gy, (unsigned)imax_i(0, (int)(a > b ? a : b)));
 }
 
+/* get_rect_lidar on n caller-supplied inputs: what tests/ hold lidargs_debug_rects (the device function) against, bit for bit */
+void lgo_rects(int n, const float* p_cr, const int* r_xy, int gx, int gy, int* rects) {
+    for (int i = 0; i < n; i++) {
+        unsigned xmin, ymin, xmax, ymax;
+        get_rect_lidar(p_cr[2 * i], p_cr[2 * i + 1], r_xy[2 * i], r_xy[2 * i + 1], (unsigned)gx, (unsigned)gy, &xmin, &ymin, &xmax, &ymax);
+        rects[4 * i] = (int)xmin; rects[4 * i + 1] = (int)ymin; rects[4 * i + 2] = (int)xmax; rects[4 * i + 3] = (int)ymax;
+    }
+}
+
 /* cr/forward.cu:216-253 computeCov3D (quaternion NOT normalised, :228) */
 static void compute_cov3d(const float* scale, float mod, const float* rot, float* cov3D) {
     m3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);

@@ -67,6 +67,15 @@ static void sf_get_rect(float px, float py, int rx, int ry, unsigned gx, unsigne
     *ymax = sf_umin(gy, (unsigned)sf_imax(0, (int)(roundf((py + ry)))));
 }
 
+/* sf_get_rect on n caller-supplied inputs (tests/: against lidargs_debug_rects with surfel = 1) */
+void sfo_rects(int n, const float* p_cr, const int* r_xy, int gx, int gy, int* rects) {
+    for (int i = 0; i < n; i++) {
+        unsigned xmin, ymin, xmax, ymax;
+        sf_get_rect(p_cr[2 * i], p_cr[2 * i + 1], r_xy[2 * i], r_xy[2 * i + 1], (unsigned)gx, (unsigned)gy, &xmin, &ymin, &xmax, &ymax);
+        rects[4 * i] = (int)xmin; rects[4 * i + 1] = (int)ymin; rects[4 * i + 2] = (int)xmax; rects[4 * i + 3] = (int)ymax;
+    }
+}
+
 static sf3 sf_point4x3(sf3 p, const float* m) {
     sf3 t = { m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
               m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] };
