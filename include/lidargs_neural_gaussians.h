@@ -91,6 +91,21 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
                              const float* dL_drot, const float* dL_dneural_opacity, float* dL_danchor_feat, float* dL_danchor, float* dL_doffset,
                              float* dL_dscaling_in, float* partials, char* scratch, size_t scratch_bytes, void* stream);
 
+/* model.W2T of all four MLPs in one launch: W2[m] = the second Linear's weight [dout_m][32] (device pointers, host array of four);
+ * out f32[320 k] = [32][k] | [32][7k] | [32][k] | [32][k], i.e. model.W2T[m] = out + 32 * (0, k, 8k, 9k)[m]. */
+int lidargs_ng_transpose_w2(int n_offsets, const float* const* W2, float* out, void* stream);
+
+/* The sixteen parameter gradients out of lidargs_ng_backward_mfma's partials, in two small launches (sum over the waves + unpack; what the
+ * binding did with a framework reduction, four concatenations and four strided copies).  din[m] = input width of MLP m's first layer
+ * (35 or 36: 32 features + 3 view components [+ 1 distance]); waves as lidargs_ng_backward_partials reported.
+ * grads f32[lidargs_ng_weight_grad_floats(k, din)], for m = opacity, covariance, colour, ray-drop in turn:
+ *   dW1_m [32][din_m] | db1_m [32] | dW2_m [dout_m][32] | db2_m [dout_m],   dout = k, 7k, k, k
+ * -- the layouts of torch.nn.Linear's weight and bias (gaussian_model.py:113-142), so each block is that parameter's .grad.
+ * stage: lidargs_ng_weight_grad_stage_floats(k, din) floats of scratch (the first launch's row-group sums).  Sums are taken in a fixed order (deterministic). */
+int lidargs_ng_weight_grad_floats(int n_offsets, const int* din);
+int lidargs_ng_weight_grad_stage_floats(int n_offsets, const int* din);
+int lidargs_ng_reduce_weight_grads(int n_offsets, const int* din, int waves, const float* partials, float* grads, float* stage, void* stream);
+
 /* Densification statistics -- GaussianModel.training_statis (scene/gaussian_model.py:599-622), in place, one launch chain, no host
  * read.  anchor_visible_mask u8[N]; offset_selection_mask u8[n*k] and neural_opacity f32[n*k] in visible-anchor order (what
  * generate_neural_gaussians returned); update_filter u8[M] (radii > 0) and viewspace_grad f32[M*4] (means2D.grad) in the order of

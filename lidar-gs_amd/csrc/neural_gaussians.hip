@@ -829,6 +829,81 @@ __global__ void __launch_bounds__(256) k_ng_stats(int N, int K, const uint32_t* 
     anchor_demon[i] += 1.f;                                             // :608
 }
 
+
+// The weight gradients out of the backward's partial sums, in one launch: sum over the persistent waves' rows and unpack the tiles
+// into the sixteen parameter gradients (the layout of include/lidargs_neural_gaussians.h).  Before: a framework reduction over
+// [1024][10368] in 48 us, four concatenations and four strided copies (~90 us of a 0.55-ms backward).  One thread per OUTPUT element
+// (neighbours in the output are neighbours in a tile row, so a wave's 64 loads of a row are a few lines); the four waves of a
+// workgroup and the 32 row groups of the grid take 8 rows each, eight loads in flight, and meet in a fixed
+// order (LDS, then a second tiny launch over the row groups): deterministic sums.  One workgroup per 64 outputs walking all
+// 1024 rows took 42 us whether with 4 waves x 8 loads or 16 x 16 in flight (105 workgroups on 256 CUs); so did the framework's.
+struct NgGradMap { int k, nc, per_wave, din[4], base[4]; int total; };   // base[m]: first output float of MLP m's block
+__device__ __forceinline__ int ng_grad_source(const NgGradMap& g, int j) {
+    int m = 3;
+    if (j < g.base[1]) m = 0; else if (j < g.base[2]) m = 1; else if (j < g.base[3]) m = 2;
+    const int dout = m == 1 ? 7 * g.k : g.k, din = g.din[m];
+    int r = j - g.base[m];
+    if (r < 32 * din) {                                                // dW1_m[t][q]
+        const int t = r / din, q = r - t * din;
+        return q < 32 ? m * 1024 + t * 32 + q : 4 * 1024 + t * 32 + 8 * m + (q - 32);
+    }
+    r -= 32 * din;
+    if (r < 32) return 4 * 1024 + r * 32 + 8 * m + 4;                  // db1_m[t]: input 36 is the constant 1
+    r -= 32;
+    const int w2_tile = m == 0 ? 5 : (m == 1 ? 6 : (m == 2 ? 6 + g.nc : 7 + g.nc));
+    if (r < dout * 32) return w2_tile * 1024 + r;                      // dW2_m[o][t] = row o of its tile(s)
+    r -= dout * 32;
+    const int col0 = m == 0 ? 0 : (m == 1 ? g.k : (m == 2 ? 8 * g.k : 9 * g.k));
+    return (8 + g.nc) * 1024 + col0 + r;                               // db2_m[o]
+}
+constexpr int NG_REDUCE_SPLIT = 32;                                     // row groups of the first stage (its grid: column groups x this)
+__global__ void __launch_bounds__(256) k_ng_reduce_weight_grads(const NgGradMap g, int waves, const float* __restrict__ partials, float* __restrict__ stage) {
+    constexpr int W = 4, U = 8;                                        // waves per workgroup, loads in flight per wave
+    __shared__ float part[W][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool live = j < g.total;
+    const int src = live ? ng_grad_source(g, j) : 0;
+    const int rows = (waves + NG_REDUCE_SPLIT * W - 1) / (NG_REDUCE_SPLIT * W);
+    const int r0 = min(waves, ((int)blockIdx.y * W + w) * rows), r1 = min(waves, r0 + rows);
+    const float* p = partials + (size_t)r0 * g.per_wave + src;
+    float acc = 0.f;
+    int r = r0;
+    for (; r + U <= r1; r += U) {                                      // a row every 41 KB: the loads are independent, only their sum is ordered
+        float v[U];
+#pragma unroll
+        for (int q = 0; q < U; q++) v[q] = p[(size_t)q * g.per_wave];
+#pragma unroll
+        for (int q = 0; q < U; q++) acc += v[q];
+        p += (size_t)U * g.per_wave;
+    }
+    for (; r < r1; r++) { acc += *p; p += g.per_wave; }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && live) stage[(size_t)blockIdx.y * g.total + j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+__global__ void __launch_bounds__(256) k_ng_reduce_weight_grads_fold(int total, const float* __restrict__ stage, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    float t = stage[j];
+#pragma unroll
+    for (int q = 1; q < NG_REDUCE_SPLIT; q++) t += stage[(size_t)q * total + j];
+    out[j] = t;
+}
+
+// W2^T of the four MLPs in one launch (the B operand of Y = H W2^T): out = [32][k] | [32][7k] | [32][k] | [32][k], block m at
+// 32 * (0, k, 8k, 9k).  Four framework transposes before, every forward.
+struct NgW2 { const float* w[4]; int k; };
+__global__ void __launch_bounds__(256) k_ng_transpose_w2(const NgW2 a, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 320 * a.k) return;
+    const int k = a.k;
+    const int m = i < 32 * k ? 0 : (i < 256 * k ? 1 : (i < 288 * k ? 2 : 3));
+    const int dout = m == 1 ? 7 * k : k;
+    const int r = i - 32 * (m == 0 ? 0 : (m == 1 ? k : (m == 2 ? 8 * k : 9 * k)));
+    const int t = r / dout, o = r - t * dout;                           // out_m[t][o] = W2_m[o][t]
+    out[i] = a.w[m][o * 32 + t];
+}
 }  // namespace lg
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -970,6 +1045,48 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
     NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward_mfma<K>, dim3(waves), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset,
                                         scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
                                         dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials));
+    NG_HIP(hipGetLastError());
+    return 0;
+}
+
+int lidargs_ng_transpose_w2(int n_offsets, const float* const* W2, float* out, void* stream_) {
+    const int k = n_offsets;
+    if (!(k == 4 || k == 5 || k == 6 || k == 8 || k == 10) || !W2 || !out || !W2[0] || !W2[1] || !W2[2] || !W2[3])
+        return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_transpose_w2: bad argument");
+    lg::NgW2 a; a.k = k;
+    for (int m = 0; m < 4; m++) a.w[m] = W2[m];
+    hipLaunchKernelGGL(lg::k_ng_transpose_w2, dim3((320 * k + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a, out);
+    NG_HIP(hipGetLastError());
+    return 0;
+}
+static int ng_grad_map(int k, const int* din, lg::NgGradMap* g) {
+    if (!(k == 4 || k == 5 || k == 6 || k == 8 || k == 10) || !din) return 1;
+    g->k = k; g->nc = (7 * k + 31) / 32; g->per_wave = (5 + 3 + g->nc) * 1024 + 128;
+    int off = 0;
+    for (int m = 0; m < 4; m++) {
+        if (din[m] < 32 || din[m] > 36) return 1;
+        const int dout = m == 1 ? 7 * k : k;
+        g->din[m] = din[m]; g->base[m] = off;
+        off += 32 * din[m] + 32 + dout * 32 + dout;
+    }
+    g->total = off;
+    return 0;
+}
+int lidargs_ng_weight_grad_floats(int n_offsets, const int* din) {
+    lg::NgGradMap g;
+    if (ng_grad_map(n_offsets, din, &g)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_weight_grad_floats: bad argument");
+    return g.total;
+}
+int lidargs_ng_weight_grad_stage_floats(int n_offsets, const int* din) {
+    lg::NgGradMap g;
+    if (ng_grad_map(n_offsets, din, &g)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_weight_grad_stage_floats: bad argument");
+    return lg::NG_REDUCE_SPLIT * g.total;
+}
+int lidargs_ng_reduce_weight_grads(int n_offsets, const int* din, int waves, const float* partials, float* grads, float* stage, void* stream_) {
+    lg::NgGradMap g;
+    if (ng_grad_map(n_offsets, din, &g) || waves <= 0 || !partials || !grads || !stage) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_reduce_weight_grads: bad argument");
+    hipLaunchKernelGGL(lg::k_ng_reduce_weight_grads, dim3((g.total + 63) / 64, lg::NG_REDUCE_SPLIT), dim3(256), 0, (hipStream_t)stream_, g, waves, partials, stage);
+    hipLaunchKernelGGL(lg::k_ng_reduce_weight_grads_fold, dim3((g.total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, g.total, stage, grads);
     NG_HIP(hipGetLastError());
     return 0;
 }

@@ -132,6 +132,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom_buffer, binning_buffer, img_buffer)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # an output nobody used arrives as None in backward (handled there), not as a zero plane
         # no zero tensors made for outputs the loss does not use (radii never has a gradient: that alone is one fill of P ints a
         # frame); backward fills in the image planes that are missing
         ctx.set_materialize_grads(False)

@@ -25,9 +25,19 @@ class _Model(C.Structure):
 
 
 for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_ng_backward_mfma",
-           "lidargs_ng_backward_partials", "lidargs_ng_training_stats"):
+           "lidargs_ng_backward_partials", "lidargs_ng_training_stats", "lidargs_ng_weight_grad_floats", "lidargs_ng_weight_grad_stage_floats", "lidargs_ng_reduce_weight_grads", "lidargs_ng_transpose_w2"):
     getattr(_lib, _n).restype = C.c_int
 _lib.lidargs_ng_scratch_bytes.restype = C.c_size_t
+
+
+def _transposed_w2(params, k, dev):
+    """Transposed second-layer weights, the B operand of Y = H W2^T on the matrix pipe (forward and backward): one launch for the four."""
+    out = torch.empty(320 * k, dtype=torch.float32, device=dev)
+    ptrs = (C.c_void_p * 4)(*[params[4 * i + 2].data_ptr() for i in range(4)])
+    with torch.cuda.device(dev):
+        _check(_lib.lidargs_ng_transpose_w2(C.c_int(k), ptrs, _base._ptr(out), _base._stream(dev)), "lidargs_ng_transpose_w2")
+    o = (0, k, 8 * k, 9 * k)
+    return tuple(out[32 * o[i]:32 * o[i] + 32 * (7 * k if i == 1 else k)].view(32, 7 * k if i == 1 else k) for i in range(4))
 
 
 def _check(rc, what):
@@ -57,8 +67,7 @@ class _Decode(torch.autograd.Function):
         anchor_feat, anchor, offset, scaling = f32(anchor_feat), f32(anchor), f32(offset), f32(scaling)
         params = tuple(f32(p) for p in params)
         N, k = int(anchor.shape[0]), int(offset.shape[1])
-        # transposed second-layer weights: the B operand of Y = H W2^T on the matrix pipe (forward and backward)
-        w2t = tuple(params[4 * i + 2].t().contiguous() for i in range(4))
+        w2t = _transposed_w2(params, k, dev)
         model = _model_struct(k, flags, params, w2t)
         nb = int(_lib.lidargs_ng_scratch_bytes(C.c_int(N), C.c_int(k)))
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -79,6 +88,7 @@ class _Decode(torch.autograd.Function):
                 _check(_lib.lidargs_ng_forward_decode(C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
                                                       p(neural_opacity), p(xyz), p(color), p(opacity), p(scal), p(rot), p(scratch), C.c_size_t(nb),
                                                       _base._stream(dev)), "lidargs_ng_forward_decode")
+        ctx.set_materialize_grads(False)          # an unused output (neural_opacity, the mask) must not cost a zero fill of n k entries
         ctx.save_for_backward(anchor_feat, anchor, offset, scaling, scratch, *params, *w2t)
         ctx.meta = (N, k, n, M, tuple(float(c) for c in cam), tuple(bool(f) for f in flags))
         neural_opacity = neural_opacity[:n * k].view(n * k, 1)
@@ -140,19 +150,26 @@ class _Decode(torch.autograd.Function):
                                                          p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
                                                          p(d_offset), p(d_scaling), p(partials), p(scratch), C.c_size_t(scratch.numel()),
                                                          _base._stream(dev)), "lidargs_ng_backward_mfma")
-                total = partials.sum(0)
-            else:
-                total = torch.zeros(per_wave.value, dtype=torch.float32, device=dev)
-            nc = (7 * k + 31) // 32
-            T = total[:(8 + nc) * 1024].view(8 + nc, 32, 32)
-            db2 = total[(8 + nc) * 1024:(8 + nc) * 1024 + 10 * k]
+            # sum over the waves and unpack into the sixteen parameter gradients, two small launches (before: a framework reduction over
+            # [1024, 10368], four concatenations and four strided copies, ~90 us of the backward)
             dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
-            dW2 = (T[5][:k], T[6:6 + nc].reshape(nc * 32, 32)[:7 * k], T[6 + nc][:k], T[7 + nc][:k])      # views of the tiles
-            cols = ((0, k), (k, 8 * k), (8 * k, 9 * k), (9 * k, 10 * k))
-            g_params = []
+            douts = (k, 7 * k, k, k)
+            din_c = (C.c_int * 4)(*dins)
+            nfl = int(_lib.lidargs_ng_weight_grad_floats(C.c_int(k), din_c))
+            _check(nfl, "lidargs_ng_weight_grad_floats")
+            if N:
+                nst = int(_lib.lidargs_ng_weight_grad_stage_floats(C.c_int(k), din_c))
+                flat = torch.empty(nfl + nst, dtype=torch.float32, device=dev)     # the gradients, then the first stage's row-group sums
+                with torch.cuda.device(dev):
+                    _check(_lib.lidargs_ng_reduce_weight_grads(C.c_int(k), din_c, C.c_int(waves.value), p(partials), p(flat), p(flat[nfl:]), _base._stream(dev)),
+                           "lidargs_ng_reduce_weight_grads")
+            else:
+                flat = torch.zeros(nfl, dtype=torch.float32, device=dev)
+            g_params, o = [], 0
             for i in range(4):
-                dW1 = torch.cat([T[i], T[4][:, 8 * i:8 * i + dins[i] - 32]], dim=1)                        # columns 0..31 | 32..din-1
-                g_params += [dW1, T[4][:, 8 * i + 4], dW2[i], db2[cols[i][0]:cols[i][1]]]
+                for shape in ((32, dins[i]), (32,), (douts[i], 32), (douts[i],)):
+                    cnt = shape[0] * (shape[1] if len(shape) == 2 else 1)
+                    g_params.append(flat[o:o + cnt].view(shape)); o += cnt
             return (d_feat, d_anchor, d_offset, d_scaling, *g_params, None, None, None)
         cols = ((0, k), (k, 8 * k), (8 * k, 9 * k), (9 * k, 10 * k))
         dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
