@@ -78,16 +78,21 @@ class _Decode(torch.autograd.Function):
         camv = (C.c_float * 3)(*[float(c) for c in cam])
         p = _base._ptr
         with torch.cuda.device(dev):
+            stream = _base._stream(dev)
+            # everything the decode launch needs that does not depend on (n, M), before the select's host read: the device is idle from
+            # that read to the launch, so nothing but the output allocation sits between them (the output views are made behind it)
+            dec_head = (C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv, p(neural_opacity))
+            dec_tail = (p(scratch), C.c_size_t(nb), stream)
             _check(_lib.lidargs_ng_forward_select(C.c_int(N), C.byref(model), p(vis), p(anchor_feat), p(anchor), camv, p(neural_opacity), p(mask),
-                                                  counts, p(scratch), C.c_size_t(nb), _base._stream(dev)), "lidargs_ng_forward_select")
+                                                  counts, p(scratch), C.c_size_t(nb), stream), "lidargs_ng_forward_select")
             n, M = int(counts[0]), int(counts[1])
             out = torch.empty(M * 13, dtype=torch.float32, device=dev)
+            if N:
+                base = out.data_ptr()
+                at = lambda floats: C.c_void_p(base + 4 * floats) if M else None
+                _check(_lib.lidargs_ng_forward_decode(*dec_head, at(0), at(3 * M), at(5 * M), at(6 * M), at(9 * M), *dec_tail), "lidargs_ng_forward_decode")
             xyz, color, opacity = out[:3 * M].view(M, 3), out[3 * M:5 * M].view(M, 2), out[5 * M:6 * M].view(M, 1)
             scal, rot = out[6 * M:9 * M].view(M, 3), out[9 * M:13 * M].view(M, 4)
-            if N:
-                _check(_lib.lidargs_ng_forward_decode(C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
-                                                      p(neural_opacity), p(xyz), p(color), p(opacity), p(scal), p(rot), p(scratch), C.c_size_t(nb),
-                                                      _base._stream(dev)), "lidargs_ng_forward_decode")
         ctx.set_materialize_grads(False)          # an unused output (neural_opacity, the mask) must not cost a zero fill of n k entries
         ctx.save_for_backward(anchor_feat, anchor, offset, scaling, scratch, *params, *w2t)
         ctx.meta = (N, k, n, M, tuple(float(c) for c in cam), tuple(bool(f) for f in flags))
@@ -109,14 +114,17 @@ class _Decode(torch.autograd.Function):
         g_scaling, g_rot = f(g_scaling, (M, 3)), f(g_rot, (M, 4))
         g_no = None if g_no is None else g_no.to(torch.float32).contiguous()
         dense = torch.empty(N * (32 + 3 + 3 * k + 6), dtype=torch.float32, device=dev)          # every row is written by the kernel
-        o = 0
-        d_feat = dense[o:o + N * 32].view(N, 32); o += N * 32
-        d_anchor = dense[o:o + N * 3].view(N, 3); o += N * 3
-        d_offset = dense[o:o + N * 3 * k].view(N, k, 3); o += N * 3 * k
-        d_scaling = dense[o:o + N * 6].view(N, 6)
         p = _base._ptr
+
+        def dense_views():
+            o = 0
+            d_feat = dense[o:o + N * 32].view(N, 32); o += N * 32
+            d_anchor = dense[o:o + N * 3].view(N, 3); o += N * 3
+            d_offset = dense[o:o + N * 3 * k].view(N, k, 3); o += N * 3 * k
+            return d_feat, d_anchor, d_offset, dense[o:o + N * 6].view(N, 6)
         if os.environ.get("LIDARGS_NG_ACT_BUFFERS", "0") == "1":
             # the older formulation: the kernel writes what two library GEMMs reduce (1.4 KB per visible anchor)
+            d_feat, d_anchor, d_offset, d_scaling = dense_views()
             act_x = torch.empty((n, 40), dtype=torch.float32, device=dev)
             act_h = torch.empty((n, 132), dtype=torch.float32, device=dev)
             delta1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
@@ -146,10 +154,13 @@ class _Decode(torch.autograd.Function):
             partials = torch.empty((waves.value, per_wave.value), dtype=torch.float32, device=dev)
             if N:
                 with torch.cuda.device(dev):
+                    base = dense.data_ptr()
+                    at = lambda floats: C.c_void_p(base + 4 * floats)       # the launch first, the views of `dense` behind it
                     _check(_lib.lidargs_ng_backward_mfma(C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv,
-                                                         p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), p(d_feat), p(d_anchor),
-                                                         p(d_offset), p(d_scaling), p(partials), p(scratch), C.c_size_t(scratch.numel()),
+                                                         p(g_xyz), p(g_color), p(g_opacity), p(g_scaling), p(g_rot), p(g_no), at(0), at(N * 32),
+                                                         at(N * 35), at(N * (35 + 3 * k)), p(partials), p(scratch), C.c_size_t(scratch.numel()),
                                                          _base._stream(dev)), "lidargs_ng_backward_mfma")
+            d_feat, d_anchor, d_offset, d_scaling = dense_views()
             # sum over the waves and unpack into the sixteen parameter gradients, two small launches (before: a framework reduction over
             # [1024, 10368], four concatenations and four strided copies, ~90 us of the backward)
             dins = (35 + int(flags[0]), 35 + int(flags[1]), 35 + int(flags[2]), 35 + int(flags[2]))
