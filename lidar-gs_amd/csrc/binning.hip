@@ -200,6 +200,15 @@ __global__ void __launch_bounds__(256) k_radix_chunk_prefix(uint32_t* __restrict
     if (lane == 0) tot[d] = carry;
 }
 
+// Phase clocks of k_radix_scatter for tools/micro/scatter_phases.cpp (compiled in with -DLG_PHASE_CLOCKS only; the product build has none):
+// wave 0 of the first 4096 workgroups stores the 100-MHz wall clock at each phase boundary.
+#ifdef LG_PHASE_CLOCKS
+__device__ unsigned long long lg_phase_clk[8 * 4096];
+#define LG_PHASE_CLK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) lg_phase_clk[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+void phase_clocks_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lg_phase_clk), sizeof(unsigned long long) * 8 * 4096); }
+#else
+#define LG_PHASE_CLK(slot) do { } while (0)
+#endif
 template <int BITS, int ITEMS, typename KT = uint32_t>
 __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        KT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -212,6 +221,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
     constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
     if (n_dev) n = min(n, (size_t)*n_dev);
     if ((size_t)blockIdx.x * CHUNK >= n) return;     // wave-uniform, before any barrier
+    LG_PHASE_CLK(0);
     __shared__ uint32_t run[SORT_WAVES][BINS];   // per-wave running digit counts, then wave bases
     __shared__ uint32_t dbase[BINS];             // block-local start of each digit run
     __shared__ uint32_t gbase[BINS];             // global start of this block's run of each digit
@@ -256,6 +266,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
     }
     for (int d = lane; d < BINS; d += 64) run[w][d] = 0;
     __syncthreads();
+    LG_PHASE_CLK(1);                                  // keys requested, digit bases scanned
 
     // A. wave-local stable ranks
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -284,6 +295,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    LG_PHASE_CLK(2);                                  // ranked
 
     // B. block-local digit starts: digit-major, then wave-major inside a digit
     {
@@ -312,6 +324,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
         }
     }
     __syncthreads();
+    LG_PHASE_CLK(3);                                  // block-local digit starts
 
     // C. park the block in LDS in sorted order
 #pragma unroll
@@ -323,6 +336,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
         }
     }
     __syncthreads();
+    LG_PHASE_CLK(4);                                  // parked
 
     // D. stream out: thread i writes element i of the sorted block to its digit run
     const uint32_t count = (uint32_t)(n - blk_base < (size_t)CHUNK ? n - blk_base : (size_t)CHUNK);
@@ -362,6 +376,10 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
                 if (tid + 256u * (uint32_t)r < count) { vals_out[g[r]] = v[r]; static_cast<uint2*>(tail.dst)[g[r]] = make_uint2(sp[r].y, sp[r].x); }
         }
     }
+#ifdef LG_PHASE_CLOCKS
+    __builtin_amdgcn_s_waitcnt(0);                    // the stores' completion belongs to the last phase
+    LG_PHASE_CLK(5);
+#endif
 }
 
 // Keys per sort block: 4096 (16 per lane), or 2048 for inputs up to 4 M pairs when the scratch has room for twice the blocks -- at
