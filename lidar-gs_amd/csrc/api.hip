@@ -481,7 +481,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         uint32_t* const k_in = flip ? bin.tile_b : bin.tile_a; uint32_t* const k_out = flip ? bin.tile_a : bin.tile_b;
         uint32_t* const v_in = flip ? bin.val_b : bin.val_a; uint32_t* const v_out = flip ? bin.val_a : bin.val_b;
         lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, pp.compact != 0, (size_t)P, grid,
-                                  k_in, v_in, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16);
+                                  k_in, v_in, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16, img.ranges);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
         const int side = key16 ? lg::launch_radix_sort_pairs16(reinterpret_cast<uint16_t*>(k_in), reinterpret_cast<uint16_t*>(k_out), v_in, v_out, R,
@@ -495,7 +495,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         LG_STAGE_CHECK("tile bin");
         g_prof.mark("tile_bin", stream);
     }
-    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev, key16, bin.work, LG_WORK_REGIONS * LG_WORK_CNT_STRIDE);
+    lg::launch_tile_ranges(bin.tile_a, R, img.ranges, grid.num_tiles(), stream, R_dev, key16, bin.work, LG_WORK_REGIONS * LG_WORK_CNT_STRIDE, R != 0);
     LG_STAGE_CHECK("tile ranges");
     g_prof.mark("ranges", stream);
 

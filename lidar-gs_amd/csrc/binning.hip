@@ -725,7 +725,12 @@ void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint
 template <bool COMPACT, typename KT = uint32_t>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ block_off,
                                                                const void* __restrict__ span_sorted_, size_t P, int th_shift, int tiles_x,
-                                                               KT* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap) {
+                                                               KT* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap,
+                                                               uint2* __restrict__ ranges, uint32_t tiles) {
+    // every tile's list range starts out empty, as the reference pre-zeroes `ranges` (R3/cr/rasterizer_impl.cu:324): k_tile_ranges, two
+    // sorts later, writes the non-empty ones.  (It used to zero the tiles a step of the sorted keys skips, one thread per step: a far range
+    // shell's frame, whose lists leave a thousand tiles empty in a row, spent 42 us there.)
+    for (size_t t = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; t < tiles; t += (size_t)gridDim.x * SCAN_BLOCK) ranges[t] = make_uint2(0u, 0u);
     __shared__ uint32_t s_tot[SCAN_BLOCK / 64];                        // instance count of each wave's 64 Gaussians
     __shared__ uint32_t s_own[SCAN_BLOCK / 64][64];                    // per wave: the lane whose instances start at each slot of the window
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -790,21 +795,22 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
 }
 
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
-                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap, bool key16) {
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap, bool key16, uint2* ranges) {
+    const uint32_t tiles = ranges ? (uint32_t)grid.num_tiles() : 0u;
     int sh = 0;
     while ((1 << sh) < grid.TH) sh++;
     if (key16) {
         uint16_t* t16 = reinterpret_cast<uint16_t*>(inst_tile);
         if (compact) hipLaunchKernelGGL((k_emit_instances<true, uint16_t>), dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                                        P, sh, grid.tiles_x, t16, inst_val, cap);
+                                        P, sh, grid.tiles_x, t16, inst_val, cap, ranges, tiles);
         else hipLaunchKernelGGL((k_emit_instances<false, uint16_t>), dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                                P, sh, grid.tiles_x, t16, inst_val, cap);
+                                P, sh, grid.tiles_x, t16, inst_val, cap, ranges, tiles);
         return;
     }
     if (compact) hipLaunchKernelGGL(k_emit_instances<true>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                                    P, sh, grid.tiles_x, inst_tile, inst_val, cap);
+                                    P, sh, grid.tiles_x, inst_tile, inst_val, cap, ranges, tiles);
     else hipLaunchKernelGGL(k_emit_instances<false>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                            P, sh, grid.tiles_x, inst_tile, inst_val, cap);
+                            P, sh, grid.tiles_x, inst_tile, inst_val, cap, ranges, tiles);
 }
 
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles
@@ -814,7 +820,7 @@ void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off
 constexpr int RANGES_ITEMS = 8;
 template <typename KT = uint32_t>
 __global__ void __launch_bounds__(256) k_tile_ranges(const KT* __restrict__ tile_sorted, size_t R, const uint32_t* __restrict__ R_dev,
-                                                     uint2* __restrict__ ranges, uint32_t tiles, uint32_t* __restrict__ zero, int n_zero) {
+                                                     uint2* __restrict__ ranges, uint32_t tiles, uint32_t* __restrict__ zero, int n_zero, bool prezeroed) {
     const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * RANGES_ITEMS;
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < n_zero; q += 256) zero[q] = 0u;    // the work list's counters (lidargs_common.h WorkList)
     if (R_dev) R = min(R, (size_t)*R_dev);                             // enqueue-only forward: the count lives on the device
@@ -841,28 +847,29 @@ __global__ void __launch_bounds__(256) k_tile_ranges(const KT* __restrict__ tile
         const size_t i = i0 + (size_t)q;
         if (i >= R) break;
         const uint32_t cur = key[q];
+        // prezeroed: the emit launch cleared every range; otherwise the thread at a step clears the tiles it skips
         if (i == 0) {
-            for (uint32_t t = 0; t < cur && t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+            if (!prezeroed) for (uint32_t t = 0; t < cur && t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
             ranges[cur].x = 0;
         } else if (cur != prev) {
             ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i;
-            for (uint32_t t = prev + 1; t < cur; t++) ranges[t] = make_uint2(0u, 0u);
+            if (!prezeroed) for (uint32_t t = prev + 1; t < cur; t++) ranges[t] = make_uint2(0u, 0u);
         }
         if (i == R - 1) {
             ranges[cur].y = (uint32_t)R;
-            for (uint32_t t = cur + 1; t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
+            if (!prezeroed) for (uint32_t t = cur + 1; t < tiles; t++) ranges[t] = make_uint2(0u, 0u);
         }
         prev = cur;
     }
 }
 
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev, bool key16,
-                        uint32_t* zero, int n_zero) {
+                        uint32_t* zero, int n_zero, bool prezeroed) {
     if (!zero) n_zero = 0;
     if (R && key16) hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((unsigned)((R + 256 * RANGES_ITEMS - 1) / (256 * RANGES_ITEMS))), dim3(256), 0, s,
-                                       reinterpret_cast<const uint16_t*>(tile_sorted), R, R_dev, ranges, (uint32_t)tiles, zero, n_zero);
+                                       reinterpret_cast<const uint16_t*>(tile_sorted), R, R_dev, ranges, (uint32_t)tiles, zero, n_zero, prezeroed);
     else if (R) hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((unsigned)((R + 256 * RANGES_ITEMS - 1) / (256 * RANGES_ITEMS))), dim3(256), 0, s, tile_sorted, R, R_dev,
-                                   ranges, (uint32_t)tiles, zero, n_zero);
+                                   ranges, (uint32_t)tiles, zero, n_zero, prezeroed);
     else {
         hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
         if (n_zero) hipMemsetAsync(zero, 0, sizeof(uint32_t) * (size_t)n_zero, s);

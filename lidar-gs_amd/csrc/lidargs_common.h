@@ -377,10 +377,11 @@ void launch_finish_totals(const uint32_t* totals, const unsigned long long* slot
 void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s);
 // key16: the tile keys are 16-bit (the array is the same allocation, half used): every image with at most 65536 list tiles
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
-                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, bool key16 = false);
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, bool key16 = false,
+                           uint2* ranges = nullptr);   // ranges: the launch also clears every tile's list range (then launch_tile_ranges(..., prezeroed = true))
 // zero / n_zero: words this launch also clears (the work lists' counters: nothing before the blends touches them)
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr, bool key16 = false,
-                        uint32_t* zero = nullptr, int n_zero = 0);
+                        uint32_t* zero = nullptr, int n_zero = 0, bool prezeroed = false);
 int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit, uint32_t* scratch, hipStream_t s,
                               const uint32_t* n_dev = nullptr);
 int radix_sort_result_side(size_t n, int end_bit);   // side the two functions above (default digit width, no tail) leave the result on
