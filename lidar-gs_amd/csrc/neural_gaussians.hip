@@ -700,8 +700,14 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_decode_mfma(int N, NgModel m, f
                                                              const uint32_t* __restrict__ sel_flags, const uint32_t* __restrict__ slot,
                                                              const float* __restrict__ neural_opacity, float* __restrict__ o_xyz, float* __restrict__ o_color,
                                                              float* __restrict__ o_opacity, float* __restrict__ o_scaling, float* __restrict__ o_rot) {
-    constexpr int YROWS = (7 * K + 2 * NG_U - 1) / (2 * NG_U) * (2 * NG_U);
-    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS], s_y[YROWS * NG_LS];
+    // LDS sets the occupancy here (one wave per workgroup): x (40 rows), h (32) and the covariance MLP's 7k outputs as three arrays were
+    // 31 KB for k = 6, five waves to a CU.  x is dead once the LAST recompute has its hidden units, so that one writes its outputs over
+    // x; the two k-output recomputes before it put theirs in the rows behind x: 20.8 KB, seven waves.
+    constexpr int UROWS = (7 * K > NG_XS + K) ? 7 * K : NG_XS + K;
+    __shared__ float s_u[UROWS * NG_LS], s_h[NG_HID * NG_LS];
+    float* const s_x = s_u;
+    float* const s_ys = s_u + NG_XS * NG_LS;                           // rows of the colour / ray-drop outputs (k each, one after the other)
+    float* const s_y = s_u;                                            // rows of the covariance outputs (7k), over x
     const int lane = threadIdx.x;
     const int i = blockIdx.x * NG_BLOCK + lane;
     bool active = false;
@@ -722,15 +728,15 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_decode_mfma(int N, NgModel m, f
     }
     __builtin_amdgcn_wave_barrier();
     float col[K], rd[K];
-    ng_mfma_recompute<K>(m, NG_COL, s_x, s_h, s_y, lane);
+    ng_mfma_recompute<K>(m, NG_COL, s_x, s_h, s_ys, lane);
 #pragma unroll
-    for (int j = 0; j < K; j++) col[j] = s_y[j * NG_LS + lane];
+    for (int j = 0; j < K; j++) col[j] = s_ys[j * NG_LS + lane];
     __builtin_amdgcn_wave_barrier();
-    ng_mfma_recompute<K>(m, NG_RD, s_x, s_h, s_y, lane);
+    ng_mfma_recompute<K>(m, NG_RD, s_x, s_h, s_ys, lane);
 #pragma unroll
-    for (int j = 0; j < K; j++) rd[j] = s_y[j * NG_LS + lane];
+    for (int j = 0; j < K; j++) rd[j] = s_ys[j * NG_LS + lane];
     __builtin_amdgcn_wave_barrier();
-    ng_mfma_recompute<7 * K>(m, NG_COV, s_x, s_h, s_y, lane);
+    ng_mfma_recompute<7 * K>(m, NG_COV, s_x, s_h, s_y, lane);          // its outputs land on x (dead behind the hidden layer)
     if (!active) return;
     const float* sc = scaling + 6 * (size_t)i;
     const float s0 = sc[0], s1 = sc[1], s2 = sc[2], s3 = sc[3], s4 = sc[4], s5 = sc[5];
@@ -760,8 +766,8 @@ template <int K>
 __global__ void __launch_bounds__(NG_BLOCK) k_ng_opacity_mfma(int N, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
                                                               const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
                                                               float* __restrict__ neural_opacity, uint8_t* __restrict__ mask, uint32_t* __restrict__ sel_flags) {
-    constexpr int YROWS = (K + 2 * NG_U - 1) / (2 * NG_U) * (2 * NG_U);
-    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS], s_y[YROWS * NG_LS];
+    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS];
+    float* const s_y = s_x;                                            // the k outputs over x, dead behind the hidden layer (18.7 KB: eight waves to a CU)
     const int lane = threadIdx.x;
     const int i = blockIdx.x * NG_BLOCK + lane;
     const bool vis = i < N && vis_flags[i] != 0u;
