@@ -47,6 +47,13 @@ size_t lidargs_ng_scratch_bytes(int N, int n_offsets);
 int lidargs_ng_forward_select(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
                               const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
                               int* counts_host, char* scratch, size_t scratch_bytes, void* stream);
+/* The same without the wait: the two counts are copied to `counts_pinned` (PINNED host memory, int[2]) by the stream and the call
+ * returns at once.  Step 2 does not need them -- its output rows come from the device-side scan -- so a caller that gives step 2
+ * arrays of N*k rows each (the upper bound of M) can queue it right behind this call and wait for the counts (an event recorded
+ * after this call) while it runs, then take the first M rows: the device never idles between the two steps. */
+int lidargs_ng_forward_select_enqueue(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
+                                      const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
+                                      int* counts_pinned, char* scratch, size_t scratch_bytes, void* stream);
 
 /* Step 2 (:70-113): colour / ray-drop / covariance MLPs and the post-processing, for the selected pairs only.
  * Outputs have M rows: xyz f32[M*3], color f32[M*2], opacity f32[M], scaling f32[M*3], rot f32[M*4].

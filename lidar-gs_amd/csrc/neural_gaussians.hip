@@ -939,9 +939,9 @@ size_t lidargs_ng_scratch_bytes(int N, int n_offsets) {
     return lg::ng_carve(nullptr, (size_t)(N > 0 ? N : 1), (size_t)(n_offsets > 0 ? n_offsets : 1), nullptr);
 }
 
-int lidargs_ng_forward_select(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
-                              const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
-                              int* counts_host, char* scratch, size_t scratch_bytes, void* stream_) {
+static int ng_forward_select(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
+                             const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
+                             int* counts_host, char* scratch, size_t scratch_bytes, void* stream_, bool wait) {
     hipStream_t stream = (hipStream_t)stream_;
     lg::NgModel m;
     if (int rc = ng_model(model, &m)) return rc;
@@ -963,11 +963,25 @@ int lidargs_ng_forward_select(int N, const lidargs_ng_model* model, const uint8_
                                             s.vis_idx, neural_opacity, mask, s.sel_flags));
     }
     lg::launch_exclusive_scan(s.sel_flags, s.slot, (size_t)N * m.k, s.totals + 1, s.scan, stream);
+    if (!wait) {                                                       // counts_host is pinned memory of the caller's, who waits (an event behind this call)
+        NG_HIP(hipMemcpyAsync(counts_host, s.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        return 0;
+    }
     uint32_t tot[2] = {0, 0};
     NG_HIP(hipMemcpyAsync(tot, s.totals, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     NG_HIP(hipStreamSynchronize(stream));
     counts_host[0] = (int)tot[0]; counts_host[1] = (int)tot[1];
     return (int)tot[1];
+}
+int lidargs_ng_forward_select(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
+                              const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
+                              int* counts_host, char* scratch, size_t scratch_bytes, void* stream) {
+    return ng_forward_select(N, model, visible_mask, anchor_feat, anchor, cam_center, neural_opacity, mask, counts_host, scratch, scratch_bytes, stream, true);
+}
+int lidargs_ng_forward_select_enqueue(int N, const lidargs_ng_model* model, const uint8_t* visible_mask, const float* anchor_feat,
+                                      const float* anchor, const float* cam_center, float* neural_opacity, uint8_t* mask,
+                                      int* counts_pinned, char* scratch, size_t scratch_bytes, void* stream) {
+    return ng_forward_select(N, model, visible_mask, anchor_feat, anchor, cam_center, neural_opacity, mask, counts_pinned, scratch, scratch_bytes, stream, false);
 }
 
 int lidargs_ng_forward_decode(int N, const lidargs_ng_model* model, const float* anchor_feat, const float* anchor,

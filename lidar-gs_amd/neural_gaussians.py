@@ -24,7 +24,7 @@ class _Model(C.Structure):
                 ("W1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("W2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("W2T", C.c_void_p * 4)]
 
 
-for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_ng_backward_mfma",
+for _n in ("lidargs_ng_forward_select", "lidargs_ng_forward_select_enqueue", "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_ng_backward_mfma",
            "lidargs_ng_backward_partials", "lidargs_ng_training_stats", "lidargs_ng_weight_grad_floats", "lidargs_ng_weight_grad_stage_floats", "lidargs_ng_reduce_weight_grads", "lidargs_ng_transpose_w2"):
     getattr(_lib, _n).restype = C.c_int
 _lib.lidargs_ng_scratch_bytes.restype = C.c_size_t
@@ -38,6 +38,21 @@ def _transposed_w2(params, k, dev):
         _check(_lib.lidargs_ng_transpose_w2(C.c_int(k), ptrs, _base._ptr(out), _base._stream(dev)), "lidargs_ng_transpose_w2")
     o = (0, k, 8 * k, 9 * k)
     return tuple(out[32 * o[i]:32 * o[i] + 32 * (7 * k if i == 1 else k)].view(32, 7 * k if i == 1 else k) for i in range(4))
+
+
+_CAPACITY_BYTES = int(os.environ.get("LIDARGS_NG_CAPACITY_BYTES", str(1 << 30)))   # largest N k x 52-byte output block the decode allocates to skip the wait; 0 = always wait
+_PINNED = {}
+
+
+def _pinned_counts(dev):
+    """Per (device, thread): two pinned ints the selection's counts land in, and the event in front of the decode launch."""
+    import threading
+    key = (dev.index, threading.get_ident())
+    hit = _PINNED.get(key)
+    if hit is None:
+        hit = (torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        _PINNED[key] = hit
+    return hit
 
 
 def _check(rc, what):
@@ -83,16 +98,34 @@ class _Decode(torch.autograd.Function):
             # that read to the launch, so nothing but the output allocation sits between them (the output views are made behind it)
             dec_head = (C.c_int(N), C.byref(model), p(anchor_feat), p(anchor), p(offset), p(scaling), camv, p(neural_opacity))
             dec_tail = (p(scratch), C.c_size_t(nb), stream)
-            _check(_lib.lidargs_ng_forward_select(C.c_int(N), C.byref(model), p(vis), p(anchor_feat), p(anchor), camv, p(neural_opacity), p(mask),
-                                                  counts, p(scratch), C.c_size_t(nb), stream), "lidargs_ng_forward_select")
-            n, M = int(counts[0]), int(counts[1])
-            out = torch.empty(M * 13, dtype=torch.float32, device=dev)
-            if N:
+            cap = N * k                                                # rows of each output array: M itself, or its upper bound
+            if 0 < cap * 52 <= _CAPACITY_BYTES:
+                # No idle device between the two steps: the decode writes into arrays of N k rows (its rows come from the device-side
+                # scan), queued right behind the selection; the host waits for the two counts -- an event in front of the decode --
+                # while it runs, and the outputs are the first M rows.
+                pinned, ev = _pinned_counts(dev)
+                _check(_lib.lidargs_ng_forward_select_enqueue(C.c_int(N), C.byref(model), p(vis), p(anchor_feat), p(anchor), camv, p(neural_opacity),
+                                                              p(mask), C.c_void_p(pinned.data_ptr()), p(scratch), C.c_size_t(nb), stream),
+                       "lidargs_ng_forward_select_enqueue")
+                ev.record(torch.cuda.current_stream(dev))
+                out = torch.empty(cap * 13, dtype=torch.float32, device=dev)
                 base = out.data_ptr()
-                at = lambda floats: C.c_void_p(base + 4 * floats) if M else None
-                _check(_lib.lidargs_ng_forward_decode(*dec_head, at(0), at(3 * M), at(5 * M), at(6 * M), at(9 * M), *dec_tail), "lidargs_ng_forward_decode")
-            xyz, color, opacity = out[:3 * M].view(M, 3), out[3 * M:5 * M].view(M, 2), out[5 * M:6 * M].view(M, 1)
-            scal, rot = out[6 * M:9 * M].view(M, 3), out[9 * M:13 * M].view(M, 4)
+                at = lambda floats: C.c_void_p(base + 4 * floats)
+                _check(_lib.lidargs_ng_forward_decode(*dec_head, at(0), at(3 * cap), at(5 * cap), at(6 * cap), at(9 * cap), *dec_tail), "lidargs_ng_forward_decode")
+                ev.synchronize()
+                n, M = int(pinned[0]), int(pinned[1])
+            else:
+                _check(_lib.lidargs_ng_forward_select(C.c_int(N), C.byref(model), p(vis), p(anchor_feat), p(anchor), camv, p(neural_opacity), p(mask),
+                                                      counts, p(scratch), C.c_size_t(nb), stream), "lidargs_ng_forward_select")
+                n, M = int(counts[0]), int(counts[1])
+                cap = M
+                out = torch.empty(M * 13, dtype=torch.float32, device=dev)
+                if N:
+                    base = out.data_ptr()
+                    at = lambda floats: C.c_void_p(base + 4 * floats) if M else None
+                    _check(_lib.lidargs_ng_forward_decode(*dec_head, at(0), at(3 * M), at(5 * M), at(6 * M), at(9 * M), *dec_tail), "lidargs_ng_forward_decode")
+            xyz, color, opacity = out[:3 * M].view(M, 3), out[3 * cap:3 * cap + 2 * M].view(M, 2), out[5 * cap:5 * cap + M].view(M, 1)
+            scal, rot = out[6 * cap:6 * cap + 3 * M].view(M, 3), out[9 * cap:9 * cap + 4 * M].view(M, 4)
         ctx.set_materialize_grads(False)          # an unused output (neural_opacity, the mask) must not cost a zero fill of n k entries
         ctx.save_for_backward(anchor_feat, anchor, offset, scaling, scratch, *params, *w2t)
         ctx.meta = (N, k, n, M, tuple(float(c) for c in cam), tuple(bool(f) for f in flags))
