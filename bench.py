@@ -816,6 +816,35 @@ def bench_train_step(args):
     t_step = (time.perf_counter() - t0) / args.steps
     for _ in range(5):
         step(True)
+    # the step's longest launch, k_ng_backward_mfma, timed by HIP events on the op's stream around its C-ABI call (5 more steps): its
+    # matrix-pipe side against the dense f32 MFMA peak (1064 v_mfma_f32_32x32x2_f32 per 64-anchor tile, 4096 flop each)
+    import neural_gaussians as ngmod
+    real_call = ngmod._lib.lidargs_ng_backward_mfma
+    spans = []
+
+    class _Timed:                                                       # stands in for the ctypes library for five steps; every other name passes through
+        def __getattr__(self, name):
+            return getattr(ngmod._lib_real, name)
+
+        def lidargs_ng_backward_mfma(self, *a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); rc = real_call(*a); e1.record()
+            spans.append((e0, e1))
+            return rc
+
+    ngmod._lib_real, ngmod._lib = ngmod._lib, _Timed()
+    try:
+        for _ in range(5):
+            step(False)
+        torch.cuda.synchronize()
+    finally:
+        ngmod._lib = ngmod._lib_real
+    t_bwd_kernel = sum(a.elapsed_time(b) for a, b in spans) / max(1, len(spans)) * 1e-3
+    mfma_insts = ((N + 63) // 64) * 1064
+    mfma = {"bound": "mfma", "kernel": "k_ng_backward_mfma (the step's longest launch; HIP events around its C-ABI call inside the step)",
+            "achieved": mfma_insts * 4096.0 / t_bwd_kernel / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": mfma_insts * 4096.0 / t_bwd_kernel / 1e12 / 157.3,
+            "traffic": None, "ms": t_bwd_kernel * 1e3, "mfma_instructions_per_launch": mfma_insts,
+            "note": "f32-in / f32-accumulate tile products; they are a third of the launch, the per-anchor VALU stage and its LDS round trips the rest"}
     print(json.dumps({
         "metric": "training-step core (decode + rasterize + loss, fwd+bwd) per second", "value": 1.0 / t_step, "unit": "steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -823,7 +852,7 @@ def bench_train_step(args):
         "config": {"workload": f"train_step: {N} anchors x {k} offsets -> {info.get('gaussians')} Gaussians ({info.get('visible')} on screen) @ {H}x{W}; "
                                f"generate_neural_gaussians + GaussianRasterizer + image loss, backward to anchors and MLP weights"},
         "stage_ms": {"decode_fwd": acc[0] / 5, "rasterize_fwd": acc[1] / 5, "loss_fwd+grad": acc[2] / 5, "backward(raster+decode)": acc[3] / 5},
-        "roofline": None, "cpu_baseline": None}))
+        "roofline": mfma, "cpu_baseline": None}))
 
 
 def bench_chamfer(args):
