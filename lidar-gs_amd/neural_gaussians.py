@@ -55,6 +55,13 @@ def _pinned_counts(dev):
     return hit
 
 
+def _f32c(t):
+    """t as contiguous float32 -- t itself when it already is (the usual case: twenty tensors per call, three framework calls each otherwise)."""
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    return t.detach().to(torch.float32).contiguous()
+
+
 def _check(rc, what):
     if rc < 0:
         _base._raise(rc, what)
@@ -78,7 +85,7 @@ class _Decode(torch.autograd.Function):
         params, (cam, visible_mask, flags) = rest[:16], rest[16:]
         _base._require_device(anchor, "anchor")
         dev = anchor.device
-        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        f32 = _f32c
         anchor_feat, anchor, offset, scaling = f32(anchor_feat), f32(anchor), f32(offset), f32(scaling)
         params = tuple(f32(p) for p in params)
         N, k = int(anchor.shape[0]), int(offset.shape[1])
@@ -142,10 +149,10 @@ class _Decode(torch.autograd.Function):
         dev = anchor.device
         model = _model_struct(k, flags, params, w2t)
         camv = (C.c_float * 3)(*cam)
-        f = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.to(torch.float32).contiguous()
+        f = lambda g, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else _f32c(g)
         g_xyz, g_color, g_opacity = f(g_xyz, (M, 3)), f(g_color, (M, 2)), f(g_opacity, (M, 1))
         g_scaling, g_rot = f(g_scaling, (M, 3)), f(g_rot, (M, 4))
-        g_no = None if g_no is None else g_no.to(torch.float32).contiguous()
+        g_no = None if g_no is None else _f32c(g_no)
         dense = torch.empty(N * (32 + 3 + 3 * k + 6), dtype=torch.float32, device=dev)          # every row is written by the kernel
         p = _base._ptr
 
