@@ -26,7 +26,7 @@ class _ImageLoss(torch.autograd.Function):
         H, W = int(image.shape[-2]), int(image.shape[-1])
         if image.shape[0] != 2 or gt.shape[0] != 3 or depth.numel() != H * W:
             raise RuntimeError("image_loss: expected image [2,H,W], depth [1,H,W], gt_image [3,H,W]")
-        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        f32 = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
         img, dep, g = f32(image), f32(depth), f32(gt)
         losses = torch.empty(6, dtype=torch.float32, device=dev)
         g_image = torch.empty_like(img)

@@ -494,7 +494,7 @@ def shell_forward(module, means3D, colors, opacities, scales, rotations):
     N = H * W
     dev = means3D.device
     P = int(means3D.shape[0])
-    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    f32 = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
     inp = dict(means3D=f32(means3D), colors=f32(colors), opacities=f32(opacities), scales=f32(scales), rotations=f32(rotations),
                viewmatrix=f32(rs.viewmatrix), beams=f32(rs.beam_inclinations), H=H, W=W, scale_modifier=float(rs.scale_modifier),
                far=int(rs.lidar_far), near=int(rs.lidar_near), bg=rs.bg.to(torch.float32).to(dev).contiguous())
@@ -665,7 +665,7 @@ def wedge_forward(module, means3D, colors, opacities, scales, rotations):
     H, W = int(rs.image_height), int(rs.image_width)
     dev = means3D.device
     P = int(means3D.shape[0])
-    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    f32 = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
     inp = dict(means3D=f32(means3D), colors=f32(colors), opacities=f32(opacities), scales=f32(scales), rotations=f32(rotations),
                viewmatrix=f32(rs.viewmatrix), beams=f32(rs.beam_inclinations), H=H, W=W, scale_modifier=float(rs.scale_modifier),
                far=int(rs.lidar_far), near=int(rs.lidar_near), bg=rs.bg.to(torch.float32).to(dev).contiguous())

@@ -282,7 +282,7 @@ def training_statis(pc, viewspace_point_tensor, opacity, update_filter, offset_s
     _base._require_device(pc.opacity_accum, "opacity_accum")
     N, k = int(pc.opacity_accum.shape[0]), int(pc.n_offsets)
     u8 = lambda t: t.to(torch.bool).contiguous().view(torch.uint8)
-    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    f32 = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
     for t in (pc.opacity_accum, pc.anchor_demon, pc.offset_gradient_accum, pc.offset_denom):
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("training_statis: the accumulators must be contiguous float32 tensors")
