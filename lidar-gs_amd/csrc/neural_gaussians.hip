@@ -766,8 +766,12 @@ template <int K>
 __global__ void __launch_bounds__(NG_BLOCK) k_ng_opacity_mfma(int N, NgModel m, float3 cam, const float* __restrict__ feat, const float* __restrict__ anchor,
                                                               const uint32_t* __restrict__ vis_flags, const uint32_t* __restrict__ vis_idx,
                                                               float* __restrict__ neural_opacity, uint8_t* __restrict__ mask, uint32_t* __restrict__ sel_flags) {
-    __shared__ float s_x[NG_XS * NG_LS], s_h[NG_HID * NG_LS];
-    float* const s_y = s_x;                                            // the k outputs over x, dead behind the hidden layer (18.7 KB: eight waves to a CU)
+    // one MLP, one wave: x is dead once the hidden layer's products are in the accumulators, so h is written over it (rows 0..31) and
+    // the k outputs behind h -- 10.4 KB instead of x, h and y side by side (20.8 KB): the registers, not LDS, set the occupancy now
+    constexpr int UROWS = NG_HID + K > NG_XS ? NG_HID + K : NG_XS;
+    __shared__ float s_x[UROWS * NG_LS];
+    float* const s_h = s_x;
+    float* const s_y = s_x + NG_HID * NG_LS;
     const int lane = threadIdx.x;
     const int i = blockIdx.x * NG_BLOCK + lane;
     const bool vis = i < N && vis_flags[i] != 0u;
