@@ -130,3 +130,22 @@ def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_buil
     assert int((r["mask"] != exp["out_mask"]).sum()) == 0
     for k in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
         parity(k, r[k], exp["out_" + k])
+
+
+def test_decode_queued_behind_the_selection_equals_the_waiting_form(hip_lib_built, monkeypatch):
+    """By default the decode is queued right behind the selection with output arrays of N k rows (the upper bound of M) and the host
+    waits for the two counts while it runs (`lidargs_ng_forward_select_enqueue`); `LIDARGS_NG_CAPACITY_BYTES=0` (or an N k x 52-byte
+    block above the limit) waits first and allocates M rows.  Same kernels on the same inputs: every output, the mask and every
+    gradient bit for bit, and the outputs are contiguous [M, c] tensors either way."""
+    import neural_gaussians as mod
+    p, cam, vis, rng = random_case(9000, 6, 21, (True, True, True))
+    f = ng.forward(p, cam, vis)
+    M = f["xyz"].shape[0]
+    ups = [rng.normal(size=s).astype(np.float32) for s in ((M, 3), (M, 2), (M, 1), (M, 3), (M, 4))]
+    assert 0 < 9000 * 6 * 52 <= mod._CAPACITY_BYTES
+    queued = run_hip(p, cam, vis, ups)
+    monkeypatch.setattr(mod, "_CAPACITY_BYTES", 0)
+    waited = run_hip(p, cam, vis, ups)
+    assert queued["xyz"].shape == (M, 3) and queued["rot"].shape == (M, 4)
+    for key in queued:
+        assert np.array_equal(queued[key], waited[key]), key
