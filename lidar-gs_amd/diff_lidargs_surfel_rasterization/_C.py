@@ -37,11 +37,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _require_device(means3D, "means3D")
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_others = torch.zeros((7, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    radii_xy = torch.zeros((2 * P,), dtype=torch.int32, device=dev)
-    pixels = torch.zeros((P, 1), dtype=torch.float32, device=dev)
+    mk = torch.empty if P != 0 else torch.zeros                       # the library writes every pixel and every row (as the 3-D binding relies on)
+    out_color = mk((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_others = mk((7, H, W), dtype=torch.float32, device=dev)
+    radii = mk((P,), dtype=torch.int32, device=dev)
+    radii_xy = mk((2 * P,), dtype=torch.int32, device=dev)
+    pixels = torch.zeros((P, 1), dtype=torch.float32, device=dev)      # never written, by the reference either (R2/cr/forward.cu:522): zeros
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     rendered = 0
     if P != 0:

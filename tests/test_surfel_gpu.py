@@ -94,6 +94,25 @@ def test_surfel_config5_shape_crop():
     _check(surfel_scene("shell", 20_000, 64, 11), 2650, 64, 11)
 
 
+def test_surfel_outputs_are_written_everywhere():
+    """The binding hands the library uninitialised outputs (as the 3-D binding does): every pixel of both images and every row of the
+    radii must be written whatever the frame holds.  The caching allocator is primed with NaN / -1 blocks of the outputs' sizes so that
+    an element the library skipped shows up: a frame whose surfels cover a corner of the image, and one with everything culled."""
+    import torch
+    H, W, P = 16, 400, 300
+    few = surfel_scene("shell", P, H, 9)
+    culled = dict(few); culled["means3D"] = (few["means3D"] * 1000.0).astype(np.float32)
+    for scene in (few, culled):
+        for shape, dt, val in (((2, H, W), torch.float32, float("nan")), ((7, H, W), torch.float32, float("nan")), ((P,), torch.int32, -1),
+                               ((2 * P,), torch.int32, -1)):
+            t = torch.full(shape, val, dtype=dt, device="cuda"); del t      # its block is what torch.empty gets next
+        hip = hip_surfel_forward_backward(scene, W, H, None)
+        ref = oracle_surfel_forward_backward(scene, W, H, None)
+        assert np.isfinite(hip["color"]).all() and np.isfinite(hip["others"]).all()
+        assert (hip["radii"] >= 0).all() and np.array_equal(hip["radii"], ref["radii"])
+        parity("color", hip["color"], ref["color"])
+
+
 def test_surfel_empty_and_all_culled():
     import torch
     sc = surfel_scene("shell", 64, 16, 2)
