@@ -349,7 +349,10 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         if (threadIdx.x == 6 || threadIdx.x == 7) {
             const int c = threadIdx.x;
             const uint32_t m = max(max(s_part[0][c], s_part[1][c]), max(s_part[2][c], s_part[3][c]));
-            if (m) atomicMax(a.key_span + 2 * (size_t)(blockIdx.x % LG_INST_SLOTS) + (c - 6), m);
+            uint32_t* ks = a.key_span + 2 * (size_t)(blockIdx.x % LG_INST_SLOTS) + (c - 6);
+            // the maxima only grow: a plain look first (stale at worst = lower = one atomic too many) spares all but the few blocks that
+            // raise one their atomic on the slots' four cache lines
+            if (m > __hip_atomic_load(ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ks, m);
         }
         if (threadIdx.x < 6) {
             const uint32_t sum = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];

@@ -95,6 +95,7 @@ struct SfPreArgs {
     uint32_t* dirty;       // the geometry buffer's "gradient lines hold sums" word (LG_TOTALS_DIRTY_WORD): cleared here
     unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: word 0 of each slot = part of the instance total (zeroed by the caller)
     unsigned long long* diag_slots;     // [LG_INST_SLOTS][2]: visible surfels, reference tiles_touched (diagnostics)
+    uint32_t* key_span;                 // [LG_INST_SLOTS][2]: ~(smallest), largest range key of the visible surfels (zeroed by the caller), as k_preprocess
     int compact;                        // 4-byte span records (compact_spans)
     float4* gacc;          // [8P] packed gradient lines of the backward: zeroed here for every surfel with radii > 0
 };
@@ -194,13 +195,38 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     {   // the instance total (what the host sizes the binning buffer with), known before anything is sorted: one sum per wave, added
         // to one of LG_INST_SLOTS slots (k_preprocess has the same, per tile height); the host adds the slots up after its one read
         uint32_t sum = tiles, sv = reftiles ? 1u : 0u, sr = reftiles;       // (+ the diagnostics of lidargs_last_counters)
+        // ~(smallest) and largest range key of the wave's visible surfels (0xFFFFFFFF: culled -> neutral for both maxima): the range sort
+        // runs on key - kmin and skips the passes the frame's key span does not need (api.hip, surfel_api.inc)
+        uint32_t kinv = ~key, kmx = (key == 0xFFFFFFFFu) ? 0u : key;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sv += __shfl_xor(sv, o); sr += __shfl_xor(sr, o); }
-        if ((threadIdx.x & 63) == 0 && sv) {
-            const size_t slot = (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % LG_INST_SLOTS);
-            if (sum) atomicAdd(a.inst_slots + slot * 4, (unsigned long long)sum);
-            atomicAdd(a.diag_slots + slot * 2, (unsigned long long)sv);
-            atomicAdd(a.diag_slots + slot * 2 + 1, (unsigned long long)sr);
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o); sv += __shfl_xor(sv, o); sr += __shfl_xor(sr, o);
+            kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, o)); kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o));
+        }
+        // one set of atomics per BLOCK, not per wave (k_preprocess does the same): 31 k waves x 5 atomics on a few cache lines serialise
+        // at ~11 ns each on a line -- two more per wave for the key span made this launch 141 -> 205 us before they met in LDS first
+        __shared__ uint32_t s_part[4][5];
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t* q = s_part[threadIdx.x >> 6];
+            q[0] = sum; q[1] = sv; q[2] = sr; q[3] = kinv; q[4] = kmx;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            const int c = threadIdx.x;
+            const size_t slot = (size_t)(blockIdx.x % LG_INST_SLOTS);
+            if (c < 3) {
+                const uint32_t v = s_part[0][c] + s_part[1][c] + s_part[2][c] + s_part[3][c];
+                if (v) {
+                    if (c == 0) atomicAdd(a.inst_slots + slot * 4, (unsigned long long)v);
+                    else atomicAdd(a.diag_slots + slot * 2 + (c - 1), (unsigned long long)v);
+                }
+            } else if (a.key_span) {
+                const uint32_t m = max(max(s_part[0][c], s_part[1][c]), max(s_part[2][c], s_part[3][c]));
+                uint32_t* ks = a.key_span + 2 * slot + (c - 3);
+                // the maxima only grow: a plain look first (stale at worst = lower = one atomic too many) spares all but the few blocks
+                // that raise one their atomic
+                if (m > __hip_atomic_load(ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ks, m);
+            }
         }
     }
     // the packed 128-byte gradient lines the backward adds into are zeroed here, not by a 128 B x P fill launch per frame: the wave
