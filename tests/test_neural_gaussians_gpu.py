@@ -142,7 +142,7 @@ def test_decode_queued_behind_the_selection_equals_the_waiting_form(hip_lib_buil
     f = ng.forward(p, cam, vis)
     M = f["xyz"].shape[0]
     ups = [rng.normal(size=s).astype(np.float32) for s in ((M, 3), (M, 2), (M, 1), (M, 3), (M, 4))]
-    assert 0 < 9000 * 6 * 52 <= mod._CAPACITY_BYTES
+    monkeypatch.setattr(mod, "_CAPACITY_BYTES", 1 << 30)             # whatever LIDARGS_NG_CAPACITY_BYTES says in this environment
     queued = run_hip(p, cam, vis, ups)
     monkeypatch.setattr(mod, "_CAPACITY_BYTES", 0)
     waited = run_hip(p, cam, vis, ups)
