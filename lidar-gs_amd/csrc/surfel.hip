@@ -827,7 +827,15 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
         return;
     }
     const float* vm = a.view;
-    const float* g = a.gacc + 32 * (size_t)idx;
+    // the surfel's 128-byte line as eight 16-byte loads issued together (the slots are read all over the function: left to the
+    // compiler they became a dozen 4-/8-/12-byte loads, each a pass over 64 different lines for the wave)
+    float gl[32];
+    {
+        const float4* g4 = reinterpret_cast<const float4*>(a.gacc) + 8 * (size_t)idx;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float4 v = g4[k]; gl[4 * k] = v.x; gl[4 * k + 1] = v.y; gl[4 * k + 2] = v.z; gl[4 * k + 3] = v.w; }
+    }
+    const float* g = gl;
     const float3 pw = sf3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
     const float3 pv = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
                           vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
