@@ -157,6 +157,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
         if (dist >= pp.far_f || dist <= pp.near_f) break;            // R3/cr/forward.cu:304
         if (!(dist >= pp.shell_lo && dist < pp.shell_hi)) break;     // range shell (multi-GPU only)
+        // every other input of a surviving Gaussian is requested here, together: the opacity and the colours are needed a thousand
+        // instructions further down, where a load issued on the spot would be waited for
+        const float op_in = FILTER ? 0.f : a.opacities[idx], col0_in = FILTER ? 0.f : a.colors[2 * idx], col1_in = FILTER ? 0.f : a.colors[2 * idx + 1];   // (K2 has neither)
 
         Sym3 S;
         if (a.cov3D_precomp) {
@@ -259,7 +262,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // an axis-aligned bound in (column, row) that follows the footprint's anisotropy.  Tiles / rows outside it
         // are dropped from the lists without changing any pixel; the margins cover float rounding.
         int tx0 = xmin, tx1 = xmax, ty_lo = ymin, ty_hi = ymax;
-        const float op = a.opacities[idx];
+        const float op = op_in;
         // The bounds below turn |sin(dbeta)| <= sb into |dbeta| <= asin(sb), which holds on [0, pi/2] only.  The reference evaluates the
         // Gaussian at EVERY pixel of the 16-column tiles its rect touches, and a pixel looking the other way (dbeta near pi) has
         // sin(dbeta) near 0 again: delta = pixel_dir - dir projects onto the tangent plane as (0, 0) at the antipode, so the reference
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         r0 = make_float4(dir.x, dir.y, dir.z, dist);
         r1 = make_float4(u1.x * i1, u2.x * i2, u1.y * i1, u2.y * i2);                  // (u1', u2') interleaved by component:
         r2 = make_float4(u1.z * i1, u2.z * i2, conA, conC);                            // the blend evaluates both projections in
-        r3 = make_float4(conB, a.opacities[idx], a.colors[2 * idx], a.colors[2 * idx + 1]);   // packed-fp32 operations
+        r3 = make_float4(conB, op_in, col0_in, col1_in);   // packed-fp32 operations
     } while (false);
 
     if (in_range) {
@@ -349,10 +352,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         if (threadIdx.x == 6 || threadIdx.x == 7) {
             const int c = threadIdx.x;
             const uint32_t m = max(max(s_part[0][c], s_part[1][c]), max(s_part[2][c], s_part[3][c]));
-            uint32_t* ks = a.key_span + 2 * (size_t)(blockIdx.x % LG_INST_SLOTS) + (c - 6);
-            // the maxima only grow: a plain look first (stale at worst = lower = one atomic too many) spares all but the few blocks that
-            // raise one their atomic on the slots' four cache lines
-            if (m > __hip_atomic_load(ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ks, m);
+            // (a plain look at the slot first, to skip the atomic when it would change nothing, cost 14 us of this launch: the load has to
+            //  come back before the block can retire, the atomic does not)
+            if (m) atomicMax(a.key_span + 2 * (size_t)(blockIdx.x % LG_INST_SLOTS) + (c - 6), m);
         }
         if (threadIdx.x < 6) {
             const uint32_t sum = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];

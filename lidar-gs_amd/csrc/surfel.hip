@@ -223,9 +223,7 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
             } else if (a.key_span) {
                 const uint32_t m = max(max(s_part[0][c], s_part[1][c]), max(s_part[2][c], s_part[3][c]));
                 uint32_t* ks = a.key_span + 2 * slot + (c - 3);
-                // the maxima only grow: a plain look first (stale at worst = lower = one atomic too many) spares all but the few blocks
-                // that raise one their atomic
-                if (m > __hip_atomic_load(ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ks, m);
+                if (m) atomicMax(ks, m);
             }
         }
     }
