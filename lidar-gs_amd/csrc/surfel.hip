@@ -129,6 +129,9 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         float2 pim;
         if (!sf_pix(pv, a.W, a.H, beams_tab, true, a.col_step, pim)) break;
 
+        // every other input of a surviving surfel is requested here, together (the opacity and the colours are needed at the very end, where a
+        // load issued on the spot would be waited for; K2 has neither)
+        const float op_in = FILTER ? 0.f : a.opacities[idx], col0_in = FILTER ? 0.f : a.colors[2 * idx], col1_in = FILTER ? 0.f : a.colors[2 * idx + 1];
         const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
         float3 c0, c1, c2;
         sf_quat_cols(q, c0, c1, c2);
@@ -178,8 +181,8 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         const float iu = uu > 0.f ? 1.f / uu : 0.f, iv = vv > 0.f ? 1.f / vv : 0.f;
         // (Tu', Tv') interleaved by component: the blend evaluates s = (dp.Tu', dp.Tv') and its gradients as packed-fp32 pairs
         r0 = make_float4(Bu.x * iu, Bv.x * iv, Bu.y * iu, Bv.y * iv);
-        r1 = make_float4(Bu.z * iu, Bv.z * iv, a.opacities[idx], a.colors[2 * idx]);
-        r2 = make_float4(Bw.x, Bw.y, Bw.z, a.colors[2 * idx + 1]);
+        r1 = make_float4(Bu.z * iu, Bv.z * iv, op_in, col0_in);
+        r2 = make_float4(Bw.x, Bw.y, Bw.z, col1_in);
         // lambda = |Tw| * cos(phi1) with cos(phi1) = (Tw.n)/|Tw|, rounded in the reference's order (:449-452): the hit
         // point lam2 * p - Tw cancels ~3 digits, so a 1-ulp change of lambda is a 1e-4 change of the Gaussian weight
         const float wn = Bw.x * n.x + Bw.y * n.y + Bw.z * n.z;
