@@ -436,6 +436,7 @@ struct RenderFwdArgs {
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
     WorkList fill;            // k_render_combine: the backward's work list (cnt == nullptr: none)
+    int walk2;                // k_render_fused: the second form of the T-only walk (set by its launcher)
 };
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s);     // T-only walk of every segment
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s);

@@ -197,12 +197,174 @@ __device__ __forceinline__ void walk_flagged(unsigned long long todo, const floa
     }
 }
 
+// The T-only walk over entries [0, cnt) of a chunk, second form (round 4).  What the first form (walk_flagged<true>) pays per entry
+// beside its ~21 vector instructions is ~14 scalar ones and 3-4 waits -- loop control, the clamped look-ahead index and its address,
+// the 64-bit took mask, and the `done` mask, which sits ON the loop-carried path: compare -> s_and / s_or -> the next entry's select
+// in front of its exp (a VALU -> SGPR -> SALU -> VALU round trip per entry).  A wave that is alone on its SIMD issues one instruction
+// per ~4.5 clocks whatever its kind, so those count like the arithmetic.  Here:
+//   * alpha of an entry does not depend on the entries before it; only T does, through one multiply per entry (a lane whose walk
+//     has tripped keeps multiplying: any value below `stop` is an equally good hand-over, every consumer only compares it with 1e-4
+//     or multiplies on);
+//   * entries come in groups of four with constant LDS offsets off one advancing address; the lanes behind the chunk's count parked
+//     zero records (alpha = 0), so a group needs no tail handling;
+//   * `dead` (the lanes that are out: outside the image, or T below `stop`) is refreshed once per group and only gates the
+//     contribution flags (a superset by at most three entries per trip: pass 2 applies the exact rule to the flagged entries);
+//   * the took bits are shifted into a scalar accumulator (s_andn2 sets SCC, s_addc shifts it in), newest entry at bit 0.
+// Same products in the same order as the first form while nothing trips: the Tpass planes are bit-identical.
+template <bool TRACK>
+__device__ __forceinline__ void walk_T_only_v2(const int cnt, const float4* s_rec, const float* oprow, const v2f qxy, const float qz,
+                                               WalkState& w, const unsigned long long dead0, const float stop = 0.0001f) {
+    struct Rec { float4 r0, r1, r2; float op; };
+    auto read = [&](int jj) {
+        Rec r;
+        r.r0 = lds_ahead(&s_rec[jj]);                                  // s.xyz | B  (park_record)
+        r.r1 = lds_ahead(&s_rec[LG_CHUNK + jj]); r.r2 = lds_ahead(&s_rec[2 * LG_CHUNK + jj]);
+        r.op = lds_ahead(&oprow[4 * jj]);
+        return r;
+    };
+    // -> the factor (1 - alpha) of this pixel for the entry (1 when it does not take it) and the lanes that take it
+    auto factor = [&](const Rec& r, unsigned long long& hitmask) {
+        const v2f exy = v2f{r.r0.x, r.r0.y} - qxy;
+        const float ez = r.r0.z - qz;
+        const v2f d = exy.x * v2f{r.r1.x, r.r1.y} + exy.y * v2f{r.r1.z, r.r1.w} + ez * v2f{r.r2.x, r.r2.y};
+        const v2f qd = v2f{r.r2.z, r.r2.w} * d * d;
+        const float power = -0.5f * (qd.x + qd.y) - r.r0.w * d.x * d.y;   // :601
+        const float pw = (power <= 0.0f) ? power : -INFINITY;             // :602 (exp(-inf) = 0: fails the 1/255 test)
+        const float alpha = fminf(0.99f, r.op * __expf(pw));
+        const bool hit = alpha >= 1.0f / 255.0f;
+        hitmask = __ballot(hit);
+        return hit ? 1.f - alpha : 1.f;
+    };
+    float T = w.T;
+    unsigned long long dead = dead0 | __ballot(T < stop);
+    uint32_t acc_lo = 0u, acc_hi = 0u;                                 // took bits, newest entry at bit 0
+    // acc = (acc << 1) | ((hitmask & ~dead) != 0) in three scalar instructions: s_andn2 leaves "result != 0" in SCC, the two s_addc shift
+    // it in (x + x + carry) and carry bit 31 of the low word into the high one.  (Written out: the compiler's form of the same goes
+    // through a v_cndmask and a v_readfirstlane per entry.)
+    auto note = [&](unsigned long long hitmask) {
+        if (TRACK) {
+            unsigned long long tmp;
+            asm volatile("s_andn2_b64 %2, %3, %4\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1"
+                         : "+s"(acc_lo), "+s"(acc_hi), "=&s"(tmp) : "s"(hitmask), "s"(dead) : "scc");
+        }
+    };
+    const int ng = (cnt + 3) >> 2;
+    Rec ra = read(0), rb = read(1);
+    for (int g = 0; g < ng; g++) {
+        const int j = 4 * g;
+        unsigned long long h0, h1, h2, h3;
+        const float f0 = factor(ra, h0); ra = read(j + 2);
+        const float f1 = factor(rb, h1); rb = read(j + 3);
+        const float f2 = factor(ra, h2); ra = read(j + 4);
+        const float f3 = factor(rb, h3); rb = read(j + 5);
+        note(h0); note(h1); note(h2); note(h3);
+        T = T * f0; T = T * f1; T = T * f2; T = T * f3;
+        dead = dead0 | __ballot(T < stop);
+    }
+    w.T = T;
+    w.done = w.done || (T < stop);
+    if (TRACK) {
+        // entry e of the chunk sits at bit 4 ng - 1 - e of the accumulator
+        const unsigned long long acc = ((unsigned long long)acc_hi << 32) | acc_lo;
+        const unsigned long long rev = __brevll(acc) >> (64 - 4 * ng);
+        w.took = rev;
+    }
+}
+
+// The full walk, second form: over entries [0, cnt) of a chunk whose visited records were parked COMPACTED (park_compact below: the
+// flagged entries first, in list order, zero records behind them), in groups of four like walk_T_only_v2.  No mask scan per entry
+// (find-first-set, clear, compare, the look-ahead's clamp and address: ~10 scalar instructions), and no `done` mask on the
+// loop-carried path.  The per-pixel state is three things:
+//   Tw   the working transmittance, NEGATED once the pixel is out (outside the image, started below 1e-4, or its walk tripped): then
+//        test = Tw (1 - alpha) <= 0 fails `test >= stop` by itself, nothing is blended any more, and |Tw| stays the transmittance
+//        after the last blended entry (R3/cr/forward.cu:608-618);
+//   C01, D   the sums;   last   the 1-based position of the last blended entry (its position rides in the parked record).
+// An entry a live pixel does not take has alpha_eff = 0: test = Tw exactly, blended with weight 0.  The same products and sums in
+// the same order as the first form.  T_break (only ever compared with 1e-4 by its consumers -- the combine's stop test, the shells'
+// compose) is T while the pixel is live and 0 once its walk has tripped here.
+template <bool TRACK>
+__device__ __forceinline__ void walk_full_v2(const int cnt, const float4* s_rec, const float* oprow, const v2f qxy, const float qz, WalkState& w) {
+    struct Rec { float4 r0, r1, r2, r3; float op; };
+    auto read = [&](int jj) {
+        Rec r;
+        r.r0 = lds_ahead(&s_rec[jj]);                                  // s.xyz | B
+        r.r1 = lds_ahead(&s_rec[LG_CHUNK + jj]); r.r2 = lds_ahead(&s_rec[2 * LG_CHUNK + jj]);
+        r.r3 = lds_ahead(&s_rec[3 * LG_CHUNK + jj]);                   // range, position, colour0, colour1
+        r.op = lds_ahead(&oprow[4 * jj]);
+        return r;
+    };
+    auto alpha_eff = [&](const Rec& r) {
+        const v2f exy = v2f{r.r0.x, r.r0.y} - qxy;
+        const float ez = r.r0.z - qz;
+        const v2f d = exy.x * v2f{r.r1.x, r.r1.y} + exy.y * v2f{r.r1.z, r.r1.w} + ez * v2f{r.r2.x, r.r2.y};
+        const v2f qd = v2f{r.r2.z, r.r2.w} * d * d;
+        const float power = -0.5f * (qd.x + qd.y) - r.r0.w * d.x * d.y;   // :601
+        const float pw = (power <= 0.0f) ? power : -INFINITY;             // :602
+        const float alpha = fminf(0.99f, r.op * __expf(pw));
+        return (alpha >= 1.0f / 255.0f) ? alpha : 0.f;                    // :605
+    };
+    const bool was_done = w.done;
+    float Tw = was_done ? -w.T : w.T;
+    v2f C01 = w.C01; float D = w.D; uint32_t last = w.last;
+    uint32_t acc_lo = 0u, acc_hi = 0u;
+    auto blend = [&](const Rec& r, const float a) {
+        const float test = Tw * (1.f - a);
+        const bool ok = test >= 0.0001f;                               // live, and this entry does not trip it (:608-613)
+        const float wt = ok ? a * Tw : 0.f;
+        C01 += v2f{r.r3.z, r.r3.w} * wt; D += r.r3.x * wt;             // :615-617
+        const bool blended = wt > 0.f;
+        last = blended ? __float_as_uint(r.r3.y) : last;
+        Tw = ok ? test : -fabsf(Tw);
+        if (TRACK) {
+            const unsigned long long m = __ballot(blended);
+            asm volatile("s_cmp_lg_u64 %2, 0\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1" : "+s"(acc_lo), "+s"(acc_hi) : "s"(m) : "scc");
+        }
+    };
+    const int ng = (cnt + 3) >> 2;
+    Rec ra = read(0), rb = read(1);
+    for (int g = 0; g < ng; g++) {
+        const int j = 4 * g;
+        const float a0 = alpha_eff(ra); const Rec r0 = ra; ra = read(j + 2);
+        const float a1 = alpha_eff(rb); const Rec r1 = rb; rb = read(j + 3);
+        blend(r0, a0); blend(r1, a1);
+        const float a2 = alpha_eff(ra); const Rec r2 = ra; ra = read(j + 4);
+        const float a3 = alpha_eff(rb); const Rec r3 = rb; rb = read(j + 5);
+        blend(r2, a2); blend(r3, a3);
+    }
+    const bool now_done = (__float_as_uint(Tw) >> 31) != 0u;
+    w.T = fabsf(Tw);
+    w.T_break = now_done ? (was_done ? w.T_break : 0.f) : Tw;
+    w.done = now_done;
+    w.C01 = C01; w.D = D; w.last = last;
+    if (TRACK) {
+        const unsigned long long acc = ((unsigned long long)acc_hi << 32) | acc_lo;
+        w.took = __brevll(acc) >> (64 - 4 * ng);
+    }
+}
+
+// Parks a chunk's records for the second form of the walks: lane `lane` holds entry `lane` of the chunk (zeros if it is not to be
+// visited); the visited ones go to slots 0 .. cnt-1 in list order, the others behind them, so that every slot is written and the
+// slots behind cnt hold zero records (alpha = 0).  `pos`: the entry's 1-based position in its segment.  Returns cnt.
+__device__ __forceinline__ int park_compact(float4* s_rec, float4* s_oprow, const int lane, const bool have, const Staged& st, const uint32_t pos, const int y0) {
+    const unsigned long long todo = __ballot(have);
+    const int cnt = __builtin_popcountll(todo);
+    const uint32_t lo = (uint32_t)todo, hi = (uint32_t)(todo >> 32);
+    const int before = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));   // visited entries in front of this lane
+    const int slot = have ? before : cnt + (lane - before);
+    s_rec[slot] = make_float4(st.a0.x, st.a0.y, st.a0.z, st.a3.x);
+    s_rec[LG_CHUNK + slot] = st.a1;
+    s_rec[2 * LG_CHUNK + slot] = st.a2;
+    s_rec[3 * LG_CHUNK + slot] = make_float4(st.a0.w, __uint_as_float(pos), st.a3.z, st.a3.w);
+    s_oprow[slot] = rows_opacity(st.span, st.a3.y, y0);
+    return cnt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One workgroup = (patch, segment).  T_ONLY: pass 1.  Otherwise pass 2.
-template <bool T_ONLY>
+template <bool T_ONLY, bool V2 = false>
 __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ float4 s_oprow[LG_CHUNK];                               // the entry's opacity per pixel row of this patch, 0 outside its row span
+    __shared__ float4 s_oprow[LG_CHUNK + 2];                           // the entry's opacity per pixel row of this patch, 0 outside its row span (+2: the second form's look-ahead reads)
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -224,6 +386,14 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
     const v2f qxy = v2f{px.q.x, px.q.y};
 
+    uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
+    // pass 2, second form: the first chunk's list entries and flags are requested in front of the transmittance planes (a loop of
+    // loads and waits), so that the two round trips -- ids, then records -- overlap it instead of following it
+    uint32_t g_first = 0u; bool have_first = false;
+    if (!T_ONLY && V2 && n > 0) {
+        g_first = (uint32_t)lane < n ? a.point_list[sr.x + lane] : 0u;
+        have_first = (uint32_t)lane < n && (!fl || fl[lane] != 0);
+    }
     float T = 1.0f;
     if (!T_ONLY) {
         if (a.T_in && px.inside) T = a.T_in[px.pix];
@@ -238,7 +408,6 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     // backward) then touch only flagged entries -- no record gather, no LDS traffic, no evaluation for the rest.
     // Pass 1 starts from T = 1 (>= the true transmittance), so every pixel is active at least as long as in
     // pass 2: the flagged set is a superset of what pass 2 / backward can ever blend.
-    uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
     uint32_t c_done = 0;                                               // chunks whose flags pass 1 has written
     if (__ballot(!w.done) != 0ull && n > 0) {
         auto entry_valid = [&](uint32_t k) { return k < n && (T_ONLY || !fl || fl[k] != 0); };
@@ -248,12 +417,18 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
             return gather_record(a.rec, a.rowspan, g, have);
         };
         bool have;
-        Staged st = fetch((uint32_t)lane, have);
+        Staged st;
+        if (!T_ONLY && V2) { have = have_first; st = gather_record(a.rec, a.rowspan, g_first, have); }
+        else st = fetch((uint32_t)lane, have);
         for (uint32_t c = 0; c < nchunks; c++) {
             __syncthreads();
-            park_record(s_rec, lane, st);
-            s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
             unsigned long long todo = __ballot(have);                  // entries of this chunk worth visiting
+            int cnt = 0;
+            if (!T_ONLY && V2) cnt = park_compact(s_rec, s_oprow, lane, have, st, c * LG_CHUNK + (uint32_t)lane + 1u, y0);
+            else {
+                park_record(s_rec, lane, st);
+                s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
+            }
             __syncthreads();
             if (c + 1 < nchunks) {
                 st = fetch((c + 1) * LG_CHUNK + lane, have);
@@ -261,7 +436,9 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
             if (__ballot(!w.done) == 0ull) break;                       // R3/cr/forward.cu:559-561 early-out
             w.took = 0ull;
             if (todo) {
-                walk_flagged<T_ONLY>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
+                if (T_ONLY && V2) walk_T_only_v2<true>(__builtin_popcountll(todo), s_rec, oprow, qxy, px.q.z, w, __ballot(!px.inside));
+                else if (V2) walk_full_v2<false>(cnt, s_rec, oprow, qxy, px.q.z, w);
+                else walk_flagged<T_ONLY>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
             }
             if (T_ONLY && fl) {
                 const uint32_t k = c * LG_CHUNK + lane;
@@ -302,10 +479,10 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
 // every entry, records the contribution flags itself (exact ones: a subset of what the T-only walks, which restart from T = 1 in
 // every segment, would flag), and leaves in the head's T_pass planes the hand-over value (in segment 0's; 1 in the others), so that
 // the product pass 2 and k_render_alive form over the segments in front of the tail is the transmittance the tail starts from.
-template <bool FIRST>
+template <bool FIRST, bool V2 = false>
 __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs a, const int G) {
     __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ float4 s_oprow[LG_CHUNK];
+    __shared__ float4 s_oprow[LG_CHUNK + 2];
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -354,15 +531,22 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
         if (!all_done) {
             for (uint32_t c = 0; c < nchunks; c++) {
                 __syncthreads();
-                park_record(s_rec, lane, st);
-                s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
                 const unsigned long long todo = __ballot(have);
+                int cnt = 0;
+                if (V2) cnt = park_compact(s_rec, s_oprow, lane, have, st, c * LG_CHUNK + (uint32_t)lane + 1u, y0);   // (FIRST: every entry is visited, slot = lane)
+                else {
+                    park_record(s_rec, lane, st);
+                    s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
+                }
                 __syncthreads();
                 if (c + 1 < nchunks) st = fetch(sr, n, c + 1, have);
                 else if (sg + 1 < s1) { const uint2 nsr = segment_range(tr, St, sg + 1); st = fetch(nsr, nsr.y - nsr.x, 0u, have); }
                 if (__ballot(!w.done) == 0ull) { all_done = true; break; }   // R3/cr/forward.cu:559-561 early-out
                 w.took = 0ull;
-                if (todo) walk_flagged<false, FIRST>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
+                if (todo) {
+                    if (V2) walk_full_v2<FIRST>(cnt, s_rec, oprow, qxy, px.q.z, w);
+                    else walk_flagged<false, FIRST>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, w);
+                }
                 if (FIRST && flp) {
                     const uint32_t k = c * LG_CHUNK + lane;
                     if (k < n) flp[sr.x + k] = (uint8_t)((w.took >> lane) & 1ull);
@@ -415,7 +599,7 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a) {
     __shared__ float4 s_rec_all[NW][4 * LG_CHUNK];
-    __shared__ float4 s_oprow_all[NW][LG_CHUNK];
+    __shared__ float4 s_oprow_all[NW][LG_CHUNK + 2];                 // (+2: walk_T_only_v2's look-ahead reads)
     __shared__ float s_x[NW][6][64];                                   // per wave: Tpass | C0, C1, D, T_end, T_break of its segment
     __shared__ unsigned long long s_took[NW][8];                       // contribution masks of the chunks of the wave's segment (<= 8 kept)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -453,6 +637,7 @@ __global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a)
             // (a hair low: a smaller threshold only walks further, never stops a lane the serial walk would still blend)
             const float stop = carry > 0.0001f ? (0.0001f / carry) * 0.999f : 2.0f;   // carry already below: every hit ends the walk
             WalkState ws{1.0f, 1.0f, v2f{0.f, 0.f}, 0.f, 0u, !px.inside || carry < 0.0001f, 0ull};
+            const unsigned long long dead0 = __ballot(ws.done);
             uint32_t c_done = 0;
             if (__ballot(!ws.done) != 0ull && n > 0) {
                 bool have;
@@ -472,7 +657,10 @@ __global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a)
                     if (c + 1 < nchunks) st = fetch((c + 1) * LG_CHUNK + lane, have);
                     if (__ballot(!ws.done) == 0ull) break;
                     ws.took = 0ull;
-                    if (todo) walk_flagged<true>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, ws, stop);
+                    if (todo) {
+                        if (a.walk2) walk_T_only_v2<true>(__builtin_popcountll(todo), s_rec, oprow, qxy, px.q.z, ws, dead0, stop);
+                        else walk_flagged<true>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, ws, stop);
+                    }
                     const uint32_t kk = c * LG_CHUNK + lane;
                     if (kk < n) flp[sr.x + kk] = (uint8_t)((ws.took >> lane) & 1ull);
                     if (lane == 0 && c < 8) s_took[w][c] = ws.took;
@@ -663,8 +851,14 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     a.out_occ[pix] = 1.f - T_final;
 }
 
+// LIDARGS_WALK2 (bits; default all): 1 = the second form of the T-only walk, 2 = of the full walk, 4 = of the backward walk; 0 = the first forms (A/B)
+static int walk2() {
+    static const int m = [] { const char* e = getenv("LIDARGS_WALK2"); return e ? atoi(e) : 7; }();
+    return m;
+}
 // waves per workgroup of the fused forward blend: LIDARGS_FUSED_WAVES = 4, 8 (default) or 16
-void launch_render_fused(const RenderFwdArgs& a, hipStream_t s) {
+void launch_render_fused(const RenderFwdArgs& a_, hipStream_t s) {
+    RenderFwdArgs a = a_; a.walk2 = walk2() & 1;
     static const int env = [] { const char* e = getenv("LIDARGS_FUSED_WAVES"); return e ? atoi(e) : 0; }();
     const unsigned patches = (unsigned)a.grid.window_patches();
     if (env == 4) hipLaunchKernelGGL(k_render_fused<4>, dim3(patches), dim3(256), 0, s, a);
@@ -677,7 +871,8 @@ void launch_render_alive(const RenderFwdArgs& a, hipStream_t s) {
 }
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
-    hipLaunchKernelGGL(k_render_forward<true>, dim3(blocks), dim3(64), 0, s, a);
+    if (walk2() & 1) hipLaunchKernelGGL((k_render_forward<true, true>), dim3(blocks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_render_forward<true, false>), dim3(blocks), dim3(64), 0, s, a);
 }
 // Segments a pass-2 workgroup walks in a row.  Measured (r02): on the 64-entry plan of the 64x2650 frames grouping LOSES (cfg3 pass 2
 // 0.069 ms at 1, 0.090 at 2, 0.146 at 4: the patches that never saturate set the launch's length, and their walk becomes G times as
@@ -691,16 +886,19 @@ void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s) {
     const int G = pass2_group(a.seg_len);
     if (G <= 1 || a.seg_hi != a.S) {
         const unsigned blocks = segment_grid(a.grid.window_patches(), a.seg_hi - a.seg_lo);
-        hipLaunchKernelGGL(k_render_forward<false>, dim3(blocks), dim3(64), 0, s, a);
+        if (walk2() & 2) hipLaunchKernelGGL((k_render_forward<false, true>), dim3(blocks), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_render_forward<false, false>), dim3(blocks), dim3(64), 0, s, a);
         return;
     }
     const unsigned blocks = segment_grid(a.grid.window_patches(), ((a.S - a.seg_lo + G - 1) / G) | 1);
-    hipLaunchKernelGGL(k_render_pass2_grouped<false>, dim3(blocks), dim3(64), 0, s, a, G);
+    if (walk2() & 2) hipLaunchKernelGGL((k_render_pass2_grouped<false, true>), dim3(blocks), dim3(64), 0, s, a, G);
+    else hipLaunchKernelGGL((k_render_pass2_grouped<false, false>), dim3(blocks), dim3(64), 0, s, a, G);
 }
 // the first `head` segments of every list, walked once from the true transmittance (see k_render_pass2_grouped<true>)
 void launch_render_head(const RenderFwdArgs& a, int head, hipStream_t s) {
     const unsigned blocks = segment_grid(a.grid.window_patches(), 1);
-    hipLaunchKernelGGL(k_render_pass2_grouped<true>, dim3(blocks), dim3(64), 0, s, a, head);
+    if (walk2() & 2) hipLaunchKernelGGL((k_render_pass2_grouped<true, true>), dim3(blocks), dim3(64), 0, s, a, head);
+    else hipLaunchKernelGGL((k_render_pass2_grouped<true, false>), dim3(blocks), dim3(64), 0, s, a, head);
 }
 void launch_render_combine(const RenderFwdArgs& a, hipStream_t s) {
     const unsigned patches = (unsigned)a.grid.window_patches();
@@ -749,10 +947,21 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
     return v[0];
 }
 
+// V2 (round 4): the visited records of a chunk are parked compacted (the flagged entries in slots 0 .. cnt-1, in list order, zero
+// records behind them; every array two slots further up, so that the look-ahead reads below slot 0 stay inside it) and walked from
+// slot cnt-1 (or cnt, a zero record, when cnt is odd) down in pairs: a counted loop, the entry's position and Gaussian id riding in LDS
+// -- no find-last-set / clear / compare / clamp on a 64-bit scalar mask per entry (~10 scalar instructions of the ~45 a visited entry
+// that contributes nothing costs).  The arithmetic per entry is the first form's, in the same order.
+template <bool V2>
 __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
-    __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ float4 s_oprow[LG_CHUNK];                               // opacity per pixel row of the patch, 0 outside the entry's row span
-    __shared__ uint32_t s_gid[LG_CHUNK];
+    constexpr int OFS = V2 ? 2 : 0;                                    // slack slots below slot 0 (V2's look-ahead reads)
+    __shared__ float4 s_rec_[4 * (LG_CHUNK + OFS)];
+    __shared__ float4 s_oprow_[LG_CHUNK + OFS];                        // opacity per pixel row of the patch, 0 outside the entry's row span
+    __shared__ uint32_t s_gid_[LG_CHUNK + OFS];
+    constexpr int CS = LG_CHUNK + OFS;                                 // component stride of s_rec
+    float4* const s_rec = s_rec_ + OFS;
+    float4* const s_oprow = s_oprow_ + OFS;
+    uint32_t* const s_gid = s_gid_ + OFS;
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -784,8 +993,21 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
     if (n_max == 0) return;                                            // nothing blended in this segment
 
-    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
     const uint2 sr = segment_range(tr, St, seg);
+    // The first chunk's list entries and flags are requested FIRST: its records hang on them (a second round trip), and everything
+    // between here and the walk -- the pixel's rays, upstream gradients, T planes, the sums over the segments behind -- waits for
+    // loads of its own that can be in flight at the same time.  (In program order the gather used to come after the plane sums'
+    // loop: one or more round trips later.)
+    const int c_last = (int)((n_max - 1) / LG_CHUNK);
+    const uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
+    uint32_t g_first = 0u; bool have_first = false;
+    if (V2) {
+        const uint32_t k = (uint32_t)c_last * LG_CHUNK + lane;
+        const bool in = k < n_max;
+        g_first = in ? a.point_list[sr.x + k] : 0u;
+        have_first = in && (!fl || fl[k] != 0);
+    }
+    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
     const size_t N = (size_t)a.grid.W * a.grid.H;
 
     // per-pixel state of the back-to-front walk (R3/cr/backward.cu:590-615), restricted to this segment:
@@ -796,6 +1018,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     float g0 = 0.f, g1 = 0.f, gd = 0.f, go = 0.f;
     if (px.inside) { g0 = a.dL_dpix[px.pix]; g1 = a.dL_dpix[N + px.pix]; gd = a.dL_ddepth[px.pix]; go = a.dL_docc[px.pix]; }
     const float bgdot = a.bg ? (a.bg[0] * g0 + a.bg[1] * g1) : 0.f;
+    Staged st; uint32_t gid = 0u; bool have = false;
+    if (V2) { have = have_first; gid = have ? g_first : 0u; st = gather_record(a.rec, a.rowspan, g_first, have); }   // behind the ids, in front of the plane sums
     // accum_rec[2] | accum_red, accum_reo: the four "colour behind" recurrences run as two packed pairs
     v2f acc01 = v2f{0.f, 0.f}, accdo = v2f{0.f, 0.f};
     const v2f g01 = v2f{g0, g1}, gdo = v2f{gd, go};
@@ -818,11 +1042,9 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     float last_alpha = 0.f;
     v2f lc01 = v2f{0.f, 0.f}, ldo = v2f{0.f, 1.f};                    // last entry's (colour0, colour1) | (range, 1)
 
-    const int c_last = (int)((n_max - 1) / LG_CHUNK);
     const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
     const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
     const v2f qxy = v2f{px.q.x, px.q.y};
-    const uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
     auto gather = [&](int c, Staged& st, uint32_t& gid, bool& have) {
         const uint32_t k = (uint32_t)c * LG_CHUNK + lane;
         const bool in = k < n_max;
@@ -831,13 +1053,24 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
         gid = have ? g : 0u;
         st = gather_record(a.rec, a.rowspan, g, have);
     };
-    Staged st; uint32_t gid; bool have;
-    gather(c_last, st, gid, have);
+    if (!V2) gather(c_last, st, gid, have);
     for (int c = c_last; c >= 0; c--) {
         __syncthreads();
-        park_record(s_rec, lane, st);
-        s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0); s_gid[lane] = gid;
         unsigned long long todo = __ballot(have);
+        int cnt = 0;
+        if (V2) {
+            cnt = __builtin_popcountll(todo);
+            const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+            const int slot = have ? before : cnt + (lane - before);
+            s_rec[slot] = make_float4(st.a0.x, st.a0.y, st.a0.z, st.a3.x);
+            s_rec[CS + slot] = st.a1;
+            s_rec[2 * CS + slot] = st.a2;
+            s_rec[3 * CS + slot] = make_float4(st.a0.w, __uint_as_float((uint32_t)c * LG_CHUNK + (uint32_t)lane), st.a3.z, st.a3.w);   // range, 0-based position, colours
+            s_oprow[slot] = rows_opacity(st.span, st.a3.y, y0); s_gid[slot] = gid;
+        } else {
+            park_record(s_rec, lane, st);
+            s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0); s_gid[lane] = gid;
+        }
         __syncthreads();
         if (c > 0) gather(c - 1, st, gid, have);
         if (todo == 0ull) continue;
@@ -845,17 +1078,17 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
         struct Rec { float4 r0, r1, r2, r3; float op; };
         auto read = [&](int jj) {
             Rec r;
-            const float* f3 = reinterpret_cast<const float*>(&s_rec[3 * LG_CHUNK + jj]);
+            const float* f3 = reinterpret_cast<const float*>(&s_rec[3 * CS + jj]);
             const float4 s0 = lds_ahead(&s_rec[jj]);                   // s.xyz | B  (park_record)
-            r.r1 = lds_ahead(&s_rec[LG_CHUNK + jj]); r.r2 = lds_ahead(&s_rec[2 * LG_CHUNK + jj]);
+            r.r1 = lds_ahead(&s_rec[CS + jj]); r.r2 = lds_ahead(&s_rec[2 * CS + jj]);
             const v2f col = *(LG_LDS_VOLATILE(v2f))(f3 + 2);
             r.r0 = make_float4(s0.x, s0.y, s0.z, lds_ahead(f3));       // range
-            r.r3 = make_float4(s0.w, 0.f, col.x, col.y);
+            r.r3 = make_float4(s0.w, V2 ? lds_ahead(f3 + 1) : 0.f, col.x, col.y);   // B, (V2: position), colours
             r.op = lds_ahead(&oprow[4 * jj]);
             return r;
         };
         auto evaluate = [&](const Rec& r, int j) {
-            const uint32_t e = (uint32_t)c * LG_CHUNK + j;            // 0-based position inside the segment
+            const uint32_t e = V2 ? __float_as_uint(r.r3.y) : (uint32_t)c * LG_CHUNK + j;   // 0-based position inside the segment
             const v2f exy = v2f{r.r0.x, r.r0.y} - qxy;
             const float ex = exy.x, ey = exy.y, ez = r.r0.z - px.q.z;
             const v2f ux = v2f{r.r1.x, r.r1.y}, uy = v2f{r.r1.z, r.r1.w}, uz = v2f{r.r2.x, r.r2.y};        // (u1', u2') by component
@@ -928,6 +1161,18 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 }
             }
         };
+        if (V2) {
+            // pairs from the top slot down; an odd count starts one slot higher, on a zero record (alpha = 0: nothing to do)
+            int j = ((cnt + 1) & ~1) - 1;
+            Rec ra = read(j), rb;
+            for (; j > 0; j -= 2) {
+                rb = read(j - 1);
+                evaluate(ra, j);
+                ra = read(j - 2);                                      // (below slot 0 on the last trip: the slack slots)
+                evaluate(rb, j - 1);
+            }
+            continue;
+        }
         auto top = [&](unsigned long long& m) { const int jj = 63 - __builtin_clzll(m); m &= ~(1ull << jj); return jj; };
         int ja = top(todo);
         Rec ra = read(ja), rb;
@@ -950,7 +1195,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
 
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
     const unsigned blocks = a.walk.cnt ? (unsigned)LG_WORK_REGIONS * a.walk.cap : segment_grid(a.grid.window_patches(), a.S);
-    hipLaunchKernelGGL(k_render_backward, dim3(blocks), dim3(64), 0, s, a);
+    if (walk2() & 4) hipLaunchKernelGGL(k_render_backward<true>, dim3(blocks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_render_backward<false>, dim3(blocks), dim3(64), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -345,11 +345,67 @@ struct SfFwdArgs {
     int seg_lo, seg_hi, front;
 };
 
+// The T-only walk over entries [0, cnt) of a chunk, second form (render.hip walk_T_only_v2, which this follows): alpha of an entry does
+// not depend on the entries before it, only T does, through one multiply; entries in groups of four at constant LDS offsets (the lanes
+// behind the chunk's count parked zero records: opacity 0, alpha 0); the lanes that are out only gate the contribution flags, refreshed
+// once per group; a tripped lane keeps multiplying (any hand-over value below 1e-4 is as good as another).  `took` comes back with bit
+// e set if some live pixel takes entry e.
+__device__ __forceinline__ void sf_walk_T_only_v2(const int cnt, const float4* s_rec, const float* oprow, const SfPixel& px, float& T_io, bool& done_io,
+                                                  const unsigned long long dead0, unsigned long long& took) {
+    struct Rec { float4 r0, r1, r2, r3, r4; float op; };
+    auto read = [&](int jj) {
+        Rec r;
+        const float* f1 = reinterpret_cast<const float*>(&s_rec[SF_CHUNK + jj]);
+        const float* f2 = reinterpret_cast<const float*>(&s_rec[2 * SF_CHUNK + jj]);
+        const float* f4 = reinterpret_cast<const float*>(&s_rec[4 * SF_CHUNK + jj]);
+        r.r0 = lds_ahead(&s_rec[jj]);
+        const sf2 tz = *(LG_LDS_VOLATILE(sf2))f1;
+        r.r3 = lds_ahead(&s_rec[3 * SF_CHUNK + jj]);
+        const v3f c4 = *(LG_LDS_VOLATILE(v3f))f4;
+        r.r4 = make_float4(c4.x, c4.y, c4.z, 0.f);
+        const v3f tw = *(LG_LDS_VOLATILE(v3f))f2;
+        r.r1 = make_float4(tz.x, tz.y, 0.f, 0.f);
+        r.r2 = make_float4(tw.x, tw.y, tw.z, 0.f);
+        r.op = lds_ahead(&oprow[4 * jj]);
+        return r;
+    };
+    auto factor = [&](const Rec& r, unsigned long long& hitmask) {
+        const SfPair q = sf_pair(px, r.r0, r.r1, r.r2, r.r3, r.r4, r.op, true);
+        hitmask = __ballot(q.ok);
+        return q.ok ? 1.f - q.alpha : 1.f;
+    };
+    float T = T_io;
+    unsigned long long dead = dead0 | __ballot(T < 0.0001f);
+    uint32_t acc_lo = 0u, acc_hi = 0u;                                 // took bits, newest entry at bit 0 (render.hip walk_T_only_v2)
+    auto note = [&](unsigned long long hitmask) {
+        unsigned long long tmp;
+        asm volatile("s_andn2_b64 %2, %3, %4\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1"
+                     : "+s"(acc_lo), "+s"(acc_hi), "=&s"(tmp) : "s"(hitmask), "s"(dead) : "scc");
+    };
+    const int ng = (cnt + 3) >> 2;
+    Rec ra = read(0), rb = read(1);
+    for (int g = 0; g < ng; g++) {
+        const int j = 4 * g;
+        unsigned long long h0, h1, h2, h3;
+        const float f0 = factor(ra, h0); ra = read(j + 2);
+        const float f1 = factor(rb, h1); rb = read(j + 3);
+        const float f2 = factor(ra, h2); ra = read(j + 4);
+        const float f3 = factor(rb, h3); rb = read(j + 5);
+        note(h0); note(h1); note(h2); note(h3);
+        T = T * f0; T = T * f1; T = T * f2; T = T * f3;
+        dead = dead0 | __ballot(T < 0.0001f);
+    }
+    T_io = T;
+    done_io = done_io || (T < 0.0001f);
+    const unsigned long long acc = ((unsigned long long)acc_hi << 32) | acc_lo;
+    took = __brevll(acc) >> (64 - 4 * ng);
+}
+
 // One workgroup = (patch, segment).  T_ONLY: pass 1 (transmittance product + flags).  Otherwise pass 2 (all sums).
-template <bool T_ONLY>
+template <bool T_ONLY, bool V2 = false>
 __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
-    __shared__ float4 s_rec[5 * SF_CHUNK];
-    __shared__ float4 s_oprow[SF_CHUNK];                               // opacity per pixel row of the patch, 0 outside the surfel's row span
+    __shared__ float4 s_rec[5 * SF_CHUNK + 2];                         // (+2: the second form's look-ahead reads)
+    __shared__ float4 s_oprow[SF_CHUNK + 2];                           // opacity per pixel row of the patch, 0 outside the surfel's row span
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -393,7 +449,9 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
             if (c + 1 < nchunks) { const uint32_t k = (c + 1) * SF_CHUNK + lane; have = entry_valid(k); st = sf_gather(a.point_list, a.rec, a.rowspan, sr.x + k, have); }
             if (__ballot(!done) == 0ull) break;
             unsigned long long took = 0ull;
-            if (todo) {
+            if (todo && T_ONLY && V2) {
+                sf_walk_T_only_v2(__builtin_popcountll(todo), s_rec, oprow, px, T, done, __ballot(!px.inside), took);
+            } else if (todo) {
                 // Two register sets used in turn, look-ahead reads that stay where they are written, only the fields the pass uses:
                 // see walk_flagged (render.hip), which this follows.
                 struct Rec { float4 r0, r1, r2, r3, r4; float op; };
@@ -568,10 +626,12 @@ __global__ void __launch_bounds__(64) k_sf_combine(const SfFwdArgs a) {
 }
 
 void launch_sf_render_pass1(const SfFwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_sf_render_forward<true>, dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
+    static const bool walk2 = [] { const char* e = getenv("LIDARGS_WALK2"); return !e || (atoi(e) & 1) != 0; }();   // render.hip walk2()
+    if (walk2) hipLaunchKernelGGL((k_sf_render_forward<true, true>), dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_sf_render_forward<true, false>), dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
 }
 void launch_sf_render_pass2(const SfFwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_sf_render_forward<false>, dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((k_sf_render_forward<false, false>), dim3(segment_grid(a.grid.num_tiles() * a.grid.waves_per_tile, a.seg_hi - a.seg_lo)), dim3(64), 0, s, a);
 }
 void launch_sf_alive(const SfFwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_sf_alive, dim3((unsigned)(a.grid.num_tiles() * a.grid.waves_per_tile)), dim3(64), 0, s, a);
