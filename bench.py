@@ -796,7 +796,7 @@ def bench_train_step(args):
         means2D = torch.zeros((xyz.shape[0], 4), device="cuda", requires_grad=True)
         image, depth, _occ, radii = rast(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color, scales=scaling, rotations=rot)
         ev[2].record()
-        loss = image_loss(image, depth, gt, 0.2)["loss"] + 0.01 * scaling.prod(dim=1).mean()
+        loss = image_loss(image, depth, gt, 0.2, scaling=scaling)["loss"]      # the reference's whole loss, scaling_reg (train.py:174) included, natively
         ev[3].record()
         loss.backward()
         ev[4].record()

@@ -321,7 +321,11 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
                  const float* beams, float near_f, float far_f, float shell_lo, float shell_hi, const float* T_in,
                  int transmittance_pass, float* out_color, float* out_depth, float* out_occ, float* T_out, int* radii,
                  int* radii_xy, int debug, hipStream_t stream, long long instance_capacity = 0, int fixed_tile_rows = 0,
-                 unsigned* status_host = nullptr, int col_lo = -1, int col_hi = -1) {
+                 unsigned* status_host = nullptr, int col_lo = -1, int col_hi = -1, bool is_shell = false) {
+    // is_shell: the call comes from lidargs_forward_shell.  Its backward (lidargs_backward_shell) walks the slot grid with the flags and
+    // limits of the segmented launches, whatever T_in / T_out / transmittance_pass were -- a first or only shell passes none of them
+    // -- so the mode is the entry point's, not inferred from those arguments (round-3 advisor finding: a direct ABI caller of a single
+    // shell got the fused blend and a work list here, and a backward that read planes and flags the fused blend never wrote).
     // instance_capacity > 0: ENQUEUE-ONLY mode.  Nothing is read back: the binning buffer is sized for `instance_capacity`
     // instances at the caller's tile height, every count the later stages need stays on the device, and the 16 status words
     // (binning.hip k_finish_totals: instances needed / binned, totals per tile height, overflow flag) are copied to
@@ -506,12 +510,12 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.final_T = img.final_T; ra.T_pass = T_out;
     ra.out_color = out_color; ra.out_depth = out_depth; ra.out_occ = out_occ;
     ra.seg = bin.seg; ra.S = S; ra.seg_len = plan.seg_len;
-    ra.run_pass1 = (S > 1 || transmittance_pass) ? 1 : 0;
+    ra.run_pass1 = (S > 1 || transmittance_pass || is_shell) ? 1 : 0;   // (a shell's backward always reads the flags)
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = Rp;
     ra.transmittance_only = transmittance_pass;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
     int head = 0;                                                      // segments at the head of every list that round 1 walked completely
-    const bool fused = plan.fused && !transmittance_pass && !T_in && !T_out;   // the plain frame (a range shell's two phases keep the launches)
+    const bool fused = plan.fused && !is_shell;                        // the plain frame (a range shell's two phases keep the launches)
     if (fused) {
         ra.flags = bin.flags; ra.alive = bin.alive;
         lg::launch_render_fused(ra, stream);
@@ -530,7 +534,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         g_prof.mark("render_pass2", stream);
     }
     // not in a range shell's phases: their backward (lidargs_backward_shell) keeps the slot grid
-    if (!transmittance_pass && !T_in && !T_out && backward_list(S, patches, false)) ra.fill = lg::work_list(bin);
+    if (!is_shell && backward_list(S, patches, false)) ra.fill = lg::work_list(bin);
     lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render combine");
     g_prof.mark("render_combine", stream);
@@ -731,7 +735,7 @@ int lidargs_forward_shell(lidargs_alloc_fn geometry_alloc, void* geometry_user, 
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
                         height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                         beam_inclinations, (float)lidar_near, (float)lidar_far, shell_lo, shell_hi, T_in, transmittance_pass,
-                        out_color, out_depth, out_occ, T_out, radii, radii_xy, debug, (hipStream_t)stream);
+                        out_color, out_depth, out_occ, T_out, radii, radii_xy, debug, (hipStream_t)stream, 0, 0, nullptr, -1, -1, true);
 }
 
 // ---- column wedges (multi-GPU): rank g bins and renders the tile columns of pixel columns [col_lo, col_hi) only --------------------

@@ -192,6 +192,42 @@ __global__ void __launch_bounds__(64) k_loss_finish(int H, int W, int blocks, co
     }
 }
 
+
+// ---- scaling_reg = weight * mean(prod(scaling, dim=1))  (train.py:174) and its gradient, the per-Gaussian term of the frame loss -------
+// One thread per Gaussian row: the product as torch.prod forms it ((s0 s1) s2 in fp32), the gradient row weight / M x (s1 s2, s0 s2, s0 s1)
+// -- the products themselves, where the framework's prod backward divides the result by each input after a host-synchronising look for
+// zeros -- and the block's sum of products in double; k_scaling_reg_finish folds the block sums in a fixed order (deterministic) and,
+// if asked, adds the value onto the image loss.
+#define SR_BLOCK 256
+__global__ void __launch_bounds__(SR_BLOCK) k_scaling_reg(int M, const float* __restrict__ scaling, float wm, float* __restrict__ grad, double* __restrict__ part) {
+    __shared__ double ws[SR_BLOCK / 64];
+    const int i = blockIdx.x * SR_BLOCK + threadIdx.x;
+    double p = 0.0;
+    if (i < M) {
+        const float s0 = scaling[3 * (size_t)i], s1 = scaling[3 * (size_t)i + 1], s2 = scaling[3 * (size_t)i + 2];
+        p = (double)((s0 * s1) * s2);
+        if (grad) { grad[3 * (size_t)i] = wm * (s1 * s2); grad[3 * (size_t)i + 1] = wm * (s0 * s2); grad[3 * (size_t)i + 2] = wm * (s0 * s1); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < SR_BLOCK / 64; k++) t += ws[k]; part[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(64) k_scaling_reg_finish(int M, int blocks, const double* __restrict__ part, float weight, float* __restrict__ value,
+                                                           float* __restrict__ add_to) {
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    for (int b = lane; b < blocks; b += 64) s += part[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const float v = weight * (float)(s / (double)M);              // M = 0: 0 / 0 = NaN, as the mean of an empty tensor is
+        if (value) *value = v;
+        if (add_to) *add_to += v;
+    }
+}
+
 }  // namespace lg
 
 extern "C" {
@@ -223,6 +259,26 @@ int lidargs_image_loss(int H, int W, const float* image, const float* depth, con
     hipLaunchKernelGGL(lg::k_ssim_rows3, dim3(blocks), dim3(LL_BLOCK), 0, stream, H, W, s.m3, win, s.t3);
     hipLaunchKernelGGL(lg::k_ssim_cols3, dim3(blocks), dim3(LL_BLOCK), 0, stream, H, W, s.t3, win, image, gt, s.gx, dL_dimage);
     hipLaunchKernelGGL(lg::k_loss_finish, dim3(1), dim3(64), 0, stream, H, W, (int)blocks, part_a, part_s, lambda_dssim, losses);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lg::api_fail(LIDARGS_ERR_HIP, hipGetErrorString(e));
+    return 0;
+}
+
+size_t lidargs_scaling_reg_scratch_bytes(int M) {
+    const size_t blocks = ((size_t)(M > 0 ? M : 1) + SR_BLOCK - 1) / SR_BLOCK;
+    return blocks * sizeof(double) + 256;
+}
+
+int lidargs_scaling_reg(int M, const float* scaling, float weight, float* value, float* add_to, float* dL_dscaling, char* scratch,
+                        size_t scratch_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "scaling_reg: M < 0");
+    if ((M > 0 && !scaling) || !scratch || (!value && !add_to)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "scaling_reg: NULL pointer");
+    if (scratch_bytes < lidargs_scaling_reg_scratch_bytes(M)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "scaling_reg: scratch too small");
+    double* part = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(scratch) + 127) & ~uintptr_t(127));
+    const unsigned blocks = (unsigned)(((size_t)M + SR_BLOCK - 1) / SR_BLOCK);
+    if (blocks) hipLaunchKernelGGL(lg::k_scaling_reg, dim3(blocks), dim3(SR_BLOCK), 0, stream, M, scaling, M > 0 ? weight / (float)M : 0.f, dL_dscaling, part);
+    hipLaunchKernelGGL(lg::k_scaling_reg_finish, dim3(1), dim3(64), 0, stream, M, (int)blocks, part, weight, value, add_to);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lg::api_fail(LIDARGS_ERR_HIP, hipGetErrorString(e));
     return 0;

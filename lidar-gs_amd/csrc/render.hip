@@ -211,7 +211,7 @@ __device__ __forceinline__ void walk_flagged(unsigned long long todo, const floa
 //     contribution flags (a superset by at most three entries per trip: pass 2 applies the exact rule to the flagged entries);
 //   * the took bits are shifted into a scalar accumulator (s_andn2 sets SCC, s_addc shifts it in), newest entry at bit 0.
 // Same products in the same order as the first form while nothing trips: the Tpass planes are bit-identical.
-template <bool TRACK>
+template <bool TRACK, int G = 4>
 __device__ __forceinline__ void walk_T_only_v2(const int cnt, const float4* s_rec, const float* oprow, const v2f qxy, const float qz,
                                                WalkState& w, const unsigned long long dead0, const float stop = 0.0001f) {
     struct Rec { float4 r0, r1, r2; float op; };
@@ -248,25 +248,29 @@ __device__ __forceinline__ void walk_T_only_v2(const int cnt, const float4* s_re
                          : "+s"(acc_lo), "+s"(acc_hi), "=&s"(tmp) : "s"(hitmask), "s"(dead) : "scc");
         }
     };
-    const int ng = (cnt + 3) >> 2;
+    static_assert(G == 2 || G == 4, "group of 2 or 4 entries");
+    const int ng = (cnt + G - 1) / G;
     Rec ra = read(0), rb = read(1);
     for (int g = 0; g < ng; g++) {
-        const int j = 4 * g;
-        unsigned long long h0, h1, h2, h3;
-        const float f0 = factor(ra, h0); ra = read(j + 2);
-        const float f1 = factor(rb, h1); rb = read(j + 3);
-        const float f2 = factor(ra, h2); ra = read(j + 4);
-        const float f3 = factor(rb, h3); rb = read(j + 5);
-        note(h0); note(h1); note(h2); note(h3);
-        T = T * f0; T = T * f1; T = T * f2; T = T * f3;
+        const int j = G * g;
+        unsigned long long h[G]; float f[G];
+#pragma unroll
+        for (int i = 0; i < G; i += 2) {
+            f[i] = factor(ra, h[i]); ra = read(j + i + 2);
+            f[i + 1] = factor(rb, h[i + 1]); rb = read(j + i + 3);
+        }
+#pragma unroll
+        for (int i = 0; i < G; i++) note(h[i]);
+#pragma unroll
+        for (int i = 0; i < G; i++) T = T * f[i];
         dead = dead0 | __ballot(T < stop);
     }
     w.T = T;
     w.done = w.done || (T < stop);
     if (TRACK) {
-        // entry e of the chunk sits at bit 4 ng - 1 - e of the accumulator
+        // entry e of the chunk sits at bit G ng - 1 - e of the accumulator
         const unsigned long long acc = ((unsigned long long)acc_hi << 32) | acc_lo;
-        const unsigned long long rev = __brevll(acc) >> (64 - 4 * ng);
+        const unsigned long long rev = __brevll(acc) >> (64 - G * ng);
         w.took = rev;
     }
 }

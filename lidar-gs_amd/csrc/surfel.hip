@@ -350,6 +350,7 @@ struct SfFwdArgs {
 // behind the chunk's count parked zero records: opacity 0, alpha 0); the lanes that are out only gate the contribution flags, refreshed
 // once per group; a tripped lane keeps multiplying (any hand-over value below 1e-4 is as good as another).  `took` comes back with bit
 // e set if some live pixel takes entry e.
+template <int G>
 __device__ __forceinline__ void sf_walk_T_only_v2(const int cnt, const float4* s_rec, const float* oprow, const SfPixel& px, float& T_io, bool& done_io,
                                                   const unsigned long long dead0, unsigned long long& took) {
     struct Rec { float4 r0, r1, r2, r3, r4; float op; };
@@ -382,23 +383,27 @@ __device__ __forceinline__ void sf_walk_T_only_v2(const int cnt, const float4* s
         asm volatile("s_andn2_b64 %2, %3, %4\n\ts_addc_u32 %0, %0, %0\n\ts_addc_u32 %1, %1, %1"
                      : "+s"(acc_lo), "+s"(acc_hi), "=&s"(tmp) : "s"(hitmask), "s"(dead) : "scc");
     };
-    const int ng = (cnt + 3) >> 2;
+    static_assert(G == 2 || G == 4, "group of 2 or 4 entries");
+    const int ng = (cnt + G - 1) / G;
     Rec ra = read(0), rb = read(1);
     for (int g = 0; g < ng; g++) {
-        const int j = 4 * g;
-        unsigned long long h0, h1, h2, h3;
-        const float f0 = factor(ra, h0); ra = read(j + 2);
-        const float f1 = factor(rb, h1); rb = read(j + 3);
-        const float f2 = factor(ra, h2); ra = read(j + 4);
-        const float f3 = factor(rb, h3); rb = read(j + 5);
-        note(h0); note(h1); note(h2); note(h3);
-        T = T * f0; T = T * f1; T = T * f2; T = T * f3;
+        const int j = G * g;
+        unsigned long long h[G]; float f[G];
+#pragma unroll
+        for (int i = 0; i < G; i += 2) {
+            f[i] = factor(ra, h[i]); ra = read(j + i + 2);
+            f[i + 1] = factor(rb, h[i + 1]); rb = read(j + i + 3);
+        }
+#pragma unroll
+        for (int i = 0; i < G; i++) note(h[i]);
+#pragma unroll
+        for (int i = 0; i < G; i++) T = T * f[i];
         dead = dead0 | __ballot(T < 0.0001f);
     }
     T_io = T;
     done_io = done_io || (T < 0.0001f);
     const unsigned long long acc = ((unsigned long long)acc_hi << 32) | acc_lo;
-    took = __brevll(acc) >> (64 - 4 * ng);
+    took = __brevll(acc) >> (64 - G * ng);
 }
 
 // One workgroup = (patch, segment).  T_ONLY: pass 1 (transmittance product + flags).  Otherwise pass 2 (all sums).
@@ -450,7 +455,7 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
             if (__ballot(!done) == 0ull) break;
             unsigned long long took = 0ull;
             if (todo && T_ONLY && V2) {
-                sf_walk_T_only_v2(__builtin_popcountll(todo), s_rec, oprow, px, T, done, __ballot(!px.inside), took);
+                sf_walk_T_only_v2<4>(__builtin_popcountll(todo), s_rec, oprow, px, T, done, __ballot(!px.inside), took);
             } else if (todo) {
                 // Two register sets used in turn, look-ahead reads that stay where they are written, only the fields the pass uses:
                 // see walk_flagged (render.hip), which this follows.

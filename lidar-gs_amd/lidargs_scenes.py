@@ -226,3 +226,34 @@ def raster_settings(scene_t, W, H, far=80, near=0, scale_modifier=1.0, debug=Fal
         viewmatrix=scene_t["viewmatrix"], projmatrix=torch.eye(4, device=dev), sh_degree=1,
         campos=torch.zeros(3, device=dev), prefiltered=False, beam_inclinations=scene_t["beams"], debug=debug,
         lidar_far=int(far), lidar_near=int(near))
+
+
+def sweep_case(seed, mid=None):
+    """The 3-D scene tools/parity_sweep.py draws for `seed` (its surfel scenes, seed % 4 == 3 with H >= 4, are drawn differently and are
+    not reproduced here): (scene, W, H, upstream grads, keyword arguments of the rasterizer, description).  One recipe for the sweep's
+    repro tool (tools/repro_sweep_seed.py) and for the regression tests built from its residue (tests/test_sweep_residue_gpu.py)."""
+    if mid is None:
+        mid = seed >= 100000 and seed < 900000
+    rng = np.random.default_rng(seed)
+    if mid:
+        H = int(rng.choice([16, 32, 64])); W = int(rng.choice([900, 1800, 2650])); P = int(rng.integers(20000, 60000))
+    else:
+        H = int(rng.choice([2, 3, 5, 16, 17, 32, 40, 64])); W = int(rng.integers(1, 700)); P = int(rng.integers(1, 6000))
+    if not mid and seed % 7 == 5:
+        W = int(rng.integers(4100, 4300)); H = int(rng.choice([2, 3, 16])); P = int(rng.integers(1, 3000))
+    if not mid and seed % 11 == 7:
+        H = int(rng.choice([130, 272])); W = int(rng.integers(1, 200)); P = int(rng.integers(1, 3000))
+    if not mid and seed % 17 == 4:
+        H = int(rng.choice([1025, 1100])); W = int(rng.integers(64, 200)); P = int(rng.integers(1, 3000))
+    if not mid and seed % 19 == 6:
+        H = 1100; W = 4800; P = int(rng.integers(1, 2000))
+    kind = "shell" if rng.random() < 0.5 else "street"
+    beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
+    kw = dict(far=int(rng.choice([80, 30])), near=int(rng.choice([0, 2])), scale_modifier=float(rng.choice([1.0, 0.5, 2.5])))
+    if not mid and seed % 13 == 3:
+        kw["scale_modifier"] = float(rng.choice([6.0, 12.0, 30.0]))
+    scene = make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)), beams=beams)
+    if seed % 23 == 8:
+        scene["opacities"] = (scene["opacities"] * np.float32(0.008)).astype(np.float32)
+    grads = upstream_grads(H, W, seed % 1000)
+    return scene, W, H, grads, kw, dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, **kw)

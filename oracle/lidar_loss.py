@@ -83,3 +83,12 @@ def forward_backward(image, depth, gt, lambda_dssim):
     g_depth[0] = gdm * rd
     return dict(loss=loss, Ll1=Ll1, depth_loss=depth_loss, ssim_loss=ssim_loss, raydrop_loss=raydrop_loss, grad_loss=grad_loss,
                 g_image=g_image.astype(np.float32), g_depth=g_depth.astype(np.float32))
+
+
+def scaling_reg(scaling, weight=0.01):
+    """train.py:174  scaling_reg = 0.01 * scaling.prod(dim=1).mean()  and its gradient w.r.t. scaling [M, 3] (f64 accumulation)."""
+    s = np.asarray(scaling, np.float64)
+    M = s.shape[0]
+    value = weight * np.prod(s, axis=1).mean() if M else float("nan")
+    g = np.stack([s[:, 1] * s[:, 2], s[:, 0] * s[:, 2], s[:, 0] * s[:, 1]], 1) * (weight / max(M, 1))
+    return float(value), g.astype(np.float32)

@@ -52,6 +52,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     worst_max = max(log, key=lambda s: s["max"])
     worst_frac = max(log, key=lambda s: s["soft_frac_used"])
     worst_flip = max(log, key=lambda s: s["flip_frac_used"])
+    worst_abs = max(log, key=lambda s: s.get("abs_max", 0.0))
     with_out = [s for s in log if s["outliers"] > 0]
     tr = terminalreporter
     tr.write_sep("-", "parity budget used (tests/util.py: rtol 1e-4 with floor 1e-3 max|ref|)")
@@ -62,6 +63,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                   f"({worst_frac['name']}); allowed {worst_frac['allowed']}")
     tr.write_line(f"worst flip fraction (err > 1e-3): {worst_flip['flip_frac_used']:.3e} = {worst_flip['flips']} of {worst_flip['n']} "
                   f"({worst_flip['name']}); allowed {worst_flip['allowed_flips']}")
+    tr.write_line(f"largest single difference: {worst_abs.get('abs_max', 0.0):.3e} x max|ref| ({worst_abs['name']}); allowed {util.FLIP_ABS_MAX}")
     try:
         import json
         out = os.path.join(ROOT, "gpurun_out")
@@ -69,7 +71,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
             os.makedirs(out, exist_ok=True)
             with open(os.path.join(out, "parity_budget.json"), "w") as f:
                 json.dump(dict(calls=len(log), calls_with_outliers=len(with_out), worst_p999=worst_p999, worst_max=worst_max,
-                               worst_soft_fraction=worst_frac, worst_flip_fraction=worst_flip,
-                               over_rtol=[dict(name=s["name"], n=s["n"], soft=s["soft"], flips=s["flips"], max=s["max"]) for s in with_out]), f, indent=1)
+                               worst_soft_fraction=worst_frac, worst_flip_fraction=worst_flip, worst_abs_difference=worst_abs,
+                               budgets=dict(soft_frac=util.SOFT_FRAC, flip_frac=util.FLIP_FRAC, flip_abs_max=util.FLIP_ABS_MAX, min_count=util.MIN_COUNT),
+                               over_rtol=[dict(name=s["name"], n=s["n"], soft=s["soft"], flips=s["flips"], max=s["max"], abs_max=s.get("abs_max", 0.0),
+                                               allowed=s["allowed"], allowed_flips=s["allowed_flips"]) for s in with_out]), f, indent=1)
     except Exception as e:      # the summary must never fail a run
         tr.write_line(f"(parity_budget.json not written: {e})")

@@ -27,7 +27,10 @@ def test_loss_and_gradients_match_reference_execution(tag):
     r = lidar_loss.forward_backward(c["image"], c["depth"], c["gt"], float(c["lambda_dssim"]))
     for k in ("Ll1", "depth_loss", "ssim_loss", "raydrop_loss", "grad_loss"):
         rel(k, r[k], c[k], rtol=2e-5)
-    rel("loss", r["loss"] + float(c["scaling_reg"]), c["loss"], rtol=2e-5)
+    reg, g_scaling = lidar_loss.scaling_reg(c["scaling"])                 # train.py:174, the per-Gaussian term of the reference's `loss`
+    rel("scaling_reg", reg, c["scaling_reg"], rtol=2e-5)
+    rel("loss", r["loss"] + reg, c["loss"], rtol=2e-5)
+    rel("g_scaling", g_scaling, c["g_scaling"])
     rel("g_image", r["g_image"], c["g_image"])
     rel("g_depth", r["g_depth"], c["g_depth"])
 

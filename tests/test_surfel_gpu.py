@@ -10,6 +10,7 @@ from util import (GRAD_KEYS_SURFEL, hip_surfel_forward_backward, oracle_surfel_f
 pytestmark = pytest.mark.gpu
 
 OTHERS = ("depth", "alpha", "normal_x", "normal_y", "normal_z", "median_depth", "distortion")
+DISTORTION_SOFT_FRAC = 7.5e-4
 MEDIAN_TIE_FRAC = 1e-3      # pixels whose T sits within rounding of 0.5 when a surfel is blended: the median-depth selection may pick the neighbour
 
 
@@ -45,7 +46,9 @@ def _check(scene, W, H, seed, grads=True, **kw):
             # R2/cr/rasterizer_impl.cu:177): scale = max(M1^2, M2) over the image (<= 1), not a constant.
             acc = ref["fwd"].array("accum").reshape(3, -1)
             scale = float(max(np.square(acc[1]).max(), acc[2].max(), 1e-6))
-            parity("others." + name, hip["others"][k], ref["others"][k], scale=scale)
+            # Its soft class is the suite's widest (round 3: 80 of 169 600 pixels between 1e-4 and 1.6e-4 of that scale, on config 5's
+            # full-size frame): stated here rather than in the general budget -- what was used plus 50 %.
+            parity("others." + name, hip["others"][k], ref["others"][k], scale=scale, soft_frac=DISTORTION_SOFT_FRAC)
         else:
             parity("others." + name, hip["others"][k], ref["others"][k])
     if grads:

@@ -38,7 +38,8 @@ def test_decode_rasterize_loss_chain_matches_oracles(hip_lib_built):
     fw = lgo.forward(f["xyz"], f["color"], f["opacity"], f["scaling"], f["rot"], scene["viewmatrix"], scene["beams"], W, H, bg=scene["bg"])
     lo = oloss.forward_backward(fw.color, fw.depth, gt, lam)
     gb = lgo.backward(fw, lo["g_image"], lo["g_depth"], np.zeros((1, H, W), np.float32))
-    g = ong.backward(p, f, gb["dL_dmeans3D"], gb["dL_dcolors"], gb["dL_dopacity"], gb["dL_dscales"], gb["dL_drotations"])
+    reg, g_reg = oloss.scaling_reg(f["scaling"])                        # train.py:174: the per-Gaussian term of the loss
+    g = ong.backward(p, f, gb["dL_dmeans3D"], gb["dL_dcolors"], gb["dL_dopacity"], gb["dL_dscales"] + g_reg, gb["dL_drotations"])
 
     # ---- product chain
     pc = build_pc(p)
@@ -48,13 +49,14 @@ def test_decode_rasterize_loss_chain_matches_oracles(hip_lib_built):
     rast = GaussianRasterizer(make_settings(st, W, H))
     means2D = torch.zeros((xyz.shape[0], 4), device="cuda", requires_grad=True)
     image, depth, occ, radii = rast(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color, scales=scaling, rotations=rot)
-    terms = image_loss(image, depth, torch.from_numpy(gt).cuda(), lam)
+    terms = image_loss(image, depth, torch.from_numpy(gt).cuda(), lam, scaling=scaling)      # the reference's whole `loss`, scaling_reg included
     terms["loss"].backward()
 
     assert xyz.shape[0] == f["xyz"].shape[0] and int((radii.cpu().numpy() != fw.radii).sum()) <= 1
     assert (fw.radii > 0).sum() > 500                                   # the scene is really rendered
     parity("image", image.detach().cpu().numpy(), fw.color); parity("depth", depth.detach().cpu().numpy(), fw.depth)
-    assert abs(float(terms["loss"]) - lo["loss"]) <= 1e-4 * abs(lo["loss"])
+    assert abs(float(terms["loss"]) - (lo["loss"] + reg)) <= 1e-4 * abs(lo["loss"] + reg)
+    assert abs(float(terms["scaling_reg"]) - reg) <= 1e-4 * abs(reg)
     parity("d anchor_feat", pc._anchor_feat.grad.cpu().numpy(), g["anchor_feat"])
     parity("d anchor", pc._anchor.grad.cpu().numpy(), g["anchor"])
     parity("d offset", pc._offset.grad.cpu().numpy(), g["offset"])

@@ -10,29 +10,35 @@ Every entry is put in one of three classes:
     flip   err > SOFT_MAX                    a hard threshold of the algorithm landed on the other side (alpha < 1/255, power > 0,
                                              T < 1e-4, ceil / round of the footprint rect): the input sat within an ulp of it and
                                              exp / atan2 / cos round differently (device libm vs host libm vs CUDA libdevice).
-                                             A flip moves a pixel by up to a whole contribution and a gradient row by more, so
-                                             its SIZE is not bounded; its COUNT is: at most FLIP_FRAC of the entries.
-(both counts: at least MIN_COUNT = 2, so that a 100-entry array is not judged on a fraction of one entry).  There are no
-per-call overrides of these budgets; a test that needs another rule states it as its own assertion (the surfel variant's median
-depth, a selection, is checked by count in tests/test_surfel_gpu.py).
+                                             A flip moves a pixel by up to a whole contribution and a gradient row by up to a
+                                             whole (pixel, Gaussian) term: its COUNT is bounded by FLIP_FRAC of the entries and its
+                                             SIZE by FLIP_ABS_MAX x max|ref| -- one contribution cannot exceed the array's largest
+                                             entry by much, whereas memory corruption, an overflowed list or a wrong index can and
+                                             usually does (round-3 advisor finding: the size used to be unbounded).
+(both counts: at least MIN_COUNT = 2, so that a 100-entry array is not judged on a fraction of one entry).  The budgets are what
+the suite's GPU run of round 3 used (profiles/r03_i_parity_budget.json: 1.4e-4 soft, 8e-5 flips at the worst call outside the
+surfel distortion plane) plus 50 %; soft + flip stays under the 5e-4 of round 2.  One plane has a stated budget of its own: the
+surfel variant's distortion (`soft_frac=` below; tests/test_surfel_gpu.py says why).  Other rules are assertions of their own in
+the tests that need them (the median depth, a selection, is checked by count).
 
 Budget vs use: conftest.py prints the summary of every run and writes gpurun_out/parity_budget.json (committed per round under
-profiles/); round 3's run (profiles/r03_*_parity_budget.json) is what SOFT_FRAC / FLIP_FRAC were set from.  For scale: two conforming
-evaluations of the reference itself differ by more (tests/test_ulp_band_cpu.py: 0.2-2.5 % of the gradient entries over 1e-4).
+profiles/).  For scale: two conforming evaluations of the reference itself differ by more (tests/test_ulp_band_cpu.py: 0.2-2.5 %
+of the gradient entries over 1e-4).
 """
 import numpy as np
 
 RTOL = 1e-4
 FLOOR = 1e-3
 SOFT_MAX = 1e-3
-SOFT_FRAC = 5e-4
-FLIP_FRAC = 2e-4
+SOFT_FRAC = 2.5e-4
+FLIP_FRAC = 1.25e-4
+FLIP_ABS_MAX = 1.0      # no entry may be off by more than this times max|ref| (the `scale` of the call)
 MIN_COUNT = 2
 # every parity() call of the session, for the "budget used" summary conftest.py prints and writes (gpurun_out/parity_budget.json)
 PARITY_LOG = []
 
 
-def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, verbose=True, scale=None):
+def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, verbose=True, scale=None, soft_frac=None):
     hip = np.asarray(hip, dtype=np.float64).ravel()
     ref = np.asarray(ref, dtype=np.float64).ravel()
     assert hip.shape == ref.shape, (name, hip.shape, ref.shape)
@@ -40,22 +46,25 @@ def parity(name, hip, ref, rtol=RTOL, floor=FLOOR, verbose=True, scale=None):
     if ref.size == 0:
         return dict(name=name, max=0.0, outliers=0, n=0)
     scale = np.abs(ref).max() if scale is None else float(scale)   # `scale`: magnitude of the terms the value is a difference of
-    err = np.abs(hip - ref) / (np.abs(ref) + floor * scale + 1e-30)
+    diff = np.abs(hip - ref)
+    err = diff / (np.abs(ref) + floor * scale + 1e-30)
+    abs_max = float(diff.max()) / (scale + 1e-30)                     # largest difference in units of max|ref|
     soft_max = max(SOFT_MAX, 10.0 * rtol)
     n_soft = int(((err > rtol) & (err <= soft_max)).sum())
     n_flip = int((err > soft_max).sum())
     stats = dict(name=name, max=float(err.max()), p999=float(np.quantile(err, 0.999)), median=float(np.median(err)),
-                 outliers=n_soft + n_flip, soft=n_soft, flips=n_flip, n=int(ref.size), scale=float(scale))
+                 outliers=n_soft + n_flip, soft=n_soft, flips=n_flip, n=int(ref.size), scale=float(scale), abs_max=abs_max)
     if verbose:
         print(f"[parity] {name:18s} n={ref.size:9d} scale={scale:.3e} median={stats['median']:.2e} "
               f"p99.9={stats['p999']:.2e} max={stats['max']:.2e} soft(>{rtol:g})={n_soft} flips(>{soft_max:g})={n_flip}")
-    allowed_soft = max(MIN_COUNT, int(SOFT_FRAC * ref.size))
+    allowed_soft = max(MIN_COUNT, int((SOFT_FRAC if soft_frac is None else soft_frac) * ref.size))
     allowed_flip = max(MIN_COUNT, int(FLIP_FRAC * ref.size))
     stats.update(allowed=allowed_soft, allowed_flips=allowed_flip, outlier_frac_used=(n_soft + n_flip) / ref.size, soft_frac_used=n_soft / ref.size,
                  flip_frac_used=n_flip / ref.size, rtol=rtol, soft_max=soft_max)
     PARITY_LOG.append(stats)
     assert n_soft <= allowed_soft, f"{name}: {n_soft} of {ref.size} entries in ({rtol}, {soft_max}] (allowed {allowed_soft}); max err {err.max():.3e}"
     assert n_flip <= allowed_flip, f"{name}: {n_flip} of {ref.size} entries over {soft_max} (threshold flips; allowed {allowed_flip}); max err {err.max():.3e}"
+    assert abs_max <= FLIP_ABS_MAX, f"{name}: an entry is off by {abs_max:.3g} x max|ref| (allowed {FLIP_ABS_MAX}): larger than any single contribution"
     return stats
 
 
@@ -180,3 +189,39 @@ def oracle_surfel_forward_backward(scene, W, H, grads=None, far=80, near=0, scal
     if grads is not None:
         out.update(lgo_surfel.backward(f, *grads))
     return out
+
+
+# ---- the band of the reference itself, entry by entry (tests/test_sweep_residue_gpu.py, tools/sweep_envelope.py) ---------------------
+ULP_MODES = ((1, 1), (1, 2), (2, 0), (3, 0))     # lgo_set_ulp_perturbation: pseudo-random (two seeds), all up, all down
+
+
+def oracle_envelope(scene, W, H, grads, kw, keys):
+    """The plain oracle and, per array of `keys`, the entry-wise [min, max] over it and four runs with every cos / sin / atan2 / tan / exp
+    result moved inside its CUDA-libdevice error bound (oracle/lidargs_oracle.c lgo_set_ulp_perturbation; tests/test_ulp_band_cpu.py)."""
+    import ctypes as C
+    from oracle import lgo
+    L = lgo.lib()
+    runs = [oracle_forward_backward(scene, W, H, grads, **kw)]
+    for mode, sd in ULP_MODES:
+        L.lgo_set_ulp_perturbation(C.c_int(mode), C.c_uint(sd))
+        try:
+            runs.append(oracle_forward_backward(scene, W, H, grads, **kw))
+        finally:
+            L.lgo_set_ulp_perturbation(C.c_int(0), C.c_uint(0))
+    lo = {k: np.min([np.asarray(r[k], np.float64) for r in runs], 0) for k in keys}
+    hi = {k: np.max([np.asarray(r[k], np.float64) for r in runs], 0) for k in keys}
+    return runs[0], lo, hi
+
+
+def envelope_residue(hip, base, lo, hi, k, rtol=RTOL, floor=FLOOR):
+    """Where HIP is off by more than rtol (parity()'s metric) on array k: does the reference's own band reach that far there, and how
+    far outside the envelope [lo, hi] does HIP lie, in units of (the envelope's width at the entry + the rtol bar)?"""
+    h = np.asarray(hip[k], np.float64); r = np.asarray(base[k], np.float64)
+    den = np.abs(r) + floor * np.abs(r).max() + 1e-30
+    off = np.abs(h - r) / den > rtol
+    band = (hi[k] - lo[k]) / den
+    out = np.maximum(np.maximum(lo[k] - h, h - hi[k]), 0.0)
+    rel_out = out / ((hi[k] - lo[k]) + rtol * den)
+    return dict(n=int(r.size), hip_over=int(off.sum()), oracle_band_over=int((band > rtol).sum()),
+                hip_over_where_oracle_moves=int((off & (band > rtol)).sum()), hip_over_where_oracle_moves_half=int((off & (band > 0.5 * rtol)).sum()),
+                worst_outside_in_widths=float(rel_out[off].max()) if off.any() else 0.0, worst_outside_anywhere=float(rel_out.max()))

@@ -7,28 +7,8 @@ import numpy as np
 import lidargs_scenes as sc
 from util import hip_forward_backward, oracle_forward_backward
 seed = int(sys.argv[1]); mid = (sys.argv[2] == "mid") if len(sys.argv) > 2 else seed >= 100000      # python tools/repro_sweep_seed.py <seed> [small|mid]
-rng = np.random.default_rng(seed)
-if mid:
-    H = int(rng.choice([16, 32, 64])); W = int(rng.choice([900, 1800, 2650])); P = int(rng.integers(20000, 60000))
-else:
-    H = int(rng.choice([2, 3, 5, 16, 17, 32, 40, 64])); W = int(rng.integers(1, 700)); P = int(rng.integers(1, 6000))
-if not mid and seed % 7 == 5:
-    W = int(rng.integers(4100, 4300)); H = int(rng.choice([2, 3, 16])); P = int(rng.integers(1, 3000))
-if not mid and seed % 11 == 7:
-    H = int(rng.choice([130, 272])); W = int(rng.integers(1, 200)); P = int(rng.integers(1, 3000))
-if not mid and seed % 17 == 4:
-    H = int(rng.choice([1025, 1100])); W = int(rng.integers(64, 200)); P = int(rng.integers(1, 3000))
-if not mid and seed % 19 == 6:
-    H = 1100; W = 4800; P = int(rng.integers(1, 2000))
-kind = "shell" if rng.random() < 0.5 else "street"
-beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
-kw = dict(far=int(rng.choice([80, 30])), near=int(rng.choice([0, 2])), scale_modifier=float(rng.choice([1.0, 0.5, 2.5])))
-if not mid and seed % 13 == 3:
-    kw["scale_modifier"] = float(rng.choice([6.0, 12.0, 30.0]))
-scene = sc.make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)), beams=beams)
-if seed % 23 == 8:
-    scene["opacities"] = (scene["opacities"] * np.float32(0.008)).astype(np.float32)
-grads = sc.upstream_grads(H, W, seed % 1000)
+scene, W, H, grads, kw, desc = sc.sweep_case(seed, mid)
+kind, P, beams = desc['kind'], desc['P'], desc['beams']
 hip = hip_forward_backward(scene, W, H, grads, **kw)
 ref = oracle_forward_backward(scene, W, H, grads, **kw)
 from diff_lidargs_rasterization import _C
