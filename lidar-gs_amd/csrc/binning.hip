@@ -596,9 +596,6 @@ static void radix_pass(const KT* kin, const uint32_t* vin, KT* kout, uint32_t* v
     static const int env = [] { const char* e = getenv("LIDARGS_SORT_ITEMS"); return e ? atoi(e) : 0; }();   // 8 / 16 forces the block size
     const bool room = BITS + 1 <= scratch_bits;                  // twice the blocks x BINS <= the histogram area (and the chunk sums likewise)
     const bool half = room && (env ? env == 8 : n <= ((size_t)4 << 20));
-    if constexpr (BITS <= 9) {
-        if (env == 4 && BITS + 2 <= scratch_bits) { radix_pass_items<BITS, SORT_ITEMS / 4, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias); return; }   // experiment: quarter-size blocks
-    }
     if constexpr (BITS <= 10) {
         if (half) { radix_pass_items<BITS, SORT_ITEMS / 2, KT>(kin, vin, kout, vout, n, n_dev, shift, scratch, s, scratch_bits, tail, bias); return; }
     }
