@@ -675,7 +675,7 @@ def bench_decode(args):
                                  "achieved": mfma_flop / t_bwd / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": mfma_flop / t_bwd / 1e12 / 157.3,
                                  "mfma_instructions_per_launch": mfma_insts, "backward_ms": t_bwd * 1e3,
                                  "note": "f32-in / f32-accumulate v_mfma_f32_32x32x2_f32, 4096 flop per instruction; the products are a third of "
-                                         "the launch, the per-anchor VALU stage and its LDS round trips the rest (DESIGN.md 6b)"}}}
+                                         "the launch, the per-anchor VALU stage and its LDS round trips the rest (DESIGN.md section 7, EXPERIMENTS.md 6b)"}}}
     if not args.no_cpu_baseline:
         from oracle import neural_gaussians as ng
         from oracle import neural_gaussians_torch as ngt
