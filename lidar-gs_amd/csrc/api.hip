@@ -386,6 +386,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     lg::RadixTail span_tail;                                           // the sort's last pass leaves the spans in range order as well
     span_tail.src = geom.spans; span_tail.dst = geom.span_sorted; span_tail.mode = pp.compact ? 1 : 2;
     const uint32_t* ids_sorted;
+    int first_side = 1;                                                // where the first pass left the pairs (0: a side, 1: b side)
     // The sort runs on key - kmin (the preprocess left ~kmin and kmax in the totals' slots): a frame's ranges span far fewer than 31 key
     // bits -- 2 m .. 80 m is 26 -- and every 8-9 bits less is a pass (three launches) less.  kmin is rounded down to a multiple of 256,
     // so the first pass (the key's own low byte) needs no host knowledge and is queued right behind the totals' copy; the host then
@@ -397,8 +398,9 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         LG_STAGE_CHECK("range sort");
         g_prof.mark("range_sort", stream);
     } else {
-        lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 8, geom.scratch, stream, 8, nullptr,
-                                    lg::SORT_MAX_RADIX_BITS, true);                                       // -> (key_b, id_b)
+        // (its result side is kept: one pass of the general form ends on the b side, the single-launch form of small inputs on the a side)
+        first_side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 8, geom.scratch, stream, 8, nullptr,
+                                                 lg::SORT_MAX_RADIX_BITS, true);
         LG_STAGE_CHECK("range sort, first pass");
         ids_sorted = nullptr;
     }
@@ -427,9 +429,11 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
             if (bits < 9) bits = 9;
             static const int env_full = [] { const char* e = getenv("LIDARGS_RANGE_SORT_FULL"); return e ? atoi(e) : 0; }();   // 1: always 31 bits (A/B)
             if (env_full) { bits = 32; kb.kmin = 0u; kb.cull = 0xFFFFFFFFu; }
-            const int side = lg::launch_radix_sort_pairs(geom.key_b, geom.key_a, geom.id_b, geom.id_a, (size_t)P, bits, geom.scratch, stream,
+            uint32_t* const k_in = first_side ? geom.key_b : geom.key_a; uint32_t* const k_out = first_side ? geom.key_a : geom.key_b;
+            uint32_t* const v_in = first_side ? geom.id_b : geom.id_a; uint32_t* const v_out = first_side ? geom.id_a : geom.id_b;
+            const int side = lg::launch_radix_sort_pairs(k_in, k_out, v_in, v_out, (size_t)P, bits, geom.scratch, stream,
                                                          bits > 26 ? 8 : 9, nullptr, lg::SORT_MAX_RADIX_BITS, false, span_tail, 8, &kb);
-            ids_sorted = side ? geom.id_a : geom.id_b;
+            ids_sorted = side ? v_out : v_in;
             LG_STAGE_CHECK("range sort");
             g_prof.mark("range_sort", stream);
         }

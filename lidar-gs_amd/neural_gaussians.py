@@ -40,18 +40,28 @@ def _transposed_w2(params, k, dev):
     return tuple(out[32 * o[i]:32 * o[i] + 32 * (7 * k if i == 1 else k)].view(32, 7 * k if i == 1 else k) for i in range(4))
 
 
-_CAPACITY_BYTES = int(os.environ.get("LIDARGS_NG_CAPACITY_BYTES", str(1 << 30)))   # largest N k x 52-byte output block the decode allocates to skip the wait; 0 = always wait
+# Largest N k x 52-byte output block the decode allocates to skip the wait (0 = always wait).  The block is capacity-sized -- N k rows, of
+# which the M selected ones (typically a fifth to a third) are handed out as views -- and autograd keeps it alive until the backward, so
+# the default bounds what a step can hold that way at 256 MB (4.9 M candidate rows: 820 k anchors x 6 offsets); larger models take the
+# waiting path, whose outputs are exactly M rows (round-3 advisor finding: the default used to be 1 GB).
+_CAPACITY_BYTES = int(os.environ.get("LIDARGS_NG_CAPACITY_BYTES", str(256 << 20)))
 _PINNED = {}
+_PINNED_LOCK = __import__("threading").Lock()
 
 
 def _pinned_counts(dev):
-    """Per (device, thread): two pinned ints the selection's counts land in, and the event in front of the decode launch."""
+    """Per (device, thread): two pinned ints the selection's counts land in, and the event in front of the decode launch.  The device
+    index is resolved (a bare "cuda" device has none) and the event is created with that device current: an event binds to the device of
+    its first record.  The table is shared by the autograd threads: guarded."""
     import threading
-    key = (dev.index, threading.get_ident())
-    hit = _PINNED.get(key)
-    if hit is None:
-        hit = (torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        _PINNED[key] = hit
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, threading.get_ident())
+    with _PINNED_LOCK:
+        hit = _PINNED.get(key)
+        if hit is None:
+            with torch.cuda.device(index):
+                hit = (torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+            _PINNED[key] = hit
     return hit
 
 
