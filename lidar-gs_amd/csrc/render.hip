@@ -1129,19 +1129,20 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 const float gdx = gd2.x, gdy = gd2.y;
                 const v2f gxy = -dL_dG * (gd2 * v2f{A, Cc} + v2f{gdy, gdx} * B);   // dL/dmean2D  (:734,:753)
                 const float gx = gxy.x, gy = gxy.y;
-                // per-pixel sphere-gradient norm statistic (:759-779): |gx u1' + gy u2'|
-                const float sx = gx * ux.x + gy * ux.y, sy = gx * uy.x + gy * uy.y, sz = gx * uz.x + gy * uz.y;
+                // per-pixel sphere-gradient norm statistic (:759-779): |gx u1' + gy u2'|.  u1, u2 are orthonormal (u1 normalised, u2 = dir x u1;
+                // u_i' = u_i / (u_i.u_i)), so the norm is sqrt(gx^2 + gy^2) up to their rounding (1e-7): three instructions instead of ten.
+                // At a pole (u1 = 0, the only degenerate case) d = 0 and with it gx = gy = 0 in both forms.
                 // dL/du1 = gx (delta/uu1 - 2 dx u1') per pixel (:738-750), with dx = delta . u1'.  Its sum over the pixels is
                 //   |u1'|^2 G1 - 2 u1' (u1' . G1),   G1 = sum gx delta   (and the same with gy, u2' for dL/du2),
                 // and u1', u2' are per-Gaussian: the pixels only accumulate the two moment vectors G1, G2 (three packed
                 // multiplies instead of ten packed operations); k_gaussian_backward finishes the expression once per Gaussian
-                const v2f bx = gxy * ex, by = gxy * ey, bz = gxy * ez;   // (gx, gy) * delta
+
                 float v[16];
                 v[0] = gx;
                 v[1] = gy;
                 // hardware square root (1 ulp, one instruction; sqrtf's correctly rounded expansion is 17): this slot is the sum of
                 // per-pixel norms that feeds the densification statistic, not a gradient, and a last-bit error per term is 1e-7 of it
-                v[2] = __builtin_amdgcn_sqrtf(sx * sx + sy * sy + sz * sz);
+                v[2] = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
                 const float mh = -0.5f * dL_dG;
                 const v2f cac = mh * gd2 * d;                          // conic A, C (:783)
                 const v2f wc = w * g01;                                // colours (:702)
@@ -1152,8 +1153,8 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 v[7] = wc.x;
                 v[8] = wc.y;
                 v[9] = w * gd;                                         // range (:711)
-                v[10] = bx.x; v[11] = by.x; v[12] = bz.x;              // G1 = sum gx delta  (-> dL/du1)
-                v[13] = bx.y; v[14] = by.y; v[15] = bz.y;              // G2 = sum gy delta  (-> dL/du2)
+                v[10] = gx * ex; v[11] = gx * ey; v[12] = gx * ez;     // G1 = sum gx delta  (-> dL/du1)   (six plain multiplies: the packed
+                v[13] = gy * ex; v[14] = gy * ey; v[15] = gy * ez;     // G2 = sum gy delta  (-> dL/du2)    form cost five moves to pair delta up)
                 T = Tn;
                 acc01 = a01; accdo = ado;
                 lc01 = c01; ldo = cdo;
