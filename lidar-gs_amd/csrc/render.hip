@@ -1045,6 +1045,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     }
     float last_alpha = 0.f;
     v2f lc01 = v2f{0.f, 0.f}, ldo = v2f{0.f, 1.f};                    // last entry's (colour0, colour1) | (range, 1)
+    float* const gacc_slot = a.gacc + (8 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 2 * (lane & 1) + ((lane >> 1) & 1));   // this lane's slot of a Gaussian's packed line (reduce_scatter16)
 
     const int y0 = (tile / a.grid.tiles_x) * a.grid.TH + sub * LG_WAVE_ROWS;       // first pixel row of the patch
     const float* oprow = reinterpret_cast<const float*>(s_oprow) + (lane >> 4);
@@ -1079,9 +1080,10 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
         if (c > 0) gather(c - 1, st, gid, have);
         if (todo == 0ull) continue;
         // back to front, software-pipelined like the forward walk (walk_flagged): two register sets, unconditional look-ahead reads
-        struct Rec { float4 r0, r1, r2, r3; float op; };
+        struct Rec { float4 r0, r1, r2, r3; float op; uint32_t gid; };
         auto read = [&](int jj) {
             Rec r;
+            r.gid = lds_ahead(&s_gid[jj]);                             // with the look-ahead reads: fetched where the atomic needs it, the owners waited out an LDS round trip per entry
             const float* f3 = reinterpret_cast<const float*>(&s_rec[3 * CS + jj]);
             const float4 s0 = lds_ahead(&s_rec[jj]);                   // s.xyz | B  (park_record)
             r.r1 = lds_ahead(&s_rec[CS + jj]); r.r2 = lds_ahead(&s_rec[2 * CS + jj]);
@@ -1159,11 +1161,10 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
                 acc01 = a01; accdo = ado;
                 lc01 = c01; ldo = cdo;
                 last_alpha = alpha;
+                // (the slot's address before the reduction, in every lane: independent work for the wait states between its dependent DPP steps)
+                float* const dst = gacc_slot + 16 * (size_t)r.gid;
                 const float mine = reduce_scatter16(v, lane);
-                if ((lane & 12) == 0) {                                 // one owner per slot
-                    const int slot = 8 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 2 * (lane & 1) + ((lane >> 1) & 1);
-                    atomicAdd(a.gacc + 16 * (size_t)s_gid[j] + slot, mine);
-                }
+                if ((lane & 12) == 0) atomicAdd(dst, mine);             // one owner per slot
             }
         };
         if (V2) {
