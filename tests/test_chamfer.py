@@ -74,3 +74,61 @@ def test_hip_duplicates_pick_lowest_index_and_errors(hip_lib_built):
         chamfer_3D.forward(a.cpu(), b, d1, d2, i1, i2)
     with pytest.raises(RuntimeError, match="int32"):
         chamfer_3D.forward(a, b, d1, d2, i1.long(), i2)
+
+
+def _hip_forward(a, b):
+    import torch
+    import chamfer_3D
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    d1, d2 = torch.full((B, n), -1.0, device="cuda"), torch.full((B, m), -1.0, device="cuda")
+    i1, i2 = torch.full((B, n), -1, dtype=torch.int32, device="cuda"), torch.full((B, m), -1, dtype=torch.int32, device="cuda")
+    chamfer_3D.forward(ta, tb, d1, d2, i1, i2)
+    return d1.cpu().numpy(), d2.cpu().numpy(), i1.cpu().numpy(), i2.cpu().numpy()
+
+
+GRID_CASES = {
+    # what the grid search has to get right: (name -> builder of (a, b))
+    "far_apart": lambda r: ((r.normal(size=(1, 3000, 3)) * 2 + 500).astype(np.float32), (r.normal(size=(1, 2500, 3)) * 2 - 500).astype(np.float32)),   # nobody settles within the rings: the brute force behind takes over
+    "one_far_query": lambda r: (np.concatenate([r.normal(size=(1, 2000, 3)) * 5, [[[900.0, -700.0, 300.0]]]], 1).astype(np.float32), (r.normal(size=(1, 2500, 3)) * 5).astype(np.float32)),
+    "flat": lambda r: (np.concatenate([r.uniform(-60, 60, size=(1, 4000, 2)), np.zeros((1, 4000, 1))], 2).astype(np.float32),
+                       np.concatenate([r.uniform(-60, 60, size=(1, 3500, 2)), np.zeros((1, 3500, 1))], 2).astype(np.float32)),
+    "line": lambda r: (np.concatenate([r.uniform(-80, 80, size=(1, 3000, 1)), np.full((1, 3000, 2), 1.5)], 2).astype(np.float32),
+                       np.concatenate([r.uniform(-80, 80, size=(1, 3100, 1)), np.full((1, 3100, 2), 1.5)], 2).astype(np.float32)),
+    "clustered": lambda r: ((r.normal(size=(1, 5000, 3)) * np.where(r.random((1, 5000, 1)) < 0.9, 0.05, 40.0)).astype(np.float32),
+                            (r.normal(size=(1, 5000, 3)) * np.where(r.random((1, 5000, 1)) < 0.9, 0.05, 40.0)).astype(np.float32)),
+    "on_cell_faces": lambda r: ((np.round(r.uniform(-20, 20, size=(1, 4000, 3)) * 2) / 2).astype(np.float32), (np.round(r.uniform(-20, 20, size=(1, 4000, 3)) * 2) / 2).astype(np.float32)),   # lattice points: ties everywhere
+    "big_offset": lambda r: ((r.normal(size=(1, 3000, 3)) * 3 + 1.0e4).astype(np.float32), (r.normal(size=(1, 3000, 3)) * 3 + 1.0e4).astype(np.float32)),   # coarse ulps against a small extent
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(GRID_CASES))
+def test_hip_grid_search_edge_cases(case, hip_lib_built):
+    """The uniform-grid search in front of the brute force (round 4) on inputs built against it; indices and distances bit for bit."""
+    a, b = GRID_CASES[case](np.random.default_rng(sum(map(ord, case))))
+    ref = chamfer3d.forward(a, b)
+    d1, d2, i1, i2 = _hip_forward(a, b)
+    assert np.array_equal(i1, ref[2]) and np.array_equal(i2, ref[3]), case
+    assert np.array_equal(d1, ref[0]) and np.array_equal(d2, ref[1]), case
+
+
+@pytest.mark.gpu
+def test_hip_grid_search_at_frame_size_against_the_kdtree(hip_lib_built):
+    """Two LiDAR-like clouds of one 64 x 2650 frame each (the size PointsMeter feeds it): too many pairs for the numpy oracle, so the
+    distances are held against scipy's KD-tree (float64) and the indices by re-evaluating the reference's fp32 expression at them."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(7)
+    n = 64 * 2650
+    def cloud():
+        az = rng.uniform(-np.pi, np.pi, n); el = rng.uniform(-0.31, 0.04, n); r = np.minimum(rng.gamma(2.0, 9.0, n) + 2.0, 80.0)
+        return np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1).astype(np.float32)[None]
+    a, b = cloud(), cloud()
+    b[0, :5000] = a[0, :5000] + rng.normal(scale=0.02, size=(5000, 3)).astype(np.float32)
+    d1, d2, i1, i2 = _hip_forward(a, b)
+    for q, t, d, i in ((a[0], b[0], d1[0], i1[0]), (b[0], a[0], d2[0], i2[0])):
+        assert i.min() >= 0 and i.max() < t.shape[0]
+        diff = t[i] - q
+        assert np.array_equal(d, (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])     # the reported neighbour's own fp32 distance
+        dd, _ = cKDTree(t.astype(np.float64)).query(q.astype(np.float64))
+        assert np.all(d <= (dd ** 2) * (1 + 1e-5) + 1e-9)                                                         # ... and nobody is nearer
