@@ -8,7 +8,7 @@
 // for the roundings of the cell assignment and of the distance).  Queries that are not settled within CH_RINGS rings raise a flag,
 // and the brute-force launch behind -- which otherwise leaves on one load -- then recomputes that direction completely: pathological
 // inputs (a query cloud far from the targets) cost what round 3 cost, everything else ~50x less.  Same distances and indices bit for
-// bit (tests/test_chamfer.py against the numpy oracle).
+// bit (tests/test_chamfer.py).
 //
 // The brute force:
 // 170 k x 170 k points per evaluated frame = 2.9e10 point pairs per direction: pure VALU work (8 ops per pair as written, no
