@@ -265,6 +265,23 @@ int lidargs_forward_shell(
     float* out_color, float* out_depth, float* out_occ, float* T_out,
     int* radii, int* radii_xy, int debug, void* stream);
 
+/* lidargs_forward_shell without its host wait, as lidargs_forward_enqueue is to lidargs_forward (instance_capacity, tile_rows,
+ * status_host: see there), for rank frames the host only enqueues.  n_valid (DEVICE word, or NULL = all P): the P rows are a
+ * capacity-sized selection (lidargs_shell_select_enqueue) of which only the first *n_valid exist; the rest are culled unread. */
+int lidargs_forward_shell_enqueue(
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, const float* background, int width, int height,
+    const float* means3D, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* beam_inclinations,
+    int lidar_far, int lidar_near, float shell_lo, float shell_hi,
+    const float* T_in, int transmittance_pass,
+    float* out_color, float* out_depth, float* out_occ, float* T_out,
+    int* radii, int* radii_xy, int debug,
+    const unsigned* n_valid, int instance_capacity, int tile_rows, unsigned* status_host, void* stream);
+
 int lidargs_render_shell(
     int P, int R, const float* background, int width, int height,
     char* geom_buffer, char* binning_buffer, char* image_buffer,
@@ -292,7 +309,10 @@ int lidargs_backward_shell(
  * lidargs_shell_select_count / _gather are its two halves: count (flags + scan + the host read, result left in `scratch`) returns
  * M, after which the caller allocates exactly M rows PER FRAME and gather fills them -- a forward's selection is saved for its
  * backward and must not be overwritten by the next forward's (several views per step, gradient accumulation, an eval render).
- * lidargs_shell_transmittance: T_in[i] = prod_{g<rank} all_T[g*N+i].
+ * The gathers take chunk_counts f32[world] (or NULL): the number of selected rows whose index lies in each index chunk of
+ * chunk_rows -- the split sizes of the gradient all-to-all, read off the scan (world <= 256).
+ * lidargs_shell_transmittance: T_in[i] = prod_{g<rank} all_T[g*row_stride+i] (row_stride >= N floats: the gathered rows may
+ * carry a tail behind their N transmittances).
  * lidargs_shell_compose folds the gathered per-shell planes (planes f32[G*5*N], per shell C0, C1, D, T_end, T_hand):
  * image = sum of partials (+ T_final * background), T_final = T_end of the first shell whose T_hand < 1e-4 (the last
  * shell's otherwise), behind f32[3N] = sum of the partials of the shells behind `rank`. */
@@ -306,8 +326,24 @@ int lidargs_shell_select_count(int P, const float* means3D, const float* viewmat
 int lidargs_shell_select_gather(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
                                 const float* rotations, int* idx_out, float* out_means3D, float* out_colors,
                                 float* out_opacities, float* out_scales, float* out_rotations, char* scratch,
-                                size_t scratch_bytes, void* stream);
-int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, void* stream);
+                                size_t scratch_bytes, int chunk_rows, int world, float* chunk_counts, void* stream);
+/* The selections without their host read (enqueue-only rank frames): the caller states a row CAPACITY (e.g. 1.25 x what the
+ * previous frame selected) and gets capacity-row arrays of which the first min(selected, capacity) are filled.  idx_out's tail
+ * holds 0x7F7F7F7F (ascending order kept; every consumer skips indices >= P).  n_valid_dev u32[2] (device): [0] rows gathered --
+ * hand it to lidargs_forward_shell_enqueue / _wedge_enqueue as n_valid --, [1] rows selected; status_host (PINNED u32[2], optional)
+ * receives both behind the launches: [1] > capacity means rows were dropped and the frame must be redone with more. */
+int lidargs_shell_select_enqueue(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                                 const float* rotations, const float* viewmatrix, float shell_lo, float shell_hi, int capacity,
+                                 int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
+                                 float* out_rotations, unsigned* n_valid_dev, unsigned* status_host, char* scratch,
+                                 size_t scratch_bytes, int chunk_rows, int world, float* chunk_counts, void* stream);
+int lidargs_wedge_select_enqueue(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                                 const float* rotations, float scale_modifier, const float* viewmatrix, int width, int col_lo,
+                                 int col_hi, int capacity, int* idx_out, float* out_means3D, float* out_colors,
+                                 float* out_opacities, float* out_scales, float* out_rotations, unsigned* n_valid_dev,
+                                 unsigned* status_host, char* scratch, size_t scratch_bytes, int chunk_rows, int world,
+                                 float* chunk_counts, void* stream);
+int lidargs_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, void* stream);
 int lidargs_shell_compose(int G, int rank, int N, const float* planes, const float* background, float* out_color,
                           float* out_depth, float* out_occ, float* T_final, float* behind, void* stream);
 
@@ -338,6 +374,17 @@ int lidargs_forward_wedge(
     const float* viewmatrix, const float* beam_inclinations, int lidar_far, int lidar_near,
     int col_lo, int col_hi,
     float* out_color, float* out_depth, float* out_occ, int* radii, int* radii_xy, int debug, void* stream);
+int lidargs_forward_wedge_enqueue(               /* lidargs_forward_wedge without its host wait: see lidargs_forward_shell_enqueue */
+    lidargs_alloc_fn geometry_alloc, void* geometry_user,
+    lidargs_alloc_fn binning_alloc, void* binning_user,
+    lidargs_alloc_fn image_alloc, void* image_user,
+    int P, const float* background, int width, int height,
+    const float* means3D, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* beam_inclinations, int lidar_far, int lidar_near,
+    int col_lo, int col_hi,
+    float* out_color, float* out_depth, float* out_occ, int* radii, int* radii_xy, int debug,
+    const unsigned* n_valid, int instance_capacity, int tile_rows, unsigned* status_host, void* stream);
 int lidargs_backward_wedge(
     int P, int R, const float* background, int width, int height,
     const float* means3D, const float* colors_precomp, const float* scales, float scale_modifier,

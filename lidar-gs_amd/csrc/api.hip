@@ -321,7 +321,10 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
                  const float* beams, float near_f, float far_f, float shell_lo, float shell_hi, const float* T_in,
                  int transmittance_pass, float* out_color, float* out_depth, float* out_occ, float* T_out, int* radii,
                  int* radii_xy, int debug, hipStream_t stream, long long instance_capacity = 0, int fixed_tile_rows = 0,
-                 unsigned* status_host = nullptr, int col_lo = -1, int col_hi = -1, bool is_shell = false) {
+                 unsigned* status_host = nullptr, int col_lo = -1, int col_hi = -1, bool is_shell = false,
+                 const uint32_t* n_valid = nullptr) {
+    // n_valid (device word, optional): the P rows are a capacity-sized selection of which only the first *n_valid exist (enqueue-only
+    // rank frames of the sharded path): the preprocess culls the rest before reading them, everything behind it sees culled Gaussians.
     // is_shell: the call comes from lidargs_forward_shell.  Its backward (lidargs_backward_shell) walks the slot grid with the flags and
     // limits of the segmented launches, whatever T_in / T_out / transmittance_pass were -- a first or only shell passes none of them
     // -- so the mode is the entry point's, not inferred from those arguments (round-3 advisor finding: a direct ABI caller of a single
@@ -371,6 +374,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     pp.col_step = 2 * pi_f / width; pp.inv_col_step = (1.f / pp.col_step) * 1.000001f;                                    // R3/cr/forward.cu:334
     pp.tan_col_step = tanf(2 * pi_f / width);                          // R3/cr/forward.cu:362
     pp.view = viewmatrix;
+    pp.n_valid = n_valid;
 
     lg::launch_preprocess(pp, means3D, scales, rotations, opacities, colors_precomp, cov3D_precomp, beams, radii, radii_xy,
                           geom, &img, false, stream);                  // also fills the pixel-ray tables of the image buffer
@@ -742,6 +746,22 @@ int lidargs_forward_shell(lidargs_alloc_fn geometry_alloc, void* geometry_user, 
                         out_color, out_depth, out_occ, T_out, radii, radii_xy, debug, (hipStream_t)stream, 0, 0, nullptr, -1, -1, true);
 }
 
+int lidargs_forward_shell_enqueue(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                                  lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
+                                  const float* means3D, const float* colors_precomp, const float* opacities, const float* scales,
+                                  float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                  const float* beam_inclinations, int lidar_far, int lidar_near, float shell_lo, float shell_hi,
+                                  const float* T_in, int transmittance_pass, float* out_color, float* out_depth, float* out_occ,
+                                  float* T_out, int* radii, int* radii_xy, int debug, const unsigned* n_valid, int instance_capacity,
+                                  int tile_rows, unsigned* status_host, void* stream) {
+    if (instance_capacity <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_shell_enqueue: instance_capacity must be positive%s");
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
+                        height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        beam_inclinations, (float)lidar_near, (float)lidar_far, shell_lo, shell_hi, T_in, transmittance_pass,
+                        out_color, out_depth, out_occ, T_out, radii, radii_xy, debug, (hipStream_t)stream, (long long)instance_capacity,
+                        tile_rows, status_host, -1, -1, true, n_valid);
+}
+
 // ---- column wedges (multi-GPU): rank g bins and renders the tile columns of pixel columns [col_lo, col_hi) only --------------------
 int lidargs_forward_wedge(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
                           lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
@@ -758,6 +778,24 @@ int lidargs_forward_wedge(lidargs_alloc_fn geometry_alloc, void* geometry_user, 
                         height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                         beam_inclinations, (float)lidar_near, (float)lidar_far, -inf, inf, nullptr, 0, out_color, out_depth, out_occ,
                         nullptr, radii, radii_xy, debug, (hipStream_t)stream, 0, 0, nullptr, col_lo, col_hi);
+}
+
+int lidargs_forward_wedge_enqueue(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_alloc_fn binning_alloc, void* binning_user,
+                                  lidargs_alloc_fn image_alloc, void* image_user, int P, const float* background, int width, int height,
+                                  const float* means3D, const float* colors_precomp, const float* opacities, const float* scales,
+                                  float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                  const float* beam_inclinations, int lidar_far, int lidar_near, int col_lo, int col_hi, float* out_color,
+                                  float* out_depth, float* out_occ, int* radii, int* radii_xy, int debug, const unsigned* n_valid,
+                                  int instance_capacity, int tile_rows, unsigned* status_host, void* stream) {
+    if (col_lo < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_wedge: col_lo < 0%s");
+    if (cov3D_precomp) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_wedge: cov3D_precomp is not supported on the column-wedge path (give scales + rotations)%s");
+    if (instance_capacity <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward_wedge_enqueue: instance_capacity must be positive%s");
+    const float inf = std::numeric_limits<float>::infinity();
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, background, width,
+                        height, means3D, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                        beam_inclinations, (float)lidar_near, (float)lidar_far, -inf, inf, nullptr, 0, out_color, out_depth, out_occ,
+                        nullptr, radii, radii_xy, debug, (hipStream_t)stream, (long long)instance_capacity, tile_rows, status_host,
+                        col_lo, col_hi, false, n_valid);
 }
 
 int lidargs_backward_wedge(int P, int R, const float* background, int width, int height, const float* means3D, const float* colors_precomp,
@@ -845,13 +883,12 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.flags = bin.flags; ra.R = Rp;             // written by the shell's phase 1 (lidargs_forward_shell)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
+    ra.T_end_out = transmittance_pass ? nullptr : T_end_out;          // the combine writes it beside final_T
     if (!transmittance_pass && (!out_color || !out_depth || !out_occ)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "render_shell: NULL output%s");
     if (ra.run_pass1) run_pass1_rounds(ra, plan, bin.alive, stream);
     if (!transmittance_pass) lg::launch_render_pass2(ra, stream);
     lg::launch_render_combine(ra, stream);
     LG_STAGE_CHECK("render shell");
-    if (T_end_out && !transmittance_pass)
-        LG_HIP(hipMemcpyAsync(T_end_out, img.final_T, sizeof(float) * (size_t)width * height, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 
@@ -986,10 +1023,15 @@ int lidargs_shell_select_count(int P, const float* means3D, const float* viewmat
 
 int lidargs_shell_select_gather(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
                                 const float* rotations, int* idx_out, float* out_means3D, float* out_colors, float* out_opacities,
-                                float* out_scales, float* out_rotations, char* scratch, size_t scratch_bytes, void* stream_) {
+                                float* out_scales, float* out_rotations, char* scratch, size_t scratch_bytes, int chunk_rows, int world,
+                                float* chunk_counts, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: P < 0%s");
-    if (P == 0) return 0;
+    if (chunk_counts && (chunk_rows <= 0 || world <= 0 || world > 256)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: chunk counts need chunk_rows > 0 and 1 <= world <= 256%s");
+    if (P == 0) {
+        if (chunk_counts) LG_HIP(hipMemsetAsync(chunk_counts, 0, sizeof(float) * (size_t)world, stream));
+        return 0;
+    }
     if (!means3D || !colors || !opacities || !scales || !rotations || !idx_out || !out_means3D || !out_colors || !out_opacities ||
         !out_scales || !out_rotations || !scratch)
         return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select: NULL pointer%s");
@@ -997,9 +1039,71 @@ int lidargs_shell_select_gather(int P, const float* means3D, const float* colors
     lg::Carver c(scratch);
     uint32_t* flags = c.take<uint32_t>((size_t)P);
     uint32_t* offs = c.take<uint32_t>((size_t)P);
+    uint32_t* total = c.take<uint32_t>(64);                            // (left there by the count step)
     lg::launch_shell_gather(P, flags, offs, means3D, colors, opacities, scales, rotations, idx_out, out_means3D, out_colors, out_opacities,
-                            out_scales, out_rotations, stream);
+                            out_scales, out_rotations, stream, 0xFFFFFFFFu, total, nullptr, chunk_rows, world, chunk_counts);
     return check_launch(stream, 0, "shell select gather");
+}
+
+// Enqueue-only selections (no host read): flags + scan as above, then the gather into CAPACITY rows.  idx_out's tail is filled with
+// 0x7F7F7F7F (above every index: the array stays ascending, and every consumer skips indices >= P); n_valid_dev[0] = rows gathered =
+// min(selected, capacity), [1] = rows selected; both words go to status_host (pinned, optional) behind the launches.
+namespace {
+int select_gather_capped(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
+                         int capacity, int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
+                         float* out_rotations, unsigned* n_valid_dev, unsigned* status_host, const uint32_t* flags, const uint32_t* offs,
+                         const uint32_t* total, int chunk_rows, int world, float* chunk_counts, hipStream_t stream) {
+    if (chunk_counts && (chunk_rows <= 0 || world <= 0 || world > 256)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "select (enqueue-only): chunk counts need chunk_rows > 0 and 1 <= world <= 256%s");
+    LG_HIP(hipMemsetAsync(idx_out, 0x7F, sizeof(int) * (size_t)capacity, stream));
+    lg::launch_shell_gather(P, flags, offs, means3D, colors, opacities, scales, rotations, idx_out, out_means3D, out_colors, out_opacities,
+                            out_scales, out_rotations, stream, (uint32_t)capacity, total, n_valid_dev, chunk_rows, world, chunk_counts);
+    if (status_host) LG_HIP(hipMemcpyAsync(status_host, n_valid_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return check_launch(stream, 0, "select gather (enqueue-only)");
+}
+}  // namespace
+
+int lidargs_shell_select_enqueue(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                                 const float* rotations, const float* viewmatrix, float shell_lo, float shell_hi, int capacity, int* idx_out,
+                                 float* out_means3D, float* out_colors, float* out_opacities, float* out_scales, float* out_rotations,
+                                 unsigned* n_valid_dev, unsigned* status_host, char* scratch, size_t scratch_bytes, int chunk_rows, int world,
+                                 float* chunk_counts, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0 || capacity <= 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select_enqueue: P and capacity must be positive%s");
+    if (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !idx_out || !out_means3D || !out_colors || !out_opacities ||
+        !out_scales || !out_rotations || !n_valid_dev || !scratch)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select_enqueue: NULL pointer%s");
+    if (scratch_bytes < lidargs_shell_select_scratch_bytes(P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select_enqueue: scratch too small%s");
+    lg::Carver c(scratch);
+    uint32_t* flags = c.take<uint32_t>((size_t)P);
+    uint32_t* offs = c.take<uint32_t>((size_t)P);
+    uint32_t* total = c.take<uint32_t>(64);
+    uint32_t* scan_scratch = c.take<uint32_t>(lg::scan_scratch_words((size_t)P));
+    lg::launch_shell_flags(P, means3D, viewmatrix, shell_lo, shell_hi, flags, stream);
+    lg::launch_exclusive_scan(flags, offs, (size_t)P, total, scan_scratch, stream);
+    return select_gather_capped(P, means3D, colors, opacities, scales, rotations, capacity, idx_out, out_means3D, out_colors, out_opacities,
+                                out_scales, out_rotations, n_valid_dev, status_host, flags, offs, total, chunk_rows, world, chunk_counts, stream);
+}
+
+int lidargs_wedge_select_enqueue(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                                 const float* rotations, float scale_modifier, const float* viewmatrix, int width, int col_lo, int col_hi,
+                                 int capacity, int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
+                                 float* out_rotations, unsigned* n_valid_dev, unsigned* status_host, char* scratch, size_t scratch_bytes,
+                                 int chunk_rows, int world, float* chunk_counts, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P <= 0 || capacity <= 0 || width <= 0 || col_lo < 0 || col_hi <= col_lo) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select_enqueue: bad sizes%s");
+    if (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !idx_out || !out_means3D || !out_colors || !out_opacities ||
+        !out_scales || !out_rotations || !n_valid_dev || !scratch)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select_enqueue: NULL pointer%s");
+    if (scratch_bytes < lidargs_shell_select_scratch_bytes(P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select_enqueue: scratch too small%s");
+    lg::Carver c(scratch);
+    uint32_t* flags = c.take<uint32_t>((size_t)P);
+    uint32_t* offs = c.take<uint32_t>((size_t)P);
+    uint32_t* total = c.take<uint32_t>(64);
+    uint32_t* scan_scratch = c.take<uint32_t>(lg::scan_scratch_words((size_t)P));
+    lg::launch_wedge_flags(P, means3D, scales, rotations, scale_modifier, viewmatrix, width, col_lo, col_hi, flags, stream);
+    lg::launch_exclusive_scan(flags, offs, (size_t)P, total, scan_scratch, stream);
+    return select_gather_capped(P, means3D, colors, opacities, scales, rotations, capacity, idx_out, out_means3D, out_colors, out_opacities,
+                                out_scales, out_rotations, n_valid_dev, status_host, flags, offs, total, chunk_rows, world, chunk_counts, stream);
 }
 
 // both steps in one call, into P-row arrays
@@ -1009,7 +1113,7 @@ int lidargs_shell_select(int P, const float* means3D, const float* colors, const
     const int M = lidargs_shell_select_count(P, means3D, viewmatrix, shell_lo, shell_hi, scratch, scratch_bytes, stream_);
     if (M <= 0) return M;
     const int rc = lidargs_shell_select_gather(P, means3D, colors, opacities, scales, rotations, idx_out, out_means3D, out_colors, out_opacities,
-                                               out_scales, out_rotations, scratch, scratch_bytes, stream_);
+                                               out_scales, out_rotations, scratch, scratch_bytes, 0, 0, nullptr, stream_);
     return rc < 0 ? rc : M;
 }
 
@@ -1044,9 +1148,9 @@ int lidargs_shell_scatter_radii(int M, const int* idx, const int* radii_shell, i
     return check_launch((hipStream_t)stream, 0, "shell scatter radii");
 }
 
-int lidargs_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, void* stream_) {
-    if (G < 1 || rank < 0 || rank >= G || N < 0 || !all_T || !T_in) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_transmittance: bad argument%s");
-    if (N) lg::launch_shell_transmittance(G, rank, N, all_T, T_in, (hipStream_t)stream_);
+int lidargs_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, void* stream_) {
+    if (G < 1 || rank < 0 || rank >= G || N < 0 || row_stride < (size_t)N || !all_T || !T_in) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_transmittance: bad argument%s");
+    if (N) lg::launch_shell_transmittance(G, rank, N, row_stride, all_T, T_in, (hipStream_t)stream_);
     return 0;
 }
 

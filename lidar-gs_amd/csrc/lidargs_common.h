@@ -299,6 +299,8 @@ struct PreprocessParams {
     float inv_col_step;         // a bound from above on 1 / col_step (footprint pruning only)
     float tan_col_step;         // tanf(2*pi/W)  (host libm)
     const float* view;          // DEVICE pointer to the 16 floats (wave-uniform -> scalar loads)
+    const uint32_t* n_valid = nullptr;   // DEVICE word, or NULL: rows [*n_valid, P) are padding of a capacity-sized selection (multi-GPU,
+                                         // enqueue-only rank frames) and are culled before any of their attributes is read
 };
 
 // helpers exported by api.hip for the other entry-point files
@@ -340,7 +342,7 @@ void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const f
 void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s);
 void launch_shell_chunk_counts(int M, const int* idx, int chunk, int world, float* counts, hipStream_t s);
 void launch_shell_scatter_i32(int M, const int* idx, const int* src, int P, int* dst, hipStream_t s);
-void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s);
+void launch_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, hipStream_t s);
 void launch_shell_compose(int G, int rank, int N, const float* planes, const float* bg, float* out_color, float* out_depth, float* out_occ,
                           float* T_final, float* behind, hipStream_t s);
 void launch_wedge_pack_columns(int H, int W, int c0, int c1, int wmax, const float* color, const float* depth, const float* occ, float* out, hipStream_t s);
@@ -352,7 +354,8 @@ void launch_wedge_flags(int P, const float* means3D, const float* scales, const 
 void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s);
 void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, const float* means3D, const float* colors, const float* opacities,
                          const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
-                         float* o_scales, float* o_rot, hipStream_t s);
+                         float* o_scales, float* o_rot, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, const uint32_t* total = nullptr,
+                         uint32_t* n_valid_out = nullptr, int chunk_rows = 0, int world = 0, float* chunk_counts = nullptr);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* scratch, hipStream_t s);
 // What the LAST pass of a sort may do instead of writing the sorted keys (which the range sort's callers never read): gather a
 // per-value record by the sorted value and write it at the value's final position -- mode 1: u32 src[val] -> u32 dst[pos] (compact
@@ -437,6 +440,7 @@ struct RenderFwdArgs {
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
     WorkList fill;            // k_render_combine: the backward's work list (cnt == nullptr: none)
     int walk2;                // k_render_fused: the second form of the T-only walk (set by its launcher)
+    float* T_end_out = nullptr;   // k_render_combine: a second copy of final_T (lidargs_render_shell's T_end_out), or NULL
 };
 void launch_render_pass1(const RenderFwdArgs& a, hipStream_t s);     // T-only walk of every segment
 void launch_render_pass2(const RenderFwdArgs& a, hipStream_t s);

@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const PreprocessParams& pp = a.pp;
     const bool in_range = idx < pp.P;                                  // no early return: the whole wave takes part in the sums at the end
+    // a capacity-sized selection's padding rows (enqueue-only rank frames): culled like any other Gaussian -- radius 0, the culled
+    // key, empty spans are WRITTEN for them --, but none of their (uninitialised) attributes is read
+    const bool row_exists = in_range && (pp.n_valid == nullptr || (uint32_t)idx < *pp.n_valid);
     if (!FILTER && a.coltab) {                                         // W + H table entries ride on the first workgroups: one launch less
         const int n = max(pp.W, pp.H);
         for (int i = idx; i < n; i += gridDim.x * blockDim.x) ray_table_entry(i, a.beams, pp.W, pp.H, a.coltab, a.rowtab);
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     bool live = false;
 
     do {
-        if (!in_range) break;
+        if (!row_exists) break;
         const float3 pw = f3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         const float* vm = pp.view;
         const float3 p = f3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12],
@@ -644,10 +647,24 @@ __global__ void __launch_bounds__(256) k_shell_gather(int P, const uint32_t* __r
                                                       const float* __restrict__ opacities, const float* __restrict__ scales,
                                                       const float* __restrict__ rotations, int* __restrict__ idx_out,
                                                       float* __restrict__ o_means, float* __restrict__ o_colors, float* __restrict__ o_opac,
-                                                      float* __restrict__ o_scales, float* __restrict__ o_rot) {
+                                                      float* __restrict__ o_scales, float* __restrict__ o_rot, uint32_t cap,
+                                                      const uint32_t* __restrict__ total, uint32_t* __restrict__ n_valid_out,
+                                                      int chunk_rows, int world, float* __restrict__ chunk_counts) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // the gradient all-to-all's split sizes: selected rows whose index lies in chunk d = [d * chunk_rows, (d + 1) * chunk_rows), straight
+    // from the scan (offs[i] = selected rows in front of index i); exact as floats (< 2^24 rows per chunk)
+    if (chunk_counts && blockIdx.x == 0 && (int)threadIdx.x < world) {
+        const uint32_t t = *total, lim = t < cap ? t : cap;
+        auto before = [&](long long i) { const uint32_t v = i >= (long long)P ? t : offs[i]; return v < lim ? v : lim; };
+        const long long d = threadIdx.x;
+        chunk_counts[d] = (float)(before((d + 1) * chunk_rows) - before(d * chunk_rows));
+    }
+    // capacity-sized selection (enqueue-only rank frames): rows past `cap` are dropped, and the two status words say so --
+    // [0] rows gathered = min(selected, cap) (what k_preprocess takes as its n_valid), [1] rows selected
+    if (n_valid_out && idx == 0) { const uint32_t t = *total; n_valid_out[0] = t < cap ? t : cap; n_valid_out[1] = t; }
     if (idx >= P || flags[idx] == 0u) return;
     const size_t c = offs[idx];
+    if (c >= (size_t)cap) return;
     idx_out[c] = idx;
     for (int k = 0; k < 3; k++) { o_means[3 * c + k] = means3D[3 * (size_t)idx + k]; o_scales[3 * c + k] = scales[3 * (size_t)idx + k]; }
     o_colors[2 * c] = colors[2 * (size_t)idx]; o_colors[2 * c + 1] = colors[2 * (size_t)idx + 1];
@@ -697,9 +714,10 @@ void launch_shell_flags(int P, const float* means3D, const float* view, float lo
 }
 void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, const float* means3D, const float* colors, const float* opacities,
                          const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
-                         float* o_scales, float* o_rot, hipStream_t s) {
+                         float* o_scales, float* o_rot, hipStream_t s, uint32_t cap, const uint32_t* total, uint32_t* n_valid_out,
+                         int chunk_rows, int world, float* chunk_counts) {
     hipLaunchKernelGGL(k_shell_gather, dim3((P + 255) / 256), dim3(256), 0, s, P, flags, offs, means3D, colors, opacities, scales, rotations,
-                       idx_out, o_means, o_colors, o_opac, o_scales, o_rot);
+                       idx_out, o_means, o_colors, o_opac, o_scales, o_rot, cap, total, n_valid_out, chunk_rows, world, chunk_counts);
 }
 
 // ------------------------------------------------------------------------------------------------

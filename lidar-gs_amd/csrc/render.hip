@@ -847,6 +847,7 @@ __global__ void __launch_bounds__(64) k_render_combine(const RenderFwdArgs a) {
     }
     const size_t N = (size_t)g.W * g.H;
     a.final_T[pix] = T_final;
+    if (a.T_end_out) a.T_end_out[pix] = T_final;
     if (a.T_pass) a.T_pass[pix] = T_hand;
     const float b0 = a.bg ? a.bg[0] : 0.f, b1 = a.bg ? a.bg[1] : 0.f;
     a.out_color[pix] = C0 + T_final * b0;                              // :637
@@ -1208,11 +1209,11 @@ void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // Multi-GPU glue (lidargs_dist): per-pixel folds over the G range shells, one launch each instead of a dozen
 // elementwise framework ops on a 0.2 ms critical path.
-__global__ void __launch_bounds__(256) k_shell_transmittance(int G, int rank, int N, const float* __restrict__ all_T, float* __restrict__ T_in) {
+__global__ void __launch_bounds__(256) k_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* __restrict__ all_T, float* __restrict__ T_in) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     float T = 1.f;
-    for (int g = 0; g < rank && g < G; g++) T *= all_T[(size_t)g * N + i];
+    for (int g = 0; g < rank && g < G; g++) T *= all_T[(size_t)g * row_stride + i];
     T_in[i] = T;
 }
 
@@ -1281,8 +1282,8 @@ void launch_wedge_unpack_columns(int G, int H, int W, int wmax, size_t stride, c
     hipLaunchKernelGGL(k_wedge_unpack_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, H, W, wmax, stride, ed, blocks, color, depth, occ);
 }
 
-void launch_shell_transmittance(int G, int rank, int N, const float* all_T, float* T_in, hipStream_t s) {
-    hipLaunchKernelGGL(k_shell_transmittance, dim3((N + 255) / 256), dim3(256), 0, s, G, rank, N, all_T, T_in);
+void launch_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, hipStream_t s) {
+    hipLaunchKernelGGL(k_shell_transmittance, dim3((N + 255) / 256), dim3(256), 0, s, G, rank, N, row_stride, all_T, T_in);
 }
 void launch_shell_compose(int G, int rank, int N, const float* planes, const float* bg, float* out_color, float* out_depth, float* out_occ,
                           float* T_final, float* behind, hipStream_t s) {

@@ -33,7 +33,10 @@ backward) so the collective logic above can be exercised on CPU with gloo (tests
 backend is HipShellBackend (C ABI: lidargs_shell_select / lidargs_forward_shell / lidargs_render_shell /
 lidargs_shell_compose / lidargs_backward_shell).
 """
+import contextlib
 import ctypes as C
+import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -176,6 +179,9 @@ def rebalance_shares(shares, times, damping=0.5, fixed=0.0):
     return (new / new.sum()).tolist()
 
 
+_NULL_CTX = contextlib.nullcontext()
+
+
 class HipShellBackend:
     """Per-rank compute on a HIP device through the C ABI (include/lidargs_rasterizer.h)."""
 
@@ -185,12 +191,71 @@ class HipShellBackend:
         self.lib = _C._lib
         for name in ("lidargs_wedge_select_count", "lidargs_forward_wedge", "lidargs_backward_wedge", "lidargs_wedge_pack_columns", "lidargs_wedge_unpack_columns",
                      "lidargs_wedge_unpack_grad_rows_add", "lidargs_shell_select", "lidargs_shell_select_count", "lidargs_shell_select_gather", "lidargs_shell_transmittance", "lidargs_shell_compose", "lidargs_shell_pack_grad_rows",
-                     "lidargs_shell_unpack_grad_rows", "lidargs_shell_chunk_counts", "lidargs_shell_scatter_radii"):
+                     "lidargs_shell_unpack_grad_rows", "lidargs_shell_chunk_counts", "lidargs_shell_scatter_radii", "lidargs_shell_select_enqueue",
+                     "lidargs_wedge_select_enqueue", "lidargs_forward_shell_enqueue", "lidargs_forward_wedge_enqueue"):
             getattr(self.lib, name).restype = C.c_int
         self.lib.lidargs_shell_select_scratch_bytes.restype = C.c_size_t
         self._scratch = {}          # persistent scratch of the selection (flags + offsets) per (device, P); never saved for a backward
+        self._tls = threading.local()
 
-    def select(self, inp, lo, hi):
+    fused_chunk_counts = True       # select(..., chunks=(rows, world, out)) leaves the all-to-all's split sizes in `out` (no launch of its own)
+
+    @contextlib.contextmanager
+    def frame(self, dev):
+        """One device switch and one stream lookup for everything a rank's forward (or backward) enqueues: the per-call
+        `torch.cuda.device` / `current_stream` pairs were a fifth of the host's time per frame."""
+        if dev.type != "cuda":
+            yield
+            return
+        with torch.cuda.device(dev):
+            self._tls.frame = (dev, self._C._stream(dev))
+            try:
+                yield
+            finally:
+                self._tls.frame = None
+
+    def _on(self, dev):
+        f = getattr(self._tls, "frame", None)
+        return _NULL_CTX if (f is not None and f[0] == dev) else torch.cuda.device(dev)
+
+    def _st(self, dev):
+        f = getattr(self._tls, "frame", None)
+        return f[1] if (f is not None and f[0] == dev) else self._C._stream(dev)
+
+    @staticmethod
+    def _chunk_args(chunks):
+        if chunks is None:
+            return C.c_int(0), C.c_int(0), None
+        rows, world, out = chunks
+        return C.c_int(int(rows)), C.c_int(int(world)), C.c_void_p(out.data_ptr())
+
+    def _select_enqueue(self, inp, plan, call, chunks=None):
+        """Enqueue-only selection into plan.rows rows (no host read): (idx [cap], capacity-row inputs + the device row count)."""
+        _C = self._C
+        m3 = inp["means3D"]
+        _C._require_device(m3, "means3D")
+        dev, P, cap = m3.device, int(m3.shape[0]), int(plan.rows)
+        key = (dev, P)
+        scr = self._scratch.get(key)
+        if scr is None:
+            nb = int(self.lib.lidargs_shell_select_scratch_bytes(C.c_int(P)))
+            scr = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
+            self._scratch = {key: scr}
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        sel = dict(inp)
+        sel.update(means3D=f(cap, 3), colors=f(cap, 2), opacities=f(cap, 1), scales=f(cap, 3), rotations=f(cap, 4),
+                   n_valid=torch.empty(2, dtype=torch.int32, device=dev))
+        p = _C._ptr
+        with self._on(dev):
+            rc = call(p, C.c_int(P), C.c_int(cap), p(idx), p(sel["means3D"]), p(sel["colors"]), p(sel["opacities"]), p(sel["scales"]),
+                      p(sel["rotations"]), p(sel["n_valid"]), C.c_void_p(plan.status.data_ptr() + 64), p(scr[0]), C.c_size_t(scr[1]),
+                      *self._chunk_args(chunks), self._st(dev))
+        if rc < 0:
+            _C._raise(rc, "select (enqueue-only)")
+        return idx, sel
+
+    def select(self, inp, lo, hi, plan=None, chunks=None):
         """Step 0: dense copies of the Gaussians with range in [lo, hi) + their indices (ascending).
 
         The M-row tensors are allocated PER CALL (caching allocator: no device malloc in steady state): a forward's selection
@@ -198,6 +263,10 @@ class HipShellBackend:
         an eval render) must not overwrite it.  Only the flags/offsets scratch, dead when this returns, is persistent."""
         _C, lib = self._C, self.lib
         m3 = inp["means3D"]
+        if plan is not None and int(m3.shape[0]):
+            return self._select_enqueue(inp, plan, lambda p, cP, ccap, *rest: lib.lidargs_shell_select_enqueue(
+                cP, p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), p(inp["rotations"]), p(inp["viewmatrix"]),
+                C.c_float(lo), C.c_float(hi), ccap, *rest), chunks)
         _C._require_device(m3, "means3D")
         dev, P = m3.device, int(m3.shape[0])
         key = (dev, P)
@@ -209,9 +278,9 @@ class HipShellBackend:
         p = _C._ptr
         M = 0
         if P:
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 M = lib.lidargs_shell_select_count(C.c_int(P), p(m3), p(inp["viewmatrix"]), C.c_float(lo), C.c_float(hi), p(scr[0]),
-                                                   C.c_size_t(scr[1]), _C._stream(dev))
+                                                   C.c_size_t(scr[1]), self._st(dev))
             if M < 0:
                 _C._raise(M, "lidargs_shell_select_count")
         f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
@@ -219,34 +288,44 @@ class HipShellBackend:
         sel = dict(inp)
         sel.update(means3D=f(M, 3), colors=f(M, 2), opacities=f(M, 1), scales=f(M, 3), rotations=f(M, 4))
         if M:
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 rc = lib.lidargs_shell_select_gather(C.c_int(P), p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]),
                                                      p(inp["rotations"]), p(idx), p(sel["means3D"]), p(sel["colors"]), p(sel["opacities"]),
-                                                     p(sel["scales"]), p(sel["rotations"]), p(scr[0]), C.c_size_t(scr[1]), _C._stream(dev))
+                                                     p(sel["scales"]), p(sel["rotations"]), p(scr[0]), C.c_size_t(scr[1]),
+                                                     *self._chunk_args(chunks), self._st(dev))
             if rc < 0:
                 _C._raise(rc, "lidargs_shell_select_gather")
+        elif chunks is not None:
+            chunks[2].zero_()
         return idx, sel
 
-    def forward(self, inp, lo, hi):
+    def forward(self, inp, lo, hi, plan=None, T_pass=None):
         _C, lib = self._C, self.lib
         m3 = inp["means3D"]
         dev, P, H, W = m3.device, int(m3.shape[0]), inp["H"], inp["W"]
         st = dict(inp=inp, P=P, geom=_C._Scratch(dev), binning=_C._Scratch(dev), img=_C._Scratch(dev))
         st["radii"] = torch.empty(P, dtype=torch.int32, device=dev)          # the library writes every row
         st["radii_xy"] = torch.empty(2 * P, dtype=torch.int32, device=dev)
-        T_pass = torch.ones(H * W, dtype=torch.float32, device=dev)
+        if T_pass is None:
+            T_pass = torch.empty(H * W, dtype=torch.float32, device=dev)
+        if not P:
+            T_pass.fill_(1.0)                                              # (with rows, the library writes every pixel)
         dummy = torch.empty(4 * H * W, dtype=torch.float32, device=dev)
         n = 0
         if P:
             p = _C._ptr
-            with torch.cuda.device(dev):
-                n = lib.lidargs_forward_shell(
-                    _C._alloc_cb, st["geom"].user, _C._alloc_cb, st["binning"].user, _C._alloc_cb, st["img"].user, C.c_int(P), None,
-                    C.c_int(W), C.c_int(H),
-                    p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), C.c_float(inp["scale_modifier"]),
-                    p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), C.c_int(inp["far"]), C.c_int(inp["near"]),
-                    C.c_float(lo), C.c_float(hi), None, C.c_int(1), p(dummy), p(dummy[2 * H * W:]), p(dummy[3 * H * W:]), p(T_pass),
-                    p(st["radii"]), p(st["radii_xy"]), C.c_int(0), _C._stream(dev))
+            common = (_C._alloc_cb, st["geom"].user, _C._alloc_cb, st["binning"].user, _C._alloc_cb, st["img"].user, C.c_int(P), None,
+                      C.c_int(W), C.c_int(H),
+                      p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), C.c_float(inp["scale_modifier"]),
+                      p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), C.c_int(inp["far"]), C.c_int(inp["near"]),
+                      C.c_float(lo), C.c_float(hi), None, C.c_int(1), p(dummy), p(dummy[2 * H * W:]), p(dummy[3 * H * W:]), p(T_pass),
+                      p(st["radii"]), p(st["radii_xy"]), C.c_int(0))
+            with self._on(dev):
+                if plan is None:
+                    n = lib.lidargs_forward_shell(*common, self._st(dev))
+                else:       # nothing is read back: capacities from the plan, the row count stays on the device
+                    n = lib.lidargs_forward_shell_enqueue(*common, p(inp.get("n_valid")), C.c_int(plan.instances), C.c_int(plan.tile_rows),
+                                                          C.c_void_p(plan.status.data_ptr()), self._st(dev))
             if n < 0:
                 _C._raise(n, "lidargs_forward_shell")
         for k in ("geom", "binning", "img"):       # keep only the tensors: nothing holds the registry entries alive
@@ -258,9 +337,12 @@ class HipShellBackend:
         """Step 2: T_in = product of the hand-over transmittances of the shells in front.  allT: [G, N]."""
         G, N = int(allT.shape[0]), int(allT.shape[1])
         T_in = torch.empty(N, dtype=torch.float32, device=allT.device)
-        with torch.cuda.device(allT.device):
-            rc = self.lib.lidargs_shell_transmittance(C.c_int(G), C.c_int(rank), C.c_int(N), self._C._ptr(allT.contiguous()), self._C._ptr(T_in),
-                                                      self._C._stream(allT.device))
+        if allT.stride(1) != 1 or (G > 1 and allT.stride(0) < N):
+            allT = allT.contiguous()
+        stride = int(allT.stride(0)) if G > 1 else N                       # (the gathered rows may carry the split sizes behind their N values)
+        with self._on(allT.device):
+            rc = self.lib.lidargs_shell_transmittance(C.c_int(G), C.c_int(rank), C.c_int(N), C.c_size_t(stride), C.c_void_p(allT.data_ptr()),
+                                                      self._C._ptr(T_in), self._st(allT.device))
         if rc < 0:
             self._C._raise(rc, "lidargs_shell_transmittance")
         return T_in
@@ -274,11 +356,11 @@ class HipShellBackend:
         planes = torch.empty(6 * N, dtype=torch.float32, device=dev)     # [C0, C1, D, T_end, T_hand, occ scratch]
         if st["P"]:
             p = _C._ptr
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 rc = lib.lidargs_render_shell(C.c_int(st["P"]), C.c_int(st["R"]), None, C.c_int(W), C.c_int(H), p(st["geom"]),
                                               p(st["binning"]), p(st["img"]), p(T_in.contiguous()), C.c_int(0), p(planes),
                                               p(planes[2 * N:]), p(planes[5 * N:]), p(planes[4 * N:]), p(planes[3 * N:]), C.c_int(0),
-                                              _C._stream(dev))
+                                              self._st(dev))
             if rc < 0:
                 _C._raise(rc, "lidargs_render_shell")
         else:
@@ -294,9 +376,9 @@ class HipShellBackend:
         out = torch.empty(8 * N, dtype=torch.float32, device=dev)
         color, depth, occ, T_final, behind = out[:2 * N], out[2 * N:3 * N], out[3 * N:4 * N], out[4 * N:5 * N], out[5 * N:]
         p = _C._ptr
-        with torch.cuda.device(dev):
+        with self._on(dev):
             rc = self.lib.lidargs_shell_compose(C.c_int(G), C.c_int(rank), C.c_int(N), p(planes.contiguous()), p(bg), p(color), p(depth), p(occ),
-                                                p(T_final), p(behind), _C._stream(dev))
+                                                p(T_final), p(behind), self._st(dev))
         if rc < 0:
             _C._raise(rc, "lidargs_shell_compose")
         return color.view(2, H, W), depth.view(1, H, W), occ.view(1, H, W), T_final, behind.view(3, N)
@@ -316,23 +398,27 @@ class HipShellBackend:
         if P:
             p = _C._ptr
             gc, gd, go = (g.contiguous() for g in grads)
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 rc = lib.lidargs_backward_shell(
                     C.c_int(P), C.c_int(st["R"]), p(inp["bg"]), C.c_int(W), C.c_int(H), p(inp["means3D"]), p(inp["colors"]), p(inp["scales"]),
                     C.c_float(inp["scale_modifier"]), p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), p(st["radii"]),
                     p(st["geom"]), p(st["binning"]), p(st["img"]), p(behind.contiguous()), p(T_final.contiguous()),
                     p(gc), p(gd), p(go), p(g_m2), p(g_con), p(g_op), p(g_col), p(g_dep), p(g_m3), p(g_sph), p(g_u1), p(g_u2), p(g_cov),
-                    p(g_sc), p(g_rot), C.c_int(0), _C._stream(dev))
+                    p(g_sc), p(g_rot), C.c_int(0), self._st(dev))
             if rc < 0:
                 _C._raise(rc, "lidargs_backward_shell")
         return dict(means3D=g_m3, means2D=g_m2, colors=g_col, opacities=g_op, scales=g_sc, rotations=g_rot)
 
 
     # ---- column wedges -------------------------------------------------------------------------------------------------
-    def select_wedge(self, inp, c0, c1):
+    def select_wedge(self, inp, c0, c1, plan=None, chunks=None):
         """Dense copies of the Gaussians whose rect can reach pixel columns [c0, c1) + their indices (ascending); M rows per call."""
         _C, lib = self._C, self.lib
         m3 = inp["means3D"]
+        if plan is not None and int(m3.shape[0]):
+            return self._select_enqueue(inp, plan, lambda p, cP, ccap, *rest: lib.lidargs_wedge_select_enqueue(
+                cP, p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), p(inp["rotations"]), C.c_float(inp["scale_modifier"]),
+                p(inp["viewmatrix"]), C.c_int(inp["W"]), C.c_int(c0), C.c_int(c1), ccap, *rest), chunks)
         _C._require_device(m3, "means3D")
         dev, P = m3.device, int(m3.shape[0])
         key = (dev, P)
@@ -344,10 +430,10 @@ class HipShellBackend:
         p = _C._ptr
         M = 0
         if P:
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 M = lib.lidargs_wedge_select_count(C.c_int(P), p(m3), p(inp["scales"]), p(inp["rotations"]), C.c_float(inp["scale_modifier"]),
                                                    p(inp["viewmatrix"]), C.c_int(inp["W"]), C.c_int(c0), C.c_int(c1), p(scr[0]), C.c_size_t(scr[1]),
-                                                   _C._stream(dev))
+                                                   self._st(dev))
             if M < 0:
                 _C._raise(M, "lidargs_wedge_select_count")
         f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
@@ -355,15 +441,18 @@ class HipShellBackend:
         sel = dict(inp)
         sel.update(means3D=f(M, 3), colors=f(M, 2), opacities=f(M, 1), scales=f(M, 3), rotations=f(M, 4))
         if M:
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 rc = lib.lidargs_shell_select_gather(C.c_int(P), p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]),
                                                      p(inp["rotations"]), p(idx), p(sel["means3D"]), p(sel["colors"]), p(sel["opacities"]),
-                                                     p(sel["scales"]), p(sel["rotations"]), p(scr[0]), C.c_size_t(scr[1]), _C._stream(dev))
+                                                     p(sel["scales"]), p(sel["rotations"]), p(scr[0]), C.c_size_t(scr[1]),
+                                                     *self._chunk_args(chunks), self._st(dev))
             if rc < 0:
                 _C._raise(rc, "lidargs_shell_select_gather")
+        elif chunks is not None:
+            chunks[2].zero_()
         return idx, sel
 
-    def forward_wedge(self, inp, c0, c1):
+    def forward_wedge(self, inp, c0, c1, plan=None):
         """lidargs_forward_wedge on the selected rows -> state for the backward, planes [4, H, W] (colour 0/1, depth, occupancy;
         only columns [c0, c1) are this rank's)."""
         _C, lib = self._C, self.lib
@@ -377,13 +466,16 @@ class HipShellBackend:
         if P:
             p = _C._ptr
             N = H * W
-            with torch.cuda.device(dev):
-                n = lib.lidargs_forward_wedge(
-                    _C._alloc_cb, st["geom"].user, _C._alloc_cb, st["binning"].user, _C._alloc_cb, st["img"].user, C.c_int(P), p(inp["bg"]),
-                    C.c_int(W), C.c_int(H), p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), C.c_float(inp["scale_modifier"]),
-                    p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), C.c_int(inp["far"]), C.c_int(inp["near"]),
-                    C.c_int(c0), C.c_int(c1), p(planes), p(planes[2 * N:]), p(planes[3 * N:]), p(st["radii"]), p(st["radii_xy"]), C.c_int(0),
-                    _C._stream(dev))
+            common = (_C._alloc_cb, st["geom"].user, _C._alloc_cb, st["binning"].user, _C._alloc_cb, st["img"].user, C.c_int(P), p(inp["bg"]),
+                      C.c_int(W), C.c_int(H), p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), C.c_float(inp["scale_modifier"]),
+                      p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), C.c_int(inp["far"]), C.c_int(inp["near"]),
+                      C.c_int(c0), C.c_int(c1), p(planes), p(planes[2 * N:]), p(planes[3 * N:]), p(st["radii"]), p(st["radii_xy"]), C.c_int(0))
+            with self._on(dev):
+                if plan is None:
+                    n = lib.lidargs_forward_wedge(*common, self._st(dev))
+                else:
+                    n = lib.lidargs_forward_wedge_enqueue(*common, p(inp.get("n_valid")), C.c_int(plan.instances), C.c_int(plan.tile_rows),
+                                                          C.c_void_p(plan.status.data_ptr()), self._st(dev))
             if n < 0:
                 _C._raise(n, "lidargs_forward_wedge")
         else:       # no Gaussian can reach the wedge: background only
@@ -410,12 +502,12 @@ class HipShellBackend:
         if P:
             p = _C._ptr
             gc, gd, go = (g.contiguous() for g in grads)
-            with torch.cuda.device(dev):
+            with self._on(dev):
                 rc = lib.lidargs_backward_wedge(
                     C.c_int(P), C.c_int(st["R"]), p(inp["bg"]), C.c_int(W), C.c_int(H), p(inp["means3D"]), p(inp["colors"]), p(inp["scales"]),
                     C.c_float(inp["scale_modifier"]), p(inp["rotations"]), None, p(inp["viewmatrix"]), p(inp["beams"]), p(st["radii"]),
                     p(st["geom"]), p(st["binning"]), p(st["img"]), C.c_int(st["cols"][0]), C.c_int(st["cols"][1]), p(gc), p(gd), p(go),
-                    p(g_m2), p(g_op), p(g_col), p(g_m3), p(g_cov), p(g_sc), p(g_rot), C.c_int(0), _C._stream(dev))
+                    p(g_m2), p(g_op), p(g_col), p(g_m3), p(g_cov), p(g_sc), p(g_rot), C.c_int(0), self._st(dev))
             if rc < 0:
                 _C._raise(rc, "lidargs_backward_wedge")
         return dict(means3D=g_m3, means2D=g_m2, colors=g_col, opacities=g_op, scales=g_sc, rotations=g_rot)
@@ -448,8 +540,8 @@ class HipShellBackend:
 
     # ---- step 6 helpers: one launch each instead of concatenates, casts and index copies -------------------------------
     def _call(self, name, dev, *args):
-        with torch.cuda.device(dev):
-            rc = getattr(self.lib, name)(*args, self._C._stream(dev))
+        with self._on(dev):
+            rc = getattr(self.lib, name)(*args, self._st(dev))
         if rc < 0:
             self._C._raise(rc, name)
 
@@ -484,6 +576,65 @@ class HipShellBackend:
 
 
 
+class _RankPlan:
+    """Caller-side state of ENQUEUE-ONLY rank frames (`module.enqueue_only`, or LIDARGS_ENQUEUE_ONLY=1): a rank's frame has two host
+    reads -- the number of selected rows, the number of list instances -- and each of them lets the device run dry while the host
+    catches up.  The first frame runs that way and teaches the plan both numbers; every later frame only enqueues work into
+    capacities with headroom (lidargs_*_select_enqueue, lidargs_forward_*_enqueue): the counts stay on the device and 18 status words
+    come back through pinned memory.  A frame that needed more than its capacities is found out by the backward of that frame (it
+    waits for the forward's status anyway, for the all-to-all's split sizes) or by the next forward: RuntimeError, capacities raised."""
+    HEADROOM = 1.25
+
+    def __init__(self):
+        self.rows = self.instances = 0
+        self.tile_rows = 4
+        self.status = None                # pinned int32[18]: [0..15] lidargs_forward_*_enqueue's words, [16] rows gathered, [17] rows selected
+        self.event, self.pending = None, False
+        self.frames = 0
+
+    def learn(self, rows, num_rendered):
+        need = int(num_rendered) & ~3
+        self.tile_rows = 4 << (int(num_rendered) & 3)
+        self.rows = max(self.rows, int(rows * self.HEADROOM) + 256)
+        self.instances = max(self.instances, (int(need * self.HEADROOM) + 4096 + 3) & ~3)
+
+    def next(self):
+        """The plan for an enqueue-only frame, or None while nothing has been learnt (an ordinary frame, which teaches it)."""
+        if not self.rows:
+            return None
+        self.check(wait=False)
+        if self.status is None:
+            self.status = torch.zeros(18, dtype=torch.int32).pin_memory()
+        return self
+
+    def submitted(self):
+        if self.event is None:
+            self.event = torch.cuda.Event()
+        self.event.record()
+        self.pending = True
+        self.frames += 1
+
+    def check(self, wait=True):
+        if not self.pending or (not wait and not self.event.query()):
+            return
+        self.event.synchronize()
+        self.pending = False
+        st = self.status.tolist()
+        need, over, selected = st[0], st[8], st[17]
+        rows_over = selected > self.rows
+        msg = None
+        if over:
+            msg = f"needed {need} list instances but its binning buffer held {st[9]}"
+        if rows_over:
+            msg = f"selected {selected} Gaussians but had room for {self.rows}"
+        if need * 1.08 > self.instances:
+            self.instances = (int(need * self.HEADROOM) + 4096 + 3) & ~3
+        if selected * 1.08 > self.rows:
+            self.rows = int(selected * self.HEADROOM) + 256
+        if msg:
+            raise RuntimeError(f"lidargs_dist: an enqueue-only rank frame {msg}; that frame's outputs are invalid (capacities raised, re-render it)")
+
+
 class _HostCounts:
     """The gradient all-to-all's split sizes [src, dst], on their way to the host: the device-to-host copy is queued on the stream (pinned
     memory) behind the collective that delivered them and an event is recorded; the host waits for the event only where it needs the
@@ -491,27 +642,26 @@ class _HostCounts:
     stream at the end of the forward (`.cpu()`: one full host / device serialisation per frame less)."""
 
     def __init__(self, counts):
-        c = counts.to(torch.int64)
-        if c.is_cuda:
-            self.host = torch.empty(c.shape, dtype=torch.int64, pin_memory=True)
-            self.host.copy_(c, non_blocking=True)
+        if counts.is_cuda:
+            self.host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)     # (as shipped: exact floats, converted on the host)
+            self.host.copy_(counts, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record()
         else:
-            self.host, self.event = c, None
+            self.host, self.event = counts, None
 
     def splits(self, rank):
         if self.event is not None:
             self.event.synchronize()
             self.event = None
-        return self.host[rank].tolist(), self.host[:, rank].tolist()
+        return [int(v) for v in self.host[rank].tolist()], [int(v) for v in self.host[:, rank].tolist()]
 
 
 def _chunk_rows(P, world):
     return (P + world - 1) // world
 
 
-def shell_forward(module, means3D, colors, opacities, scales, rotations):
+def _shell_forward(module, means3D, colors, opacities, scales, rotations):
     """Steps 0-4 of the module docstring.  Returns ((color, depth, occ, radii), saved-for-backward)."""
     rs, comm, be = module.raster_settings, module.comm, module.backend
     H, W = int(rs.image_height), int(rs.image_width)
@@ -532,23 +682,35 @@ def shell_forward(module, means3D, colors, opacities, scales, rotations):
             module.edges = edges               # static cut: convert once, no device read per frame
     lo, hi = edges[comm.rank], edges[comm.rank + 1]
 
-    idx, sel = be.select(inp, lo, hi)                                             # 0   [M], M-row inputs
+    plan = module.plan.next() if module.enqueue_only else None                    # None: an ordinary frame (two host reads)
     exchange = comm.world > 1 and module.grad_sync == "reduce_scatter"
-    tail = None
+    fused = getattr(be, "fused_chunk_counts", False)
+    tail = ship = None
     if exchange:
         # split sizes of the gradient all-to-all: the selection is index-sorted, so the rows bound for index chunk d are
         # contiguous.  They ride on the T_pass all-gather (exact as floats: < 2^24 rows per chunk) instead of a collective
         # of their own, and are read back at the end of the forward, off the backward's critical path.
         rows = _chunk_rows(P, comm.world)
         assert rows < (1 << 24)
-        tail = torch.empty(comm.world, dtype=torch.float32, device=dev)
-        be.chunk_counts(idx, rows, comm.world, tail)
+        ship = torch.empty(N + comm.world, dtype=torch.float32, device=dev)      # what the all-gather ships: T_pass, then the split sizes
+        tail = ship[N:]
+    if fused:       # (the selection's own gather launch leaves the split sizes in `tail`, the forward writes T_pass in place)
+        idx, sel = be.select(inp, lo, hi, plan, chunks=(rows, comm.world, tail) if exchange else None)   # 0   [M], M-row inputs
+    else:
+        idx, sel = be.select(inp, lo, hi)
+        if exchange:
+            be.chunk_counts(idx, rows, comm.world, tail)
     # `sel` already holds exactly this shell's rows: the shell test is NOT repeated inside the forward (two kernels need not
     # round the same range expression identically; a Gaussian one ulp from an edge could be selected here and culled there)
-    st, T_pass = be.forward(sel, float("-inf"), float("inf"))                     # 1
+    if fused:
+        st, T_pass = be.forward(sel, float("-inf"), float("inf"), plan, T_pass=None if ship is None else ship[:N])   # 1
+    else:
+        st, T_pass = be.forward(sel, float("-inf"), float("inf"))
+        if exchange:
+            ship[:N] = T_pass
     radii = be.scatter_radii(idx, st["radii"], P)
     wait_radii = comm.all_reduce_async(radii) if comm.world > 1 else (lambda: None)   # overlaps the rendering
-    allT = comm.all_gather(T_pass if tail is None else torch.cat([T_pass, tail]))  # 2   [G, N (+G)]
+    allT = comm.all_gather(T_pass if ship is None else ship)                       # 2   [G, N (+G)]
     counts = allT[:, N:] if exchange else None
     T_in = be.transmittance(allT[:, :N] if exchange else allT, comm.rank)
     planes = comm.all_gather(be.render(st, T_in))                                 # 3, 4   [G, 5, N]
@@ -556,11 +718,16 @@ def shell_forward(module, means3D, colors, opacities, scales, rotations):
     saved = dict(st=st, behind=behind, T_final=T_final, idx=idx, P=P)
     if exchange:
         saved.update(counts=_HostCounts(counts))                                  # [src, dst], read in the backward
+    if module.enqueue_only:
+        if plan is None:
+            module.plan.learn(int(idx.shape[0]), st["R"])
+        else:
+            module.plan.submitted()
     wait_radii()
     return (color, depth, occ, radii), saved
 
 
-def shell_backward(module, saved, g_color, g_depth, g_occ):
+def _shell_backward(module, saved, g_color, g_depth, g_occ):
     """Steps 5-6.  Returns {means3D, means2D, colors, opacities, scales, rotations} gradients, dense [P, w]."""
     st, idx, P = saved["st"], saved["idx"], saved["P"]
     comm, be = module.comm, module.backend
@@ -575,7 +742,8 @@ def shell_backward(module, saved, g_color, g_depth, g_occ):
     if sync == "reduce_scatter":
         # 6: the shell's rows go straight to their index-chunk owners; the row index travels as an 18th column (bit pattern)
         send, recv = saved["counts"].splits(comm.rank)
-        got = comm.all_to_all_rows(packed, send, recv)
+        module.plan.check()                        # (the forward's status words arrived with the split sizes)
+        got = comm.all_to_all_rows(packed[:sum(send)], send, recv)      # (an enqueue-only frame's rows are capacity-sized)
         dense = be.unpack_rows(got, P, blocked=True)
     else:
         dense = be.unpack_rows(packed, P, blocked=blocked)
@@ -598,6 +766,31 @@ def shell_backward(module, saved, g_color, g_depth, g_occ):
             out[k] = dense[:, o:o + w]
         o += w
     return out
+
+
+def _frame_of(be, dev):
+    f = getattr(be, "frame", None)
+    return f(dev) if f is not None else _NULL_CTX
+
+
+def shell_forward(module, means3D, colors, opacities, scales, rotations):
+    with _frame_of(module.backend, means3D.device):
+        return _shell_forward(module, means3D, colors, opacities, scales, rotations)
+
+
+def shell_backward(module, saved, g_color, g_depth, g_occ):
+    with _frame_of(module.backend, g_color.device):
+        return _shell_backward(module, saved, g_color, g_depth, g_occ)
+
+
+def wedge_forward(module, means3D, colors, opacities, scales, rotations):
+    with _frame_of(module.backend, means3D.device):
+        return _wedge_forward(module, means3D, colors, opacities, scales, rotations)
+
+
+def wedge_backward(module, saved, g_color, g_depth, g_occ):
+    with _frame_of(module.backend, g_color.device):
+        return _wedge_backward(module, saved, g_color, g_depth, g_occ)
 
 
 class _ShellRasterize(torch.autograd.Function):
@@ -627,6 +820,8 @@ class ShellRasterizer(nn.Module):
         self.backend = backend if backend is not None else HipShellBackend()
         self.grad_sync = grad_sync
         self.edges = edges
+        self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"     # see _RankPlan; off by default
+        self.plan = _RankPlan()
 
     def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations):
         return _ShellRasterize.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self)
@@ -683,7 +878,7 @@ def wedge_edges(means3D, viewmatrix, W, world, scales=None, shares=None):
     return edges
 
 
-def wedge_forward(module, means3D, colors, opacities, scales, rotations):
+def _wedge_forward(module, means3D, colors, opacities, scales, rotations):
     """Returns ((color, depth, occ, radii), saved-for-backward)."""
     rs, comm, be = module.raster_settings, module.comm, module.backend
     H, W = int(rs.image_height), int(rs.image_width)
@@ -700,14 +895,23 @@ def wedge_forward(module, means3D, colors, opacities, scales, rotations):
     c0, c1 = int(edges[comm.rank]), int(edges[comm.rank + 1])
     wmax = max(int(edges[g + 1]) - int(edges[g]) for g in range(comm.world))
 
-    idx, sel = be.select_wedge(inp, c0, c1)                                        # [M], M-row inputs
+    plan = module.plan.next() if module.enqueue_only else None
     exchange = comm.world > 1 and module.grad_sync == "reduce_scatter"
+    fused = getattr(be, "fused_chunk_counts", False)
     block = torch.empty(4 * H * wmax + (comm.world if exchange else 0), dtype=torch.float32, device=dev)
+    chunks = None
     if exchange:
         rows = _chunk_rows(P, comm.world)
         assert rows < (1 << 24)
-        be.chunk_counts(idx, rows, comm.world, block[4 * H * wmax:])               # the all-to-all's split sizes ride on the image gather
-    st, planes = be.forward_wedge(sel, c0, c1)
+        chunks = (rows, comm.world, block[4 * H * wmax:])                          # the all-to-all's split sizes ride on the image gather
+    if fused:
+        idx, sel = be.select_wedge(inp, c0, c1, plan, chunks=chunks)               # [M], M-row inputs
+        st, planes = be.forward_wedge(sel, c0, c1, plan)
+    else:
+        idx, sel = be.select_wedge(inp, c0, c1)
+        if exchange:
+            be.chunk_counts(idx, *chunks)
+        st, planes = be.forward_wedge(sel, c0, c1)
     radii = be.scatter_radii(idx, st["radii"], P)
     wait_radii = comm.all_reduce_max_async(radii) if comm.world > 1 else (lambda: None)   # a boundary Gaussian reports the same radius twice
     be.pack_columns(planes, H, W, c0, c1, wmax, block)
@@ -716,11 +920,16 @@ def wedge_forward(module, means3D, colors, opacities, scales, rotations):
     saved = dict(st=st, idx=idx, P=P)
     if exchange:
         saved.update(counts=_HostCounts(blocks[:, 4 * H * wmax:]))                 # [src, dst], read in the backward
+    if module.enqueue_only:
+        if plan is None:
+            module.plan.learn(int(idx.shape[0]), st["R"])
+        else:
+            module.plan.submitted()
     wait_radii()
     return (color, depth, occ, radii), saved
 
 
-def wedge_backward(module, saved, g_color, g_depth, g_occ):
+def _wedge_backward(module, saved, g_color, g_depth, g_occ):
     st, idx, P = saved["st"], saved["idx"], saved["P"]
     comm, be = module.comm, module.backend
     inp = st["inp"]
@@ -730,7 +939,8 @@ def wedge_backward(module, saved, g_color, g_depth, g_occ):
     packed = be.pack_rows(g, idx)
     if sync == "reduce_scatter":
         send, recv = saved["counts"].splits(comm.rank)
-        got = comm.all_to_all_rows(packed, send, recv)
+        module.plan.check()
+        got = comm.all_to_all_rows(packed[:sum(send)], send, recv)
         dense = be.unpack_rows_add(got, P)
     else:
         dense = be.unpack_rows_add(packed, P)
@@ -771,6 +981,8 @@ class WedgeRasterizer(nn.Module):
         self.backend = backend if backend is not None else HipShellBackend()
         self.grad_sync = grad_sync
         self.edges = edges
+        self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"     # see _RankPlan; off by default
+        self.plan = _RankPlan()
 
     def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations):
         return _WedgeRasterize.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self)

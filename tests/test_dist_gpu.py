@@ -88,7 +88,7 @@ class ThreadComm:
         return full[self.rank * rows:(self.rank + 1) * rows].clone()
 
 
-def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results, wedges=False, edges=None):
+def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results, wedges=False, edges=None, frames=1, enqueue=False):
     """Drives lidargs_dist.shell_forward / shell_backward (or the wedge pair) directly: torch's autograd engine executes all
     CUDA nodes on ONE worker thread per device, which would serialise (and deadlock) the virtual ranks."""
     comm = None
@@ -100,13 +100,16 @@ def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results, wedges=False
         gc, gd, go = (torch.from_numpy(g).cuda() for g in grads)
         if wedges:
             mod = lidargs_dist.WedgeRasterizer(make_settings(st, W, H), comm, grad_sync=grad_sync, edges=edges)
-            (color, depth, occ, radii), saved = lidargs_dist.wedge_forward(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
-            g = lidargs_dist.wedge_backward(mod, saved, gc, gd, go)
+            fwd, bwd = lidargs_dist.wedge_forward, lidargs_dist.wedge_backward
         else:
             mod = lidargs_dist.ShellRasterizer(make_settings(st, W, H), comm, grad_sync=grad_sync)
-            (color, depth, occ, radii), saved = lidargs_dist.shell_forward(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
-            g = lidargs_dist.shell_backward(mod, saved, gc, gd, go)
-        results[rank] = dict(color=color.cpu().numpy(), depth=depth.cpu().numpy(), occ=occ.cpu().numpy(), radii=radii.cpu().numpy(),
+            fwd, bwd = lidargs_dist.shell_forward, lidargs_dist.shell_backward
+        mod.enqueue_only = enqueue
+        for _ in range(frames):          # (enqueue-only: the first frame is an ordinary one and teaches the plan its capacities)
+            (color, depth, occ, radii), saved = fwd(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
+            g = bwd(mod, saved, gc, gd, go)
+        mod.plan.check()
+        results[rank] = dict(enqueue_only_frames=mod.plan.frames, color=color.cpu().numpy(), depth=depth.cpu().numpy(), occ=occ.cpu().numpy(), radii=radii.cpu().numpy(),
                              dL_dmeans3D=g["means3D"].cpu().numpy(), dL_dmeans2D=g["means2D"].cpu().numpy(),
                              dL_dcolors=g["colors"].cpu().numpy(), dL_dopacity=g["opacities"].cpu().numpy(),
                              dL_dscales=g["scales"].cpu().numpy(), dL_drotations=g["rotations"].cpu().numpy())
@@ -289,6 +292,39 @@ def test_shell_exchange_helpers_match_framework_ops(hip_lib_built):
         assert torch.equal(be.scatter_radii(idx, radii_shell, P), ref_radii)
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_selection_leaves_the_split_sizes_of_the_gradient_exchange(world, hip_lib_built):
+    """select(..., chunks=...): the all-to-all's split sizes come out of the selection's own gather launch (read off the scan), in
+    the ordinary and the enqueue-only form, shells and wedges -- equal to a bincount of the selected indices over the index chunks."""
+    import types
+    import lidargs_dist
+    be = lidargs_dist.HipShellBackend()
+    kind, P, H, W, seed = "street", 30011, 16, 512, 93
+    st = to_torch(sc.make_scene(kind, P, H, seed, random_view=True))
+    inp = dict(means3D=st["means3D"], colors=st["colors"], opacities=st["opacities"], scales=st["scales"], rotations=st["rotations"],
+               viewmatrix=st["viewmatrix"], W=W, H=H, scale_modifier=1.0)
+    chunk = lidargs_dist._chunk_rows(P, world)
+    for wedge in (False, True):
+        sel = (lambda plan, chunks: be.select_wedge(inp, 64, 256, plan, chunks=chunks)) if wedge else (lambda plan, chunks: be.select(inp, 12.0, 30.0, plan, chunks=chunks))
+        idx0, _ = sel(None, None)
+        M = int(idx0.shape[0])
+        assert 0 < M < P
+        ref = torch.bincount(idx0.long() // chunk, minlength=world).float()
+        counts = torch.full((world,), -1.0, device="cuda")
+        idx1, _ = sel(None, (chunk, world, counts))
+        assert torch.equal(idx1, idx0) and torch.equal(counts, ref)
+        plan = types.SimpleNamespace(rows=M + 100, status=torch.zeros(18, dtype=torch.int32).pin_memory())
+        counts.fill_(-1.0)
+        idx2, s2 = sel(plan, (chunk, world, counts))
+        torch.cuda.synchronize()
+        assert torch.equal(idx2[:M], idx0) and bool((idx2[M:] == 0x7F7F7F7F).all()) and torch.equal(counts, ref)
+        assert s2["n_valid"].tolist() == [M, M] and plan.status[16:].tolist() == [M, M]
+        plan.rows = M // 2                                                       # over capacity: clamped, and reported
+        idx3, s3 = sel(plan, (chunk, world, counts))
+        torch.cuda.synchronize()
+        assert torch.equal(idx3, idx0[:M // 2]) and s3["n_valid"].tolist() == [M // 2, M] and float(counts.sum()) == M // 2
+
+
 def test_cfg4_sharded_over_8_virtual_ranks_at_full_size(hip_lib_built):
     """BASELINE config 4 in its stated form, as far as one GPU allows: the 8 M-Gaussian 128 x 4096 scene sharded into 8 range
     shells, every shell driven through the product path (lidargs_shell_select -> forward phase 1 -> transmittance -> phase 2 ->
@@ -350,10 +386,10 @@ def test_cfg4_sharded_over_8_virtual_ranks_at_full_size(hip_lib_built):
 
 
 # ---- column wedges -------------------------------------------------------------------------------------------------------------
-def _virtual_ranks(world, scene, W, H, grads, grad_sync, wedges, edges=None, timeout=900):
+def _virtual_ranks(world, scene, W, H, grads, grad_sync, wedges, edges=None, timeout=900, frames=1, enqueue=False):
     shared = ThreadComm.Shared(world)
     results = [None] * world
-    threads = [threading.Thread(target=_run_rank, args=(shared, r, scene, W, H, grads, grad_sync, results, wedges, edges)) for r in range(world)]
+    threads = [threading.Thread(target=_run_rank, args=(shared, r, scene, W, H, grads, grad_sync, results, wedges, edges, frames, enqueue)) for r in range(world)]
     for t in threads: t.start()
     for t in threads: t.join(timeout=timeout)
     assert not any(t.is_alive() for t in threads), "virtual ranks hung"
@@ -429,6 +465,68 @@ def test_cfg4_column_wedges_over_8_virtual_ranks_at_full_size(hip_lib_built):
     full = _assemble(results, plain, P, world, grad_sync)
     for k in GRAD_KEYS_SR:
         parity(f"cfg4 wedges x8 {k} vs plain", full[k], plain[k])
+
+
+@pytest.mark.parametrize("wedges,grad_sync", [(False, "reduce_scatter"), (True, "reduce_scatter"), (False, "all_reduce")],
+                         ids=["shells", "wedges", "shells_all_reduce"])
+def test_enqueue_only_rank_frames_match_ordinary_ones(wedges, grad_sync, hip_lib_built):
+    """`module.enqueue_only`: after one ordinary frame a rank's frames read nothing back -- capacity-row selection with the count on the
+    device (lidargs_*_select_enqueue, k_preprocess' n_valid), capacity-sized binning (lidargs_forward_*_enqueue), the all-to-all's
+    split sizes and the status words through pinned memory.  Same radii; images and gradients equal to the ordinary frames' up to
+    the grouping of the partial sums (the segment plan follows the capacity), and within parity of the oracle."""
+    world, kind, P, H, W, seed = 4, "street", 60000, 32, 800, 91
+    scene = sc.make_scene(kind, P, H, seed, random_view=True)
+    scene["bg"] = np.array((0.2, 0.1), np.float32)
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    plain = _virtual_ranks(world, scene, W, H, grads, grad_sync, wedges)
+    res = _virtual_ranks(world, scene, W, H, grads, grad_sync, wedges, frames=3, enqueue=True)
+    for r in range(world):
+        assert res[r]["enqueue_only_frames"] == 2 and plain[r]["enqueue_only_frames"] == 0
+        assert np.array_equal(res[r]["radii"], plain[r]["radii"])
+        for k in ("color", "depth", "occ"):
+            parity(f"{k} rank {r} vs ordinary", res[r][k], plain[r][k], verbose=False)
+            parity(f"{k} rank {r}", res[r][k], ref[k], verbose=False)
+    full, full_plain = _assemble(res, ref, P, world, grad_sync), _assemble(plain, ref, P, world, grad_sync)
+    for k in GRAD_KEYS_SR:
+        parity(f"{k} vs ordinary", full[k], full_plain[k], verbose=False)
+        parity(k, full[k], ref[k])
+
+
+@pytest.mark.parametrize("wedges", [False, True], ids=["shells", "wedges"])
+@pytest.mark.parametrize("what", ["rows", "instances"])
+def test_enqueue_only_rank_frame_over_its_capacity_is_reported(wedges, what, hip_lib_built):
+    """A frame that selected more rows, or needed more list instances, than its capacities: nothing is written out of bounds, and
+    the plan raises (at the next look at its status words) and grows."""
+    import lidargs_dist
+    kind, P, H, W, seed = "street", 20000, 16, 512, 92
+    st = to_torch(sc.make_scene(kind, P, H, seed, random_view=True))
+    gc, gd, go = (torch.from_numpy(g).cuda() for g in sc.upstream_grads(H, W, seed))
+    mod = (lidargs_dist.WedgeRasterizer if wedges else lidargs_dist.ShellRasterizer)(make_settings(st, W, H))
+    mod.enqueue_only = True
+    fwd, bwd = (lidargs_dist.wedge_forward, lidargs_dist.wedge_backward) if wedges else (lidargs_dist.shell_forward, lidargs_dist.shell_backward)
+    args = (st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
+    out0, saved = fwd(mod, *args)                      # ordinary frame: teaches the plan
+    g0 = bwd(mod, saved, gc, gd, go)
+    rows, inst = mod.plan.rows, mod.plan.instances
+    assert rows > 0 and inst > 0
+    if what == "rows":
+        mod.plan.rows = 1000
+    else:
+        mod.plan.instances = 4096
+    out1, saved = fwd(mod, *args)
+    bwd(mod, saved, gc, gd, go)
+    with pytest.raises(RuntimeError, match="enqueue-only rank frame"):
+        mod.plan.check()
+    assert (mod.plan.rows if what == "rows" else mod.plan.instances) >= (rows if what == "rows" else inst) / 1.3      # grown back
+    out2, saved = fwd(mod, *args)                      # the next frame has room again
+    g2 = bwd(mod, saved, gc, gd, go)
+    mod.plan.check()
+    assert torch.equal(out2[3], out0[3])
+    for a, b in zip(out2[:3], out0[:3]):
+        parity("image after regrowth", a.cpu().numpy(), b.cpu().numpy(), verbose=False)
+    for k in g0:
+        parity(f"{k} after regrowth", g2[k].cpu().numpy(), g0[k].cpu().numpy(), verbose=False)
 
 
 def test_wedge_with_no_gaussian_in_reach(hip_lib_built):

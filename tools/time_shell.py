@@ -74,9 +74,9 @@ def frame(mod):
 
 
 def make_module(comm, edges):
-    if MODE == "wedge":
-        return lidargs_dist.WedgeRasterizer(settings, comm, edges=edges)
-    return lidargs_dist.ShellRasterizer(settings, comm, edges=edges)
+    mod = (lidargs_dist.WedgeRasterizer if MODE == "wedge" else lidargs_dist.ShellRasterizer)(settings, comm, edges=edges)
+    mod.enqueue_only = os.environ.get("ENQUEUE", "0") == "1"      # enqueue-only rank frames (no host read after the first frame)
+    return mod
 
 
 def measure(edges):
@@ -104,16 +104,28 @@ def measure(edges):
     assert not errs, errs
     torch.cuda.synchronize()
     walls, stages = [], []
-    for r in range(world):
+    only = os.environ.get("ONLY_RANK")                     # replay one rank only (for a kernel trace of its frame)
+    for r in (range(world) if only is None else [int(only)]):
         mod = make_module(ReplayComm(r, world, logs[r]), edges)
         for _ in range(3):
             frame(mod)
         torch.cuda.synchronize()
+        prof = None
+        if os.environ.get("CPROFILE"):                     # where the HOST's time goes inside the timed loop
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
         t0 = time.perf_counter()
         for _ in range(iters):
             frame(mod)
         torch.cuda.synchronize()
         walls.append(1e3 * (time.perf_counter() - t0) / iters)
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats("tottime").print_stats(28)
+        if os.environ.get("NOSTAGE"):
+            stages.append(0.0); del mod
+            continue
         _C.profile_enable(True)
         for _ in range(iters):
             frame(mod)
