@@ -682,9 +682,10 @@ def _shell_forward(module, means3D, colors, opacities, scales, rotations):
             module.edges = edges               # static cut: convert once, no device read per frame
     lo, hi = edges[comm.rank], edges[comm.rank + 1]
 
-    plan = module.plan.next() if module.enqueue_only else None                    # None: an ordinary frame (two host reads)
     exchange = comm.world > 1 and module.grad_sync == "reduce_scatter"
-    fused = getattr(be, "fused_chunk_counts", False)
+    fused = getattr(be, "fused_chunk_counts", False)                              # (the HIP backend; the framework-op backend of the CPU tests is not)
+    enqueue_only = module.enqueue_only and fused
+    plan = module.plan.next() if enqueue_only else None                           # None: an ordinary frame (two host reads)
     tail = ship = None
     if exchange:
         # split sizes of the gradient all-to-all: the selection is index-sorted, so the rows bound for index chunk d are
@@ -718,7 +719,7 @@ def _shell_forward(module, means3D, colors, opacities, scales, rotations):
     saved = dict(st=st, behind=behind, T_final=T_final, idx=idx, P=P)
     if exchange:
         saved.update(counts=_HostCounts(counts))                                  # [src, dst], read in the backward
-    if module.enqueue_only:
+    if enqueue_only:
         if plan is None:
             module.plan.learn(int(idx.shape[0]), st["R"])
         else:
@@ -895,9 +896,10 @@ def _wedge_forward(module, means3D, colors, opacities, scales, rotations):
     c0, c1 = int(edges[comm.rank]), int(edges[comm.rank + 1])
     wmax = max(int(edges[g + 1]) - int(edges[g]) for g in range(comm.world))
 
-    plan = module.plan.next() if module.enqueue_only else None
     exchange = comm.world > 1 and module.grad_sync == "reduce_scatter"
     fused = getattr(be, "fused_chunk_counts", False)
+    enqueue_only = module.enqueue_only and fused
+    plan = module.plan.next() if enqueue_only else None
     block = torch.empty(4 * H * wmax + (comm.world if exchange else 0), dtype=torch.float32, device=dev)
     chunks = None
     if exchange:
@@ -920,7 +922,7 @@ def _wedge_forward(module, means3D, colors, opacities, scales, rotations):
     saved = dict(st=st, idx=idx, P=P)
     if exchange:
         saved.update(counts=_HostCounts(blocks[:, 4 * H * wmax:]))                 # [src, dst], read in the backward
-    if module.enqueue_only:
+    if enqueue_only:
         if plan is None:
             module.plan.learn(int(idx.shape[0]), st["R"])
         else:
