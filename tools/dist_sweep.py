@@ -27,7 +27,9 @@ for seed in range(first, first + n):
     kind = "shell" if rng.random() < 0.5 else "street"
     beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
     sync = str(rng.choice(["all_reduce", "reduce_scatter"]))
-    desc = dict(seed=seed, cut="wedges" if wedges else "shells", world=world, kind=kind, P=P, H=H, W=W, beams=beams, grad_sync=sync)
+    enqueue = bool(rng.random() < 0.34)                                # enqueue-only rank frames: an ordinary frame, then two that read nothing back
+    desc = dict(seed=seed, cut="wedges" if wedges else "shells", world=world, kind=kind, P=P, H=H, W=W, beams=beams, grad_sync=sync,
+                enqueue_only=enqueue)
     n0 = len(util.PARITY_LOG)
     try:
         scene = sc.make_scene(kind, P, H, seed % 1000, random_view=True, beams=beams)
@@ -35,7 +37,7 @@ for seed in range(first, first + n):
         grads = sc.upstream_grads(H, W, seed % 1000)
         plain = hip_forward_backward(scene, W, H, grads)
         ref = oracle_forward_backward(scene, W, H, grads)
-        results = _virtual_ranks(world, scene, W, H, grads, sync, wedges)
+        results = _virtual_ranks(world, scene, W, H, grads, sync, wedges, frames=3 if enqueue else 1, enqueue=enqueue)
         ident = True
         for r in range(world):
             assert np.array_equal(results[r]["radii"], plain["radii"]), f"radii differ on rank {r}"
@@ -60,6 +62,7 @@ print(json.dumps({
     "what": "tools/dist_sweep.py: sharded frames on virtual ranks (threads on one GPU, in-memory collectives) vs the single-GPU HIP path and the oracle",
     "scenes": len(scenes), "seconds": round(time.time() - t0, 1), "first_seed": first,
     "by_cut": {c: sum(1 for s in scenes if s["cut"] == c) for c in ("shells", "wedges")},
+    "scenes_with_enqueue_only_rank_frames": sum(1 for s in scenes if s.get("enqueue_only")),
     "by_world": {str(w): sum(1 for s in scenes if s["world"] == w) for w in (2, 3, 4, 5, 8)},
     "narrow_images_W_below_40": sum(1 for s in scenes if s["W"] < 40),
     "wedge_scenes_bit_identical_to_single_gpu": sum(1 for s in scenes if s["cut"] == "wedges" and s.get("image_bit_identical_to_single_gpu")),
