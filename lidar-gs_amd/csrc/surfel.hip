@@ -307,16 +307,24 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
     const float3 n = sf3(r3.x, r3.y, r3.z);
     o.cos2 = sdot(px.p, n);
     const float safe = o.cos2 != 0.f ? o.cos2 : 1.f;
-    o.lam2 = r3.w / safe;                                              // ray / plane hit distance (:449-457)
+    // ray / plane hit distance (:449-457): one division per (pixel, surfel) pair of every walk.  The IEEE sequence is ten instructions;
+    // reciprocal + one residual correction is four and differs from it in the last bit only on a small fraction of operands
+    {
+        const float rc = __builtin_amdgcn_rcpf(safe);
+        const float q0 = r3.w * rc;
+        o.lam2 = __builtin_fmaf(__builtin_fmaf(-safe, q0, r3.w), rc, q0);
+    }
     o.dp = sf3(o.lam2 * px.p.x - r2.x, o.lam2 * px.p.y - r2.y, o.lam2 * px.p.z - r2.z);
     const sf2 sxy = o.dp.x * sf2{r0.x, r0.y} + o.dp.y * sf2{r0.z, r0.w} + o.dp.z * sf2{r1.x, r1.y};
     o.sx = sxy.x; o.sy = sxy.y;
-    const float rho3d = o.sx * o.sx + o.sy * o.sy;
+    // (the two squared distances as fused multiply-adds: a last-bit difference in a quantity that is compared and exponentiated, not
+    //  differenced -- three instructions less per pair in walks that are bound by the vector pipe)
+    const float rho3d = __builtin_fmaf(o.sx, o.sx, o.sy * o.sy);
     o.dxp = r4.x - (float)px.x; o.dyp = r4.y - (float)px.y;
-    const float rho2d = 2.0f * (40.f * o.dxp * o.dxp + 100.f * o.dyp * o.dyp);   // FilterInvSquare * (...), :469
+    const float rho2d = __builtin_fmaf(80.f * o.dxp, o.dxp, (200.f * o.dyp) * o.dyp);   // FilterInvSquare * (40 dx^2 + 100 dy^2), :469
     const bool front = o.lam2 > 0.f;
-    const float rho = front ? fminf(rho3d, rho2d) : rho2d;
     o.in3d = front && (rho3d <= rho2d);
+    const float rho = o.in3d ? rho3d : rho2d;                          // = front ? fminf(rho3d, rho2d) : rho2d, on the compare in3d needs anyway
     o.depth = o.in3d ? o.lam2 : r4.z;
     const float power = -0.5f * rho;
     const bool pass = gate && (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N) && !(power > 0.f);
