@@ -501,18 +501,24 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
                     } else {
                         const bool blend = hit != trip;
                         const float w = blend ? q.alpha * T : 0.f;
-                        const float m = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N / q.depth);
+                        // (this walk is bound by the vector pipe: the mapped depth's division as reciprocal + residual correction, like
+                        //  sf_pair's; m forced to 0 where nothing blends -- a depth of 0 would make it infinite --, after which every sum
+                        //  carries w = 0 there and needs no select of its own; the weighted sums as fused multiply-adds)
+                        const float rcd = __builtin_amdgcn_rcpf(q.depth), qd = SF_NEAR_N * rcd;
+                        const float nd = __builtin_fmaf(__builtin_fmaf(-q.depth, qd, SF_NEAR_N), rcd, qd);     // SF_NEAR_N / depth
+                        const float m_ = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - nd);
+                        const float m = blend ? m_ : 0.f;
                         // distortion with the segment-local prefix sums; the combine adds the terms in the sums of the segments
                         // in front (the expression is linear in them), R2/cr/forward.cu:497-499
-                        dist += blend ? (m * m * (1.f - T) + M2 - 2.f * m * M1) * w : 0.f;
-                        D += blend ? q.depth * w : 0.f;
-                        M1 += blend ? m * w : 0.f;
-                        M2 += blend ? m * m * w : 0.f;
+                        dist += (m * m * (1.f - T) + M2 - 2.f * m * M1) * w;
+                        D = __builtin_fmaf(q.depth, w, D);
+                        M1 = __builtin_fmaf(m, w, M1);
+                        M2 = __builtin_fmaf(m * m, w, M2);
                         const bool is_med = blend && T > 0.5f;                             // :503-507
                         med = is_med ? q.depth : med;
                         med_c = is_med ? (sr.x - tr.x + c * SF_CHUNK + (uint32_t)j + 1u) : med_c;
-                        N0 += r.r3.x * w; N1 += r.r3.y * w; N2 += r.r3.z * w;
-                        C0 += r.r1.w * w; C1 += r.r2.w * w;
+                        N0 = __builtin_fmaf(r.r3.x, w, N0); N1 = __builtin_fmaf(r.r3.y, w, N1); N2 = __builtin_fmaf(r.r3.z, w, N2);
+                        C0 = __builtin_fmaf(r.r1.w, w, C0); C1 = __builtin_fmaf(r.r2.w, w, C1);
                         T = blend ? test_T : T;
                         T_break = hit ? test_T : T_break;
                         last = blend ? (c * SF_CHUNK + (uint32_t)j + 1u) : last;
