@@ -808,26 +808,33 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             const float inv = __builtin_amdgcn_rcpf(1.f - alpha);       // 1 ulp; (1 - alpha) >= 0.01
             const float Tn = T * inv;
             const float w = alpha * Tn;
-            // recurrences of "what lies behind" (R2/cr/backward.cu:349-410)
-            const float a_c0 = last_alpha * l_c0 + (1.f - last_alpha) * acc_c0;
-            const float a_d = last_alpha * l_d + (1.f - last_alpha) * acc_d;
-            const float a_a = last_alpha + (1.f - last_alpha) * acc_a;
-            const float a_n0 = last_alpha * l_n0 + (1.f - last_alpha) * acc_n0;
-            const float a_n1 = last_alpha * l_n1 + (1.f - last_alpha) * acc_n1;
-            const float a_n2 = last_alpha * l_n2 + (1.f - last_alpha) * acc_n2;
-            float dL_dalpha = (r1.w - a_c0) * g0;                      // only channel 0 (:358-359)
+            // recurrences of "what lies behind" (R2/cr/backward.cu:349-410) and the sums over the channels: multiply-adds of terms of
+            // one sign or of differences taken first -- fused here (the launch is bound by the vector pipe; the file is built without
+            // contraction for the hit point's and the normal's cancelling expressions, which stay as written below)
+            float a_c0, a_d, a_a, a_n0, a_n1, a_n2, dL_dalpha, dL_dz;
             const float icd = __builtin_amdgcn_rcpf(c_d);
-            const float m_d = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N * icd);
-            const float dmd_dd = (SF_FAR_N * SF_NEAR_N) / (SF_FAR_N - SF_NEAR_N) * icd * icd;
-            float dL_dz = (contrib && e + 1u == med_c) ? g_med : 0.f;   // contributor == median_contributor - 1 (:371)
-            dL_dz += 2.0f * w * (m_d * final_A - final_D) * g_reg * dmd_dd;     // DETACH_WEIGHT: only the m_d path (:375-388)
-            dL_dalpha += (c_d - a_d) * g_depth + (1.f - a_a) * g_alpha;
-            dL_dalpha += (r3.x - a_n0) * gn0 + (r3.y - a_n1) * gn1 + (r3.z - a_n2) * gn2;
-            dL_dalpha *= Tn;
-            dL_dalpha -= T_final * inv * bgdot;
-            dL_dalpha = contrib ? dL_dalpha : 0.f;
+            {
+#pragma clang fp contract(fast)
+                const float keep = 1.f - last_alpha;
+                a_c0 = last_alpha * l_c0 + keep * acc_c0;
+                a_d = last_alpha * l_d + keep * acc_d;
+                a_a = last_alpha + keep * acc_a;
+                a_n0 = last_alpha * l_n0 + keep * acc_n0;
+                a_n1 = last_alpha * l_n1 + keep * acc_n1;
+                a_n2 = last_alpha * l_n2 + keep * acc_n2;
+                dL_dalpha = (r1.w - a_c0) * g0;                        // only channel 0 (:358-359)
+                const float m_d = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1.f - SF_NEAR_N * icd);
+                const float dmd_dd = (SF_FAR_N * SF_NEAR_N) / (SF_FAR_N - SF_NEAR_N) * icd * icd;
+                dL_dz = (contrib && e + 1u == med_c) ? g_med : 0.f;     // contributor == median_contributor - 1 (:371)
+                dL_dz += 2.0f * w * (m_d * final_A - final_D) * g_reg * dmd_dd;     // DETACH_WEIGHT: only the m_d path (:375-388)
+                dL_dalpha += (c_d - a_d) * g_depth + (1.f - a_a) * g_alpha;
+                dL_dalpha += (r3.x - a_n0) * gn0 + (r3.y - a_n1) * gn1 + (r3.z - a_n2) * gn2;
+                dL_dalpha *= Tn;
+                dL_dalpha -= T_final * inv * bgdot;
+                dL_dalpha = contrib ? dL_dalpha : 0.f;
+                dL_dz += w * g_depth;                                   // :420
+            }
             const float dL_dG = op * dL_dalpha;
-            dL_dz += w * g_depth;                                       // :420
             // 3-D branch: gradient through s = (dp.Tu', dp.Tv'), dp = lam2 p - Tw, lam2 = (Tw.n)/(p.n)   (:427-563); its three
             // roots are zeroed for a 2-D-branch pair, the 2-D branch's two for a 3-D one
             const bool in3d = q.in3d;
@@ -856,7 +863,7 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             for (int k = 0; k < 32; k++) v[k] = 0.f;
             v[SFA_COL0] = w * g0; v[SFA_COL1] = w * g1;
             v[SFA_OPA] = G * dL_dalpha;
-            v[SFA_N0] = w * gn0 + gN.x; v[SFA_N1] = w * gn1 + gN.y; v[SFA_N2] = w * gn2 + gN.z;
+            v[SFA_N0] = __builtin_fmaf(w, gn0, gN.x); v[SFA_N1] = __builtin_fmaf(w, gn1, gN.y); v[SFA_N2] = __builtin_fmaf(w, gn2, gN.z);
             v[SFA_TU0] = gTu.x; v[SFA_TU1] = gTu.y; v[SFA_TU2] = gTu.z;
             v[SFA_TV0] = gTv.x; v[SFA_TV1] = gTv.y; v[SFA_TV2] = gTv.z;
             v[SFA_TW0] = gTw.x; v[SFA_TW1] = gTw.y; v[SFA_TW2] = gTw.z;
