@@ -302,11 +302,14 @@ __device__ __forceinline__ SfStaged sf_gather(const uint32_t* __restrict__ point
 // exponent the same way -- exp(-inf) = 0 -- so that `ok` is ONE compare whose lane mask is the ballot itself.
 struct SfPair { bool ok, in3d; float sx, sy, dxp, dyp, lam2, cos2, depth, G, alpha; float3 dp; };
 
+// ALPHA_ONLY (the T-only walk, which uses nothing but ok / alpha): no finite stand-in for a zero cos2 -- the pair fails the cos2 test
+// whatever its other fields become.
+template <bool ALPHA_ONLY = false>
 __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, float op, bool gate) {
     SfPair o;
     const float3 n = sf3(r3.x, r3.y, r3.z);
     o.cos2 = sdot(px.p, n);
-    const float safe = o.cos2 != 0.f ? o.cos2 : 1.f;
+    const float safe = (ALPHA_ONLY || o.cos2 != 0.f) ? o.cos2 : 1.f;
     // ray / plane hit distance (:449-457): one division per (pixel, surfel) pair of every walk.  The IEEE sequence is ten instructions;
     // reciprocal + one residual correction is four and differs from it in the last bit only on a small fraction of operands
     {
@@ -327,7 +330,8 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
     const float rho = o.in3d ? rho3d : rho2d;                          // = front ? fminf(rho3d, rho2d) : rho2d, on the compare in3d needs anyway
     o.depth = o.in3d ? o.lam2 : r4.z;
     const float power = -0.5f * rho;
-    const bool pass = gate && (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N) && !(power > 0.f);
+    // (:483's `power > 0` skip cannot fire: rho is a sum of squares, and a NaN power is not > 0 either -- the test is dropped)
+    const bool pass = gate && (o.cos2 != 0.f) && !(o.depth < SF_NEAR_N);
     o.G = __expf(pass ? power : -INFINITY);
     o.alpha = fminf(0.99f, op * o.G);
     o.ok = o.alpha >= 1.0f / 255.0f;
@@ -379,7 +383,7 @@ __device__ __forceinline__ void sf_walk_T_only_v2(const int cnt, const float4* s
         return r;
     };
     auto factor = [&](const Rec& r, unsigned long long& hitmask) {
-        const SfPair q = sf_pair(px, r.r0, r.r1, r.r2, r.r3, r.r4, r.op, true);
+        const SfPair q = sf_pair<true>(px, r.r0, r.r1, r.r2, r.r3, r.r4, r.op, true);
         hitmask = __ballot(q.ok);
         return q.ok ? 1.f - q.alpha : 1.f;
     };
