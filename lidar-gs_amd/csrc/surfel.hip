@@ -318,7 +318,12 @@ __device__ __forceinline__ SfPair sf_pair(const SfPixel& px, float4 r0, float4 r
         o.lam2 = __builtin_fmaf(__builtin_fmaf(-safe, q0, r3.w), rc, q0);
     }
     o.dp = sf3(o.lam2 * px.p.x - r2.x, o.lam2 * px.p.y - r2.y, o.lam2 * px.p.z - r2.z);
-    const sf2 sxy = o.dp.x * sf2{r0.x, r0.y} + o.dp.y * sf2{r0.z, r0.w} + o.dp.z * sf2{r1.x, r1.y};
+    sf2 sxy;
+    {   // the hit point in the splat's frame: three products of like size per component, summed as fused multiply-adds (the offset dp
+        // itself, where three digits cancel, is formed above exactly as the reference writes it)
+#pragma clang fp contract(fast)
+        sxy = o.dp.x * sf2{r0.x, r0.y} + o.dp.y * sf2{r0.z, r0.w} + o.dp.z * sf2{r1.x, r1.y};
+    }
     o.sx = sxy.x; o.sy = sxy.y;
     // (the two squared distances as fused multiply-adds: a last-bit difference in a quantity that is compared and exponentiated, not
     //  differenced -- three instructions less per pair in walks that are bound by the vector pipe)
