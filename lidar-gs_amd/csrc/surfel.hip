@@ -849,16 +849,22 @@ __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
             const bool in3d = q.in3d;
             const float ga = in3d ? -dL_dG * G * q.sx : 0.f, gb = in3d ? -dL_dG * G * q.sy : 0.f;   // dL/ds
             const sf2 tx = sf2{r0.x, r0.y}, ty = sf2{r0.z, r0.w}, tz = sf2{r1.x, r1.y};   // (Tu', Tv') by component
-            const sf2 iuv = tx * tx + ty * ty + tz * tz;                  // (1/(Tu.Tu), 1/(Tv.Tv))
-            const sf2 gab = sf2{ga, gb}, s2 = 2.f * sf2{q.sx, q.sy};
-            // dL/dTu = ga (dp - 2 sx Tu)/(Tu.Tu) = ga (dp * iu - 2 sx Tu')
-            const sf2 gTx = gab * (q.dp.x * iuv - s2 * tx), gTy = gab * (q.dp.y * iuv - s2 * ty), gTz = gab * (q.dp.z * iuv - s2 * tz);
-            const float3 gTu = sf3(gTx.x, gTy.x, gTz.x), gTv = sf3(gTx.y, gTy.y, gTz.y);
-            const sf2 px2 = gab * tx, py2 = gab * ty, pz2 = gab * tz;
-            const float3 gdp = sf3(px2.x + px2.y, py2.x + py2.y, pz2.x + pz2.y);
-            const float g_lam = in3d ? sdot(gdp, px.p) + dL_dz : 0.f;
             const float icos = __builtin_amdgcn_rcpf(q.cos2 != 0.f ? q.cos2 : 1.f);
-            const float3 gTw = sf3(-gdp.x + g_lam * r3.x * icos, -gdp.y + g_lam * r3.y * icos, -gdp.z + g_lam * r3.z * icos);
+            float3 gTu, gTv, gdp, gTw;
+            float g_lam;
+            {   // (fused multiply-adds here too; the normal's gradient below stays as written)
+#pragma clang fp contract(fast)
+                const sf2 iuv = tx * tx + ty * ty + tz * tz;              // (1/(Tu.Tu), 1/(Tv.Tv))
+                const sf2 gab = sf2{ga, gb}, s2 = 2.f * sf2{q.sx, q.sy};
+                // dL/dTu = ga (dp - 2 sx Tu)/(Tu.Tu) = ga (dp * iu - 2 sx Tu')
+                const sf2 gTx = gab * (q.dp.x * iuv - s2 * tx), gTy = gab * (q.dp.y * iuv - s2 * ty), gTz = gab * (q.dp.z * iuv - s2 * tz);
+                gTu = sf3(gTx.x, gTy.x, gTz.x); gTv = sf3(gTx.y, gTy.y, gTz.y);
+                const sf2 px2 = gab * tx, py2 = gab * ty, pz2 = gab * tz;
+                gdp = sf3(px2.x + px2.y, py2.x + py2.y, pz2.x + pz2.y);
+                g_lam = in3d ? gdp.x * px.p.x + gdp.y * px.p.y + gdp.z * px.p.z + dL_dz : 0.f;
+                const float gl = g_lam * icos;
+                gTw = sf3(-gdp.x + gl * r3.x, -gdp.y + gl * r3.y, -gdp.z + gl * r3.z);
+            }
             // d lam2 / d n = (Tw (p.n) - (Tw.n) p) / (p.n)^2 = -dp / (p.n): evaluated as the reference writes it (:452-461), the
             // difference of two ~range-sized vectors, so that its rounding (3 digits of cancellation) is the reference's
             const float icos2 = icos * icos;
