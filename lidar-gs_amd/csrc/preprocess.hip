@@ -447,6 +447,7 @@ void launch_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, i
 // dL/dopacity, dL/dcolour.  dL/dsphere is NOT accumulated per pixel: by linearity it equals
 //   gx*u1' + gy*u2' (R3/cr/backward.cu:759-777 sums exactly these per-pixel terms).
 __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
+#pragma clang fp contract(fast)                                        // (see below, behind the early return)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0 && a.dirty) *a.dirty = 1u;                            // the packed lines now hold this backward's sums
     if (idx >= a.P) return;
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
                         vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
                         vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
     const float n2 = d.x * d.x + d.y * d.y + d.z * d.z;
-    const float dist = sqrtf(n2);
+    const float dist = __builtin_amdgcn_sqrtf(n2);
     if (!(a.radii[idx] > 0) || dist <= 0.f) {                         // R3/cr/backward.cu:479, :488: no gradient at all
         // every output row is written, so the caller need not pre-zero them (the reference relies on torch::zeros)
         for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; if (a.dL_dconic) a.dL_dconic[4 * idx + k] = 0.f; }
@@ -472,7 +473,14 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
         a.dL_dopacity[idx] = 0.f; if (a.dL_ddepths) a.dL_ddepths[idx] = 0.f;
         return;
     }
-    const float3 dir = f3(d.x / dist, d.y / dist, d.z / dist);
+    // Everything below is a gradient: held to 1e-4, not to the last bit, and this launch's length follows its instruction count (31 M
+    // vector instructions: 51 of its 78 us at the clock's nominal rate).  The file is built without contraction for K1's cancelling
+    // footprint expressions; here multiply-adds fuse (the one cancelling product difference, `denom`, is written with explicit rounding
+    // steps), the divisions are a reciprocal + one residual correction (four instructions for the IEEE sequence's ten), the square roots
+    // the hardware's.
+    auto frcp = [](float b) { const float r = __builtin_amdgcn_rcpf(b); return __builtin_fmaf(__builtin_fmaf(-b, r, 1.f), r, r); };
+    const float inv_dist = frcp(dist);
+    const float3 dir = f3(d.x * inv_dist, d.y * inv_dist, d.z * inv_dist);
     float3 u1, u2;
     tangent_basis(dir, u1, u2);
 
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float3 t1 = view_to_world(vm, u1), t2 = view_to_world(vm, u2);
     const float3 St1 = symmul(S, t1), St2 = symmul(S, t2);
     const float _a = dot3(t1, St1) + 0.01f, _b = dot3(t1, St2), _c = dot3(t2, St2) + 0.01f;
-    const float inv_d2 = 1.f / (dist * dist);
+    const float inv_d2 = frcp(dist * dist);
     const float ca = inv_d2 * _a, cb = inv_d2 * _b, cc = inv_d2 * _c;
 
     // unpack the blend kernel's packed sums into the caller's arrays (the reference accumulates
@@ -506,7 +514,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     float3 du1, du2;
     {
         const float w1 = dot3(u1, u1), w2 = dot3(u2, u2);
-        const float j1 = w1 > 0.f ? 1.f / w1 : 0.f, j2 = w2 > 0.f ? 1.f / w2 : 0.f;
+        const float j1 = w1 > 0.f ? frcp(w1) : 0.f, j2 = w2 > 0.f ? frcp(w2) : 0.f;
         const float3 G1 = f3(q2.z, q2.w, q3.x), G2 = f3(q3.y, q3.z, q3.w);
         const float3 p1 = scale3(u1, j1), p2 = scale3(u2, j2);
         const float c1 = 2.f * dot3(p1, G1), c2 = 2.f * dot3(p2, G2);
@@ -524,13 +532,13 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
 
     // conic -> covariance, with the reference's 1/(denom^2 + 1e-7) damping (R3/cr/backward.cu:237)
     const float denom = __fsub_rn(__fmul_rn(ca, cc), __fmul_rn(cb, cb));
-    const float k = 1.0f / ((denom * denom) + 0.0000001f);
+    const float k = frcp((denom * denom) + 0.0000001f);
     float da = k * (-cc * cc * gA + 2.f * cb * cc * gB + (denom - ca * cc) * gC);
     float dc = k * (-ca * ca * gC + 2.f * ca * cb * gB + (denom - ca * cc) * gA);
     float db = k * 2.f * (cb * cc * gA - (denom + 2.f * cb * cb) * gB + ca * cb * gC);
     // range dependence of the /dist^2 factor (:249-252)
     const float dist4 = n2 * n2;
-    const float wsum = -2.f * (da * _a + db * _b + dc * _c) / dist4;
+    const float wsum = -2.f * (da * _a + db * _b + dc * _c) * frcp(dist4);
     float3 g_mean = f3(wsum * d.x, wsum * d.y, wsum * d.z);
     da *= inv_d2; dc *= inv_d2; db *= inv_d2;                         // :254-256
 
@@ -553,23 +561,26 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
 
     // basis -> dir, with the reference's double epsilons (:336-354)
     const float rho2 = dir.x * dir.x + dir.y * dir.y;
-    const float i32 = (float)(1.0f / ((double)sqrtf(rho2 * rho2 * rho2) + 1e-9));
-    const float irho = (float)(1.0 / ((double)sqrtf(rho2) + 1e-9));
+    // (the reference's epsilons are doubles: the sum is formed in double, its reciprocal in float)
+    const float srho = __builtin_amdgcn_sqrtf(rho2);
+    const float i32 = frcp((float)((double)(srho * srho * srho) + 1e-9));
+    const float irho = frcp((float)((double)srho + 1e-9));
     float3 gdir;
     gdir.x = i32 * (-dir.y * dir.x * gu1.x - dir.y * dir.y * gu1.y + dir.z * dir.y * dir.y * gu2.x - dir.x * dir.y * dir.z * gu2.y) - dir.x * irho * gu2.z;
     gdir.y = i32 * (dir.x * dir.x * gu1.x + dir.x * dir.y * gu1.y - dir.x * dir.y * dir.z * gu2.x + dir.z * dir.x * dir.x * gu2.y) - dir.y * irho * gu2.z;
     gdir.z = irho * (dir.x * gu2.x + dir.y * gu2.y);
     // dir -> d : (|d|^2 I - d d^T) / (|d|^3 + 1e-9)  (:312-333)
-    const float id3e = (float)(1.0f / ((double)sqrtf(n2 * n2 * n2) + 1e-9));
+    const float d3 = dist * dist * dist;
+    const float id3e = frcp((float)((double)d3 + 1e-9));
     const float dg = dot3(d, gdir);
     g_mean = add3(g_mean, scale3(f3(n2 * gdir.x - d.x * dg, n2 * gdir.y - d.y * dg, n2 * gdir.z - d.z * dg), id3e));
 
     // K10: sphere-mean and range terms (R3/cr/backward.cu:490-522)
     const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
-    const float i1 = uu1 > 0.f ? 1.f / uu1 : 0.f, i2 = uu2 > 0.f ? 1.f / uu2 : 0.f;
+    const float i1 = uu1 > 0.f ? frcp(uu1) : 0.f, i2 = uu2 > 0.f ? frcp(uu2) : 0.f;
     const float3 gs = add3(scale3(u1, gx * i1), scale3(u2, gy * i2));
     if (a.dL_dsphere) { a.dL_dsphere[3 * idx] = gs.x; a.dL_dsphere[3 * idx + 1] = gs.y; a.dL_dsphere[3 * idx + 2] = gs.z; }
-    const float id3 = 1.0f / sqrtf(n2 * n2 * n2);
+    const float id3 = frcp(d3);
     const float dgs = dot3(d, gs);
     float3 v;
     v.x = g_mean.x + (n2 * gs.x - d.x * dgs) * id3 + gdep * dir.x;
