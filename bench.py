@@ -487,7 +487,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cfg5: {P} surfels ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, diff_lidargs_surfel_rasterization "
                                f"(2DGS laser-surfel variant), lidar_far=80 lidar_near=0, bg=0",
-                   "visible_surfels": V, "instances_binned": info.get("R", 0), "patch_instance_pairs_taken": int(cnt["taken_instances"]), "tile_rows": 4},
+                   "visible_surfels": V, "instances_binned": info.get("R", 0), "patch_instance_pairs_taken": int(cnt["taken_instances"]), "touched_surfels": int(cnt.get("touched", -1)), "tile_rows": 4},
         "roofline": roofline_object(table, "cfg5", pmc_names),
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
         "stage_events": f"HIP events on the op's stream, on every {STAGE_EVERY}th frame of the timed region",
@@ -1216,7 +1216,7 @@ def main():
             "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, {what}, "
                                    f"lidar_far=80 lidar_near=0, bg=0" + ("" if args.beams == "uniform" else f", beam table '{args.beams}' (non-uniform)"),
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
-                       "patch_instance_pairs_taken": cnt["taken_instances"], "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
+                       "patch_instance_pairs_taken": cnt["taken_instances"], "touched_gaussians": cnt.get("touched", -1), "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
                        "forward": ("HIP-graph replay of forward + backward (enqueue-only path captured once)" if args.graph else
                                    "enqueue-only (lidargs_forward_enqueue, no host wait)" if args.enqueue_only else "lidargs_forward (one 2-KB host read per frame)"),
                        "sharding": "single GPU" if world == 1 and not force_shells else

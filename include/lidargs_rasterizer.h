@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define LIDARGS_ABI_VERSION 1
+#define LIDARGS_ABI_VERSION 2 /* 2 (round 5): round 4 changed lidargs_shell_transmittance (row_stride), lidargs_shell_select_gather (chunk_rows, world, chunk_counts) and the chamfer scratch layout without a bump; a caller built against version 1 must be rebuilt */
 #define LIDARGS_NUM_CHANNELS 2 /* R3/cr/config.h:15 NUM_CHANNELS (intensity, ray-drop) */
 
 enum {
@@ -484,7 +484,8 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
  * [2]=instances binned by this library (num_rendered), [3]=R_ref = sum of the reference's
  * 16x1 tiles_touched (what SURVEY.md 8d's byte formula is written in), [4]=tile rows TH,
  * [5]=number of tiles, [6]=instances that at least one pixel of their patch took in pass 1 (-1 if the
- * T-only pass did not run), [7]=segments per list.  Values [1], [3], [6] are read back on demand. */
+ * T-only pass did not run), [7]=segments per list, [8]=Gaussians some pixel's walk took (the only ones with a gradient: the backward
+ * clears, adds to and reads the packed sums of these alone; -1 if unknown).  Values [1], [3], [6], [8] are read back on demand. */
 int lidargs_last_counters(long long* out, int n);
 
 /* Test hook (no reference counterpart as an entry point): the tile rect the two preprocess kernels give a Gaussian -- getRect_lidar,

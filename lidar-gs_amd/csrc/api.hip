@@ -28,6 +28,8 @@ thread_local char g_err[512] = "";
 thread_local long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 thread_local const uint8_t* g_last_flags = nullptr; thread_local size_t g_last_flags_R = 0, g_last_flags_stride = 0; thread_local int g_last_flags_planes = 0;
 thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals (geometry buffer)
+thread_local const uint8_t* g_last_touched = nullptr; thread_local size_t g_last_touched_P = 0;   // the last forward's touched marks (geometry buffer)
+thread_local long long g_touched_count = -1;
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -96,7 +98,7 @@ int choose_tile_rows(const unsigned long long (&inst)[4], int height) {
 //     num_rendered = Rp | code,   Rp = instance count rounded up to a multiple of 4,  tile height = 4 << code  (4, 8, 16, 32)
 // Rp sizes and carves the binning buffer on both sides (the list itself has `ranges`), so nothing is looked up by buffer
 // address and cloned / offloaded / checkpointed saved buffers work (the backward rebuilds its view from (P, R, W*H)).
-// Whether the packed gradient lines of the geometry buffer are still all-zero is a word IN that buffer (LG_TOTALS_DIRTY_WORD).
+// Which Gaussians have a gradient at all is a byte map IN the geometry buffer (GeomView::touched): every backward clears exactly their lines first.
 inline int encode_rendered(size_t R, int TH) { return (int)(((R + 3) & ~(size_t)3) | (size_t)(TH == 8 ? 1 : (TH == 16 ? 2 : (TH == 32 ? 3 : 0)))); }
 inline size_t rendered_capacity(int nr) { return (size_t)(nr & ~3); }
 inline int rendered_tile_rows(int nr) { return 4 << (nr & 3); }
@@ -263,7 +265,9 @@ void api_note_forward(long long P, long long R, int TH, int tiles, int S, const 
     g_counters[6] = flags ? -1 : 0; g_counters[7] = S;
     g_last_flags = flags; g_last_flags_R = (size_t)R; g_last_flags_stride = flags_stride; g_last_flags_planes = flags_planes;
     g_last_totals_dev = (uint32_t*)totals;
+    g_last_touched = nullptr; g_last_touched_P = 0; g_touched_count = -1;
 }
+void api_note_touched(const uint8_t* touched, size_t P) { g_last_touched = touched; g_last_touched_P = P; g_touched_count = -1; }
 int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }
 size_t api_rendered_capacity(int nr) { return rendered_capacity(nr); }
 int api_rendered_tile_rows(int nr) { return rendered_tile_rows(nr); }
@@ -520,10 +524,13 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     ra.seg = bin.seg; ra.S = S; ra.seg_len = plan.seg_len;
     ra.run_pass1 = (S > 1 || transmittance_pass || is_shell) ? 1 : 0;   // (a shell's backward always reads the flags)
     ra.flags = ra.run_pass1 ? bin.flags : nullptr; ra.R = Rp;
+    ra.touched = geom.touched;                                         // marked wherever a contribution flag is set (cleared by the preprocess)
     ra.transmittance_only = transmittance_pass;
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0; ra.alive = nullptr;
     int head = 0;                                                      // segments at the head of every list that round 1 walked completely
     const bool fused = plan.fused && !is_shell;                        // the plain frame (a range shell's two phases keep the launches)
+    // no flags (a one-segment plan: LIDARGS_MAX_SEGMENTS=1): pass 2 and the backward walk every listed entry, so every Gaussian may be added to
+    if (!fused && !ra.run_pass1 && R) lg::launch_touch_all(geom.touched, (size_t)P, stream);
     if (fused) {
         ra.flags = bin.flags; ra.alive = bin.alive;
         lg::launch_render_fused(ra, stream);
@@ -553,6 +560,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_counters[6] = -1; g_counters[7] = S;
     g_last_flags = ra.flags; g_last_flags_R = R; g_last_flags_stride = Rp; g_last_flags_planes = grid.waves_per_tile;
     g_last_totals_dev = geom.totals;             // R_ref / V are summed lazily in lidargs_last_counters (the diagnostic slots)
+    g_last_touched = geom.touched; g_last_touched_P = (size_t)P; g_touched_count = -1;
     return rendered;
 }
 
@@ -588,9 +596,12 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     lg::ImgView img; lg::img_carve(image_buffer, width, height, lg::make_grid(width, height, 4).num_tiles(), &img);
     g_prof.begin(stream, 1);
 
-    // The forward left the packed gradient lines zeroed; the first backward on these buffers marks them dirty (a word of the
-    // geometry buffer, set by k_gaussian_backward), and only a later one (retain_graph) finds the mark and clears them again.
-    lg::launch_zero_if_dirty(geom.totals + LG_TOTALS_DIRTY_WORD, geom.gacc, 16 * (size_t)P, stream);
+    // Only the Gaussians the forward marked as touched are ever added to, and every backward on these buffers (the first, or a later one
+    // under retain_graph) starts by clearing exactly their packed lines, listing them, and zeroing the caller's gradient rows.
+    lg::ZeroRows zr;
+    zr.add(dL_dmean2D, 4); zr.add(dL_dconic, 4); zr.add(dL_dopacity, 1); zr.add(dL_dcolor, 2); zr.add(dL_ddepths, 1); zr.add(dL_dmean3D, 3);
+    zr.add(dL_dsphere_means3D, 3); zr.add(dL_dbasis_u1, 3); zr.add(dL_dbasis_u2, 3); zr.add(dL_dcov3D, 6); zr.add(dL_dscale, 3); zr.add(dL_drot, 4);
+    lg::launch_zero_touched(geom.touched, reinterpret_cast<float4*>(geom.gacc), 4, (size_t)P, geom.tlist, geom.tcount, zr, stream);
     g_prof.mark("bwd_zero", stream);
 
     lg::RenderBwdArgs rb;
@@ -612,7 +623,7 @@ int backward_impl(int P, int R, const float* background, int width, int height, 
     gb.P = P; gb.scale_modifier = scale_modifier;
     gb.view = viewmatrix;
     gb.means3D = means3D; gb.scales = scales; gb.rotations = rotations; gb.cov3D_precomp = cov3D_precomp; gb.radii = radii;
-    gb.gacc = geom.gacc; gb.dirty = geom.totals + LG_TOTALS_DIRTY_WORD;
+    gb.gacc = geom.gacc; gb.tlist = geom.tlist; gb.tcount = geom.tcount;
     gb.dL_dmean2D = dL_dmean2D; gb.dL_dconic = dL_dconic; gb.dL_dopacity = dL_dopacity; gb.dL_dcolor = dL_dcolor;
     gb.dL_ddepths = dL_ddepths; gb.dL_dbasis_u1 = dL_dbasis_u1; gb.dL_dbasis_u2 = dL_dbasis_u2;
     gb.dL_dsphere = dL_dsphere_means3D; gb.dL_dmean3D = dL_dmean3D; gb.dL_dcov3D = dL_dcov3D; gb.dL_dscale = dL_dscale;
@@ -881,6 +892,7 @@ int lidargs_render_shell(int P, int R, const float* background, int width, int h
     ra.seg_lo = 0; ra.seg_hi = S; ra.front = 0;
     ra.alive = pass1_gated(plan, S) ? bin.alive : nullptr;        // written, like the flags, by the shell's phase 1
     ra.flags = bin.flags; ra.R = Rp;             // written by the shell's phase 1 (lidargs_forward_shell)
+    ra.touched = geom.touched;                   // (a repeated T-only pass sets the same marks again)
     ra.run_pass1 = transmittance_pass ? 1 : 0;   // phase 2 reuses the Tpass planes the shell's phase 1 left behind
     ra.transmittance_only = transmittance_pass;
     ra.T_end_out = transmittance_pass ? nullptr : T_end_out;          // the combine writes it beside final_T
@@ -990,8 +1002,18 @@ int lidargs_last_counters(long long* out, int n) {
         }
         free(h);
     }
+    if (g_touched_count < 0 && g_last_touched && g_last_touched_P) {
+        uint8_t* h = (uint8_t*)malloc(g_last_touched_P);
+        if (h && hipMemcpy(h, g_last_touched, g_last_touched_P, hipMemcpyDeviceToHost) == hipSuccess) {
+            long long c = 0;
+            for (size_t i = 0; i < g_last_touched_P; i++) c += h[i] != 0;
+            g_touched_count = c;
+        }
+        free(h);
+    }
     int k = 0;
     for (; k < n && k < 8; k++) out[k] = g_counters[k];
+    if (k < n) out[k++] = g_touched_count;                             // [8]
     return k;
 }
 

@@ -33,9 +33,9 @@ namespace lg {
 // (distance bits << 32 | index): distances are >= 0, so their bit patterns order like the values, and among equal distances the
 // lowest index wins -- exactly the reference's tie rule.
 __global__ void __launch_bounds__(CH_BLOCK) k_chamfer_nn(int n, int m, const float* __restrict__ a, const float* __restrict__ b,
-                                                         unsigned long long* __restrict__ keys, const uint32_t* __restrict__ need) {
+                                                         unsigned long long* __restrict__ keys, const uint32_t* __restrict__ need, uint32_t few) {
     __shared__ float s_b[CH_TILE * 3];
-    if (need && *need == 0u) return;                                   // the grid search settled every query of this direction
+    if (need && *need <= few) return;                                  // the grid search settled (nearly) every query of this direction: k_chamfer_nn_listed's turn, or nobody's
     const int batch = blockIdx.z;
     a += (size_t)batch * n * 3; b += (size_t)batch * m * 3; keys += (size_t)batch * n;
     const int q0 = (blockIdx.x * CH_BLOCK + threadIdx.x) * CH_Q;
@@ -74,14 +74,45 @@ __global__ void __launch_bounds__(CH_BLOCK) k_chamfer_nn(int n, int m, const flo
 }
 
 __global__ void __launch_bounds__(256) k_chamfer_unpack(size_t count, const unsigned long long* __restrict__ keys, float* __restrict__ dist, int* __restrict__ idx,
-                                                        const uint32_t* __restrict__ need) {
-    if (need && *need == 0u) return;
+                                                        const uint32_t* __restrict__ need, uint32_t few) {
+    if (need && *need <= few) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const unsigned long long k = keys[i];
     dist[i] = __uint_as_float((unsigned)(k >> 32)); idx[i] = (int)(unsigned)(k & 0xFFFFFFFFull);
 }
 
+
+// The few queries the grid search could not settle, one workgroup per listed query (block b takes items b, b + gridDim, ...): 256
+// threads stride over the targets with the reference's expression (each sees ascending indices, so the strict compare keeps the lowest
+// index of its share), the shares are merged by the minimum of (distance bits << 32 | index) -- the tie rule again.
+__global__ void __launch_bounds__(256) k_chamfer_nn_listed(int m, const float* __restrict__ a, const float* __restrict__ b, const uint32_t* __restrict__ count,
+                                                           uint32_t few, const uint32_t* __restrict__ list, float* __restrict__ dist, int* __restrict__ idx) {
+    __shared__ unsigned long long s_k[4];
+    const uint32_t cnt = *count;
+    if (cnt == 0u || cnt > few) return;
+    for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
+        const uint32_t q = list[it];
+        const float qx = a[3 * (size_t)q], qy = a[3 * (size_t)q + 1], qz = a[3 * (size_t)q + 2];
+        float best = __int_as_float(0x7f800000); int bi = 0;
+        for (int k = threadIdx.x; k < m; k += 256) {
+            const float dx = b[3 * (size_t)k] - qx, dy = b[3 * (size_t)k + 1] - qy, dz = b[3 * (size_t)k + 2] - qz;   // chamfer3D.cu:36-38
+            const float d = dx * dx + dy * dy + dz * dz;                                                               // :39
+            const bool better = d < best;
+            best = better ? d : best; bi = better ? k : bi;
+        }
+        unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other < key ? other : key; }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = key;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long k0 = s_k[0];
+            for (int w = 1; w < 4; w++) k0 = s_k[w] < k0 ? s_k[w] : k0;
+            dist[q] = __uint_as_float((unsigned)(k0 >> 32)); idx[q] = (int)(unsigned)(k0 & 0xFFFFFFFFull);
+        }
+    }
+}
 
 // ---- uniform-grid search ------------------------------------------------------------------------------------------------------------
 #define CH_RINGS 6                       // rings of cells a query may walk before it gives up (13^3 cells)
@@ -124,6 +155,9 @@ __global__ void k_ch_grid_desc(int m, uint32_t max_cells, const uint32_t* __rest
         if ((unsigned long long)d[0] * d[1] * d[2] <= (unsigned long long)max_cells && (float)d[0] * h >= ex[0] && (float)d[1] * h >= ex[1] && (float)d[2] * h >= ex[2]) break;
         h *= 1.26f;
     }
+    // (the loop always ends within its 40 steps for finite extents -- h grows 10^4-fold --; a non-finite bounding box, NaN or inf
+    //  coordinates, must still leave a grid the arrays were sized for: one cell, every query scans every target)
+    if (!((unsigned long long)d[0] * d[1] * d[2] <= (unsigned long long)max_cells) || !(h > 0.f) || !(h < 3.0e38f)) { d[0] = d[1] = d[2] = 1; h = fmaxf(emax, 1e-12f) * 1.01f; if (!(h < 3.0e38f)) h = 3.0e38f; }
     g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2]; g->h = h; g->inv_h = 1.f / h;
     g->eps = 2e-3f * h + 1e-6f * maxabs;                               // what the cell assignment's rounding can move a point by, with room
     g->dx = d[0]; g->dy = d[1]; g->dz = d[2]; g->cells = (uint32_t)d[0] * d[1] * d[2];
@@ -153,7 +187,7 @@ __global__ void __launch_bounds__(256) k_ch_fill(int m, const float* __restrict_
 // lies beyond one of the cube's faces that the grid does not clip: at least `bound` away along that axis.
 __global__ void __launch_bounds__(256) k_ch_query(int n, const float* __restrict__ a, const ChGrid* __restrict__ gp, const uint32_t* __restrict__ start,
                                                   const uint32_t* __restrict__ cnt, const float4* __restrict__ sorted, float* __restrict__ dist,
-                                                  int* __restrict__ idx, uint32_t* __restrict__ unsettled) {
+                                                  int* __restrict__ idx, uint32_t* __restrict__ unsettled, uint32_t* __restrict__ list) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ChGrid g = *gp;
@@ -194,7 +228,7 @@ __global__ void __launch_bounds__(256) k_ch_query(int n, const float* __restrict
         }
     }
     if (settled) { dist[i] = best; idx[i] = bi; }
-    else atomicOr(unsettled, 1u);
+    else list[atomicAdd(unsettled, 1u)] = (uint32_t)i;                 // (order: whatever -- every listed query is searched on its own)
 }
 
 // chamfer3D.cu:167-195: g = 2 grad_dist; +g (p - q) to the point, -g (p - q) to its neighbour (float atomics: many points share one)
@@ -220,13 +254,14 @@ __global__ void __launch_bounds__(256) k_chamfer_grad(int n, int m, const float*
 extern "C" {
 
 namespace {
-struct ChWork { unsigned long long* keys; uint32_t* box; lg::ChGrid* grid; uint32_t* flags; uint32_t* cnt; uint32_t* start; uint32_t* cursor; uint32_t* scan; float4* sorted; size_t cells; };
+struct ChWork { unsigned long long* keys; uint32_t* list; uint32_t* box; lg::ChGrid* grid; uint32_t* flags; uint32_t* cnt; uint32_t* start; uint32_t* cursor; uint32_t* scan; float4* sorted; size_t cells; };
 size_t ch_cells(int n, int m) { const size_t t = (size_t)(n > m ? n : m); return std::min<size_t>(CH_MAX_CELLS, std::max<size_t>(4096, 16 * t)); }
 size_t ch_carve(char* base, int n, int m, ChWork* w) {
     lg::Carver c(base);
     ChWork k;
     k.cells = ch_cells(n, m);
     k.keys = c.take<unsigned long long>((size_t)(n > m ? n : m) + 1);
+    k.list = c.take<uint32_t>((size_t)(n > m ? n : m) + 1);
     k.box = c.take<uint32_t>(8); k.grid = c.take<lg::ChGrid>(1); k.flags = c.take<uint32_t>(2);
     k.cnt = c.take<uint32_t>(k.cells); k.start = c.take<uint32_t>(k.cells); k.cursor = c.take<uint32_t>(k.cells);
     k.scan = c.take<uint32_t>(lg::scan_scratch_words(k.cells));
@@ -255,7 +290,8 @@ int lidargs_chamfer_forward(int B, int n, int m, const float* xyz1, const float*
     const int per = CH_BLOCK * CH_Q;
     hipError_t e = hipSuccess;
     auto direction = [&](int nq, const float* q, int nt, const float* t, float* dist, int* idx, uint32_t* flag) {
-        // grid search of the nq queries among the nt targets; *flag != 0 afterwards: some query was not settled
+        // grid search of the nq queries among the nt targets; *flag afterwards: the number of queries it did not settle (their indices in w.list)
+        const uint32_t few = (uint32_t)nq / 16u;
         if (!brute_only) {
             (void)hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * w.cells, stream);
             (void)hipMemsetAsync(w.cursor, 0, sizeof(uint32_t) * w.cells, stream);
@@ -263,12 +299,14 @@ int lidargs_chamfer_forward(int B, int n, int m, const float* xyz1, const float*
             hipLaunchKernelGGL(lg::k_ch_count, dim3((nt + 255) / 256), dim3(256), 0, stream, nt, t, w.grid, w.cnt);
             lg::launch_exclusive_scan(w.cnt, w.start, w.cells, nullptr, w.scan, stream);
             hipLaunchKernelGGL(lg::k_ch_fill, dim3((nt + 255) / 256), dim3(256), 0, stream, nt, t, w.grid, w.start, w.cursor, w.sorted);
-            hipLaunchKernelGGL(lg::k_ch_query, dim3((nq + 255) / 256), dim3(256), 0, stream, nq, q, w.grid, w.start, w.cnt, w.sorted, dist, idx, flag);
+            hipLaunchKernelGGL(lg::k_ch_query, dim3((nq + 255) / 256), dim3(256), 0, stream, nq, q, w.grid, w.start, w.cnt, w.sorted, dist, idx, flag, w.list);
+            // a few unsettled queries: each searched exhaustively on its own (leaves on one load when there are none, or too many)
+            hipLaunchKernelGGL(lg::k_chamfer_nn_listed, dim3((unsigned)std::min<uint32_t>(std::max<uint32_t>(few, 1u), 2048u)), dim3(256), 0, stream, nt, q, t, flag, few, w.list, dist, idx);
         }
-        // the brute force behind it: leaves on one load unless the flag is up (or it is all there is)
+        // the brute force behind it: leaves on one load unless more than `few` queries are unsettled (or it is all there is)
         (void)hipMemsetAsync(w.keys, 0xFF, sizeof(unsigned long long) * (size_t)nq, stream);
-        hipLaunchKernelGGL(lg::k_chamfer_nn, dim3((nq + per - 1) / per, CH_SPLIT, 1), dim3(CH_BLOCK), 0, stream, nq, nt, q, t, w.keys, brute_only ? nullptr : flag);
-        hipLaunchKernelGGL(lg::k_chamfer_unpack, dim3((unsigned)(((size_t)nq + 255) / 256)), dim3(256), 0, stream, (size_t)nq, w.keys, dist, idx, brute_only ? nullptr : flag);
+        hipLaunchKernelGGL(lg::k_chamfer_nn, dim3((nq + per - 1) / per, CH_SPLIT, 1), dim3(CH_BLOCK), 0, stream, nq, nt, q, t, w.keys, brute_only ? nullptr : flag, few);
+        hipLaunchKernelGGL(lg::k_chamfer_unpack, dim3((unsigned)(((size_t)nq + 255) / 256)), dim3(256), 0, stream, (size_t)nq, w.keys, dist, idx, brute_only ? nullptr : flag, few);
     };
     for (int b = 0; b < B; b++) {
         const float* a1 = xyz1 + (size_t)b * n * 3; const float* a2 = xyz2 + (size_t)b * m * 3;

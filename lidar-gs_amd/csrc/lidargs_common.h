@@ -43,6 +43,8 @@
 #define LG_SEG_LAST 6     // u32: entries of the segment consumed up to the last blended one
 #define LG_SEG_PLANES 7
 
+#define LG_REGION 256     // Gaussians per region of the backward's touched lists (k_zero_touched, k_gaussian_backward)
+
 namespace lg {
 
 struct Carver {
@@ -101,9 +103,7 @@ __device__ __forceinline__ uint2 span_unpack(uint32_t w) {            // -> (xsp
 // instance counts for tile heights 4 / 8 / 16 / 32), one 32-byte slot per group of preprocess blocks
 #define LG_INST_SLOTS 64
 #define LG_TOTALS_SLOT_WORD 8
-// word 4 of the totals: 0 while the packed gradient lines (gacc) are all-zero as the forward left them, 1 once a backward has
-// accumulated into them (k_gaussian_backward sets it; a further backward on the same buffers then clears the lines first)
-#define LG_TOTALS_DIRTY_WORD 4
+// (word 4 of the totals was rounds 2-4's "gradient lines dirty" mark: every backward now clears the touched Gaussians' lines itself)
 // behind the status words: LG_INST_SLOTS slots of (~smallest, largest) range key of the frame's visible Gaussians (atomicMax of the
 // preprocess blocks, spread over the slots like the instance totals; all start at 0, so an empty frame reads kmin = 0xFFFFFFFF,
 // kmax = 0).  The host folds them after its one read: the range sort then works on key - kmin and needs only as many passes as the
@@ -125,8 +125,12 @@ struct GeomView {
     uint32_t* key_a; uint32_t* key_b;   // range keys ping/pong
     uint32_t* id_a; uint32_t* id_b;     // Gaussian ids ping/pong (id_sorted ends in id_a)
     uint32_t* block_off;                // [scan_blocks(P)] exclusive instance offset of each block of SCAN_BLOCK range-consecutive Gaussians
-    uint32_t* totals;                   // [0]=#instances of the scan, [4]=gacc dirty flag, [8..] instance-total slots
+    uint32_t* totals;                   // [0]=#instances of the scan, [8..] instance-total slots
     float* gacc;                        // [16P] packed per-Gaussian gradient accumulators (backward)
+    uint8_t* touched;                   // [P] 1 = some pixel's walk took the Gaussian (the forward's contribution flags, a superset of what the
+                                        //     backward blends): only these have a gradient, and only their gacc lines are ever zeroed, added to or read
+    uint8_t* tlist; uint16_t* tcount;   // the backward's lists of them: per region of LG_REGION consecutive Gaussians, the touched ones' offsets
+                                        //     in the region (tlist[region * LG_REGION + j], j < tcount[region]); written by k_zero_touched
     uint32_t* scratch;                  // sort + scan scratch
     size_t scratch_words;
 };
@@ -143,6 +147,8 @@ inline size_t geom_carve(char* base, size_t P, GeomView* v) {
     g.block_off = c.take<uint32_t>(scan_blocks(P) + 64);
     g.totals = c.take<uint32_t>(LG_TOTALS_WORDS);
     g.gacc = c.take<float>(16 * P);
+    g.touched = c.take<uint8_t>(P + 64);
+    g.tlist = c.take<uint8_t>(P + LG_REGION); g.tcount = c.take<uint16_t>(P / LG_REGION + 64);
     g.scratch_words = sort_scratch_words(P, SORT_MAX_RADIX_BITS) + scan_scratch_words(P);
     g.scratch = c.take<uint32_t>(g.scratch_words);
     if (v) *v = g;
@@ -323,11 +329,18 @@ void api_prof_begin(hipStream_t s, int kind);
 void api_prof_mark(const char* name, hipStream_t s);
 void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans, const uint8_t* flags, size_t flags_stride,
                       int flags_planes);
+void api_note_touched(const uint8_t* touched, size_t P);              // (after api_note_forward) the frame's touched marks, for lidargs_last_counters
 int api_encode_rendered(size_t R, int TH);
 size_t api_rendered_capacity(int num_rendered);
 int api_rendered_tile_rows(int num_rendered);
-// clears `n` floats at `acc` if *dirty != 0 (device-side decision; a launch whose workgroups retire at once when it is clean)
-void launch_zero_if_dirty(const uint32_t* dirty, float* acc, size_t n, hipStream_t s);
+// First launch of a backward (preprocess.hip k_zero_touched): clears the packed gradient line (`line_f4` float4: 4 = 64 bytes, the 3-D
+// variant; 8 = 128 bytes, the surfel variant) of every Gaussian the forward marked as touched -- nobody reads or adds to the others' --,
+// lists the touched Gaussians per region (tlist / tcount of the geometry view) and zeroes every row of the caller's gradient arrays.
+struct ZeroRows { static constexpr int MAX = 12; float* p[MAX]; int w[MAX]; int n = 0;   // arrays of P rows of w floats (w = 1, 2, 3, 4, 6 or 9)
+                  void add(float* q, int width) { if (q && n < MAX) { p[n] = q; w[n] = width; n++; } } };
+void launch_zero_touched(const uint8_t* touched, float4* acc, int line_f4, size_t P, uint8_t* tlist, uint16_t* tcount, const ZeroRows& zr, hipStream_t s);
+// touched[i] = 1 for all P (frames whose forward writes no contribution flags: every listed entry is walked, so every visible Gaussian counts)
+void launch_touch_all(uint8_t* touched, size_t P, hipStream_t s);
 
 // kernels / launchers (defined in the .hip files)
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);
@@ -433,6 +446,7 @@ struct RenderFwdArgs {
     float* seg; int S;        // per-(patch, segment) planes, segment slots per list
     int seg_len;              // target entries per segment (a tile uses min(S, ceil(len / seg_len)) segments)
     uint8_t* flags; size_t R; // per-(sub, entry) contribution flags written by pass 1 (nullptr when pass 1 never runs)
+    uint8_t* touched = nullptr;   // [P]: set to 1 for the Gaussian of every entry whose flag is set (GeomView::touched); written only where flags are
     int seg_lo, seg_hi;       // segment slots [seg_lo, seg_hi) this launch covers
     int front;                // launch_render_alive: the segment the finished round ends at
     uint8_t* alive;           // [patches] (nullptr = no gating): number of segments pass 1 walked (255 = all of them)
@@ -470,8 +484,8 @@ void launch_render_backward(const RenderBwdArgs& a, hipStream_t s);
 struct GaussBwdArgs {
     int P; float scale_modifier; const float* view;   // device pointer
     const float* means3D; const float* scales; const float* rotations; const float* cov3D_precomp; const int* radii;
-    const float* gacc;             // packed sums from the backward blend
-    uint32_t* dirty;               // set to 1: gacc now holds sums (see LG_TOTALS_DIRTY_WORD)
+    const float* gacc;             // packed sums from the backward blend (lines of touched Gaussians only)
+    const uint8_t* tlist; const uint16_t* tcount;   // GeomView::tlist / tcount: the Gaussians with a gradient; the others' rows stay zero
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepths;
     float* dL_dbasis_u1; float* dL_dbasis_u2;
     float* dL_dsphere; float* dL_dmean3D; float* dL_dcov3D; float* dL_dscale; float* dL_drot;
@@ -480,6 +494,29 @@ void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s);
 
 // ---- device-side helpers shared by the blend kernels (render.hip, surfel.hip) ----------------------------------------
 #ifdef __HIPCC__
+// Whole-row stores and loads of the per-Gaussian arrays (rows of 2, 3, 4 floats at 4-byte alignment: the caller's tensors are carved
+// out of one slab): one dwordx2/x3/x4 instruction per row instead of one dword per element -- a wave's dword store of a [P, 4] column
+// touches the same sixteen 64-byte lines as the whole-row store does, for a quarter of the data.
+typedef float row4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float row3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float row2 __attribute__((ext_vector_type(2), aligned(4)));
+#if defined(LG_GB_VARIANT) && LG_GB_VARIANT == 5    /* experiment: rows are only stored when a value is NaN (never) */
+__device__ __forceinline__ void put4(float* p, size_t i, float x, float y, float z, float w) { if (x != x || w * 0.f != 0.f) *reinterpret_cast<row4*>(p + 4 * i) = row4{x, y, z, w}; }
+__device__ __forceinline__ void put3(float* p, size_t i, float x, float y, float z) { if (x != x || z * 0.f != 0.f) *reinterpret_cast<row3*>(p + 3 * i) = row3{x, y, z}; }
+__device__ __forceinline__ void put2(float* p, size_t i, float x, float y) { if (x != x || y * 0.f != 0.f) *reinterpret_cast<row2*>(p + 2 * i) = row2{x, y}; }
+#else
+__device__ __forceinline__ void put4(float* p, size_t i, float x, float y, float z, float w) { *reinterpret_cast<row4*>(p + 4 * i) = row4{x, y, z, w}; }
+__device__ __forceinline__ void put3(float* p, size_t i, float x, float y, float z) { *reinterpret_cast<row3*>(p + 3 * i) = row3{x, y, z}; }
+__device__ __forceinline__ void put2(float* p, size_t i, float x, float y) { *reinterpret_cast<row2*>(p + 2 * i) = row2{x, y}; }
+#endif
+#if defined(LG_GB_VARIANT) && LG_GB_VARIANT == 6    /* experiment: inputs made up from the index instead of loaded */
+__device__ __forceinline__ float3 get3(const float* p, size_t i) { const float f = 1.f + (float)(i & 1023) * 1e-3f; return make_float3(f, 0.5f * f, 0.25f + f); }
+__device__ __forceinline__ float4 get4(const float* p, size_t i) { const float f = 1.f + (float)(i & 1023) * 1e-3f; return make_float4(0.5f, 0.5f * f, 0.5f, 0.5f / f); }
+#else
+__device__ __forceinline__ float3 get3(const float* p, size_t i) { const row3 v = *reinterpret_cast<const row3*>(p + 3 * i); return make_float3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 get4(const float* p, size_t i) { const row4 v = *reinterpret_cast<const row4*>(p + 4 * i); return make_float4(v.x, v.y, v.z, v.w); }
+#endif
+
 // LDS reads that stay where they are written (see walk_flagged in render.hip)
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));

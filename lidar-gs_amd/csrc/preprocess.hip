@@ -108,7 +108,7 @@ struct PreKernelArgs {
     const float* colors; const float* cov3D_precomp; const float* beams;
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
-    float4* gacc;                       // [4P] packed gradient lines of the backward: zeroed here for every Gaussian with radii > 0
+    uint8_t* touched;                   // [P] "some pixel took this Gaussian" marks of the blend (GeomView::touched): cleared here
     unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: instance counts for tile heights 4, 8, 16, 32 (zeroed by the caller)
     unsigned long long* diag_slots;     // [LG_INST_SLOTS][2]: visible Gaussians, reference tiles_touched (diagnostics)
     uint32_t* key_span;                 // [LG_INST_SLOTS][2]: ~(smallest), largest range key of the visible Gaussians (zeroed by the caller)
@@ -368,23 +368,12 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
             }
         }
     }
-    // The backward blend adds into the packed 64-byte gradient line of a Gaussian: the lines are zeroed here, where the kernel has
-    // memory bandwidth to spare, instead of by a 64 B x P fill launch per frame (9 % of the forward at 2 M Gaussians).  The wave
-    // writes the 4 KB of its 64 Gaussians as four contiguous 1-KB stores (per-Gaussian stores would touch every line four times).
-    {
-        const int lane = threadIdx.x & 63, wbase = idx - lane;
-        if (wbase < pp.P) {
-            float4* z = a.gacc + 4 * (size_t)wbase;
-            const size_t room = 4 * (size_t)(pp.P - wbase);
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const size_t o = (size_t)k * 64 + lane;
-                if (o < room) z[o] = zero;
-            }
-        }
-    }
+    // The backward blend adds into the packed 64-byte gradient line of a Gaussian.  Rounds 2-4 zeroed all P lines here (64 B x P: 128 of
+    // this launch's 420 MB at 2 M Gaussians).  Only the Gaussians some pixel's walk takes -- a third of the visible ones on the street
+    // frames -- are ever added to: the blend marks them (one byte each, cleared here), and the backward's first launch clears exactly
+    // their lines (k_zero_touched).
     if (!in_range) return;
+    a.touched[idx] = 0;
     a.dkey[idx] = key;
     // an empty column span = no instances, whatever the row span holds
     if (pp.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(rspan, tiles ? xsp : 0u);
@@ -405,7 +394,7 @@ void launch_preprocess(const PreprocessParams& pp, const float* means3D, const f
     a.cov3D_precomp = cov3D_precomp; a.beams = beams; a.radii = radii; a.radii_xy = radii_xy;
     a.coltab = tables ? tables->coltab : nullptr; a.rowtab = tables ? tables->rowtab : nullptr;
     a.rec = g.rec; a.rowspan = g.rowspan; a.spans = g.spans; a.dkey = g.key_a; a.ids = g.id_a;
-    a.gacc = reinterpret_cast<float4*>(g.gacc);
+    a.touched = g.touched;
     a.inst_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_SLOT_WORD);
     a.diag_slots = reinterpret_cast<unsigned long long*>(g.totals + LG_TOTALS_DIAG_WORD);
     a.key_span = g.totals + LG_TOTALS_KEYSPAN_WORD;
@@ -446,33 +435,38 @@ void launch_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, i
 // Gaussian): dL/dconic (A,B,C), the moments G1, G2 of dL/du1, dL/du2 (direct part), (gx,gy) = dL/dmean2D.xy, dL/drange,
 // dL/dopacity, dL/dcolour.  dL/dsphere is NOT accumulated per pixel: by linearity it equals
 //   gx*u1' + gy*u2' (R3/cr/backward.cu:759-777 sums exactly these per-pixel terms).
-__global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
+//
+// Sparse (round 5).  A gradient exists only for the Gaussians the blend marked as touched -- on the street frames a fifth of the visible
+// ones (0.33 of 1.73 M); everybody else's rows are zero (K9 / K10 are linear in the sums, R3/cr/backward.cu:453-532; the reference gets
+// the same zeros from torch::zeros, R3/rasterize_points.cu:163-175).  The backward's first launch (k_zero_touched below) zeroes all
+// rows and lists the touched Gaussians region by region; k_gaussian_backward runs the chain on the listed ones only and overwrites
+// their rows.  An untouched Gaussian costs its mark and 68 bytes of zeros: no inputs, no radius, no 64-byte line.
+// the chain of one touched Gaussian
+__device__ __forceinline__ void gb_row(const GaussBwdArgs& a, const int idx) {
 #pragma clang fp contract(fast)                                        // (see below, behind the early return)
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0 && a.dirty) *a.dirty = 1u;                            // the packed lines now hold this backward's sums
-    if (idx >= a.P) return;
     const float* vm = a.view;
 
-    const float3 pw = f3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    // every input of the row is requested here, together (one round trip for the wave instead of three: the loads behind the early
+    // return and behind the covariance were issued where they stand in the text)
+    const float3 pw = get3(a.means3D, idx);
+    const float4* acc = reinterpret_cast<const float4*>(a.gacc) + 4 * (size_t)idx;
+#if defined(LG_GB_VARIANT) && LG_GB_VARIANT == 7    /* experiment: no packed-line loads */
+    const float ff = (float)(idx & 255);
+    const float4 q0 = make_float4(ff, 1.f, 2.f, ff), q1 = q0, q2 = q0, q3 = q0;
+#else
+    const float4 q0 = acc[0], q1 = acc[1], q2 = acc[2], q3 = acc[3];
+#endif
+    const bool have_sr = (a.cov3D_precomp == nullptr);
+    float3 s_in = f3(0, 0, 0); float4 q = make_float4(1, 0, 0, 0);
+    float3 cv0 = f3(0, 0, 0), cv1 = f3(0, 0, 0);
+    if (have_sr || a.scales) { s_in = get3(a.scales, idx); q = get4(a.rotations, idx); }
+    if (!have_sr) { cv0 = get3(a.cov3D_precomp, 2 * (size_t)idx); cv1 = get3(a.cov3D_precomp, 2 * (size_t)idx + 1); }
     const float3 d = f3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12],
                         vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
                         vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
     const float n2 = d.x * d.x + d.y * d.y + d.z * d.z;
     const float dist = __builtin_amdgcn_sqrtf(n2);
-    if (!(a.radii[idx] > 0) || dist <= 0.f) {                         // R3/cr/backward.cu:479, :488: no gradient at all
-        // every output row is written, so the caller need not pre-zero them (the reference relies on torch::zeros)
-        for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; if (a.dL_dconic) a.dL_dconic[4 * idx + k] = 0.f; }
-        for (int k = 0; k < 3; k++) {
-            a.dL_dmean3D[3 * idx + k] = 0.f; a.dL_dscale[3 * idx + k] = 0.f;
-            if (a.dL_dsphere) a.dL_dsphere[3 * idx + k] = 0.f;
-            if (a.dL_dbasis_u1) a.dL_dbasis_u1[3 * idx + k] = 0.f;
-            if (a.dL_dbasis_u2) a.dL_dbasis_u2[3 * idx + k] = 0.f;
-        }
-        if (a.dL_dcov3D) for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * idx + k] = 0.f;
-        a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f;
-        a.dL_dopacity[idx] = 0.f; if (a.dL_ddepths) a.dL_ddepths[idx] = 0.f;
-        return;
-    }
+    if (dist <= 0.f) return;                                           // R3/cr/backward.cu:488 (the rows are zero already)
     // Everything below is a gradient: held to 1e-4, not to the last bit, and this launch's length follows its instruction count (31 M
     // vector instructions: 51 of its 78 us at the clock's nominal rate).  The file is built without contraction for K1's cancelling
     // footprint expressions; here multiply-adds fuse (the one cancelling product difference, `denom`, is written with explicit rounding
@@ -485,17 +479,9 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     tangent_basis(dir, u1, u2);
 
     Sym3 S;
-    float3 sc = f3(0, 0, 0); float4 q = make_float4(1, 0, 0, 0);
-    const bool have_sr = (a.cov3D_precomp == nullptr);
-    if (!have_sr) {
-        const float* c = a.cov3D_precomp + 6 * (size_t)idx;
-        S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
-    } else {
-        const float m = a.scale_modifier;
-        sc = f3(m * a.scales[3 * idx], m * a.scales[3 * idx + 1], m * a.scales[3 * idx + 2]);
-        q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
-        S = covariance_world(sc, q);
-    }
+    const float3 sc = f3(a.scale_modifier * s_in.x, a.scale_modifier * s_in.y, a.scale_modifier * s_in.z);
+    if (!have_sr) { S.xx = cv0.x; S.xy = cv0.y; S.xz = cv0.z; S.yy = cv1.x; S.yz = cv1.y; S.zz = cv1.z; }
+    else S = covariance_world(sc, q);
     const float3 t1 = view_to_world(vm, u1), t2 = view_to_world(vm, u2);
     const float3 St1 = symmul(S, t1), St2 = symmul(S, t2);
     const float _a = dot3(t1, St1) + 0.01f, _b = dot3(t1, St2), _c = dot3(t2, St2) + 0.01f;
@@ -504,8 +490,6 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
 
     // unpack the blend kernel's packed sums into the caller's arrays (the reference accumulates
     // straight into them with atomics, R3/cr/backward.cu:702-788)
-    const float4* acc = reinterpret_cast<const float4*>(a.gacc) + 4 * (size_t)idx;
-    const float4 q0 = acc[0], q1 = acc[1], q2 = acc[2], q3 = acc[3];
     const float gx = q0.x, gy = q0.y;
     const float gA = q0.w, gB = q1.x, gC = q1.y;
     const float gdep = q2.y;
@@ -521,14 +505,14 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
         du1 = f3(j1 * G1.x - c1 * p1.x, j1 * G1.y - c1 * p1.y, j1 * G1.z - c1 * p1.z);
         du2 = f3(j2 * G2.x - c2 * p2.x, j2 * G2.y - c2 * p2.y, j2 * G2.z - c2 * p2.z);
     }
-    a.dL_dmean2D[4 * idx] = gx; a.dL_dmean2D[4 * idx + 1] = gy; a.dL_dmean2D[4 * idx + 2] = q0.z; a.dL_dmean2D[4 * idx + 3] = 0.f;
+    put4(a.dL_dmean2D, idx, gx, gy, q0.z, 0.f);
     // the reference's scratch gradients (conic, depth, sphere, basis) are materialised only if the caller wants them
-    if (a.dL_dconic) { a.dL_dconic[4 * idx] = gA; a.dL_dconic[4 * idx + 1] = gB; a.dL_dconic[4 * idx + 2] = 0.f; a.dL_dconic[4 * idx + 3] = gC; }
+    if (a.dL_dconic) put4(a.dL_dconic, idx, gA, gB, 0.f, gC);
     a.dL_dopacity[idx] = q1.z;
-    a.dL_dcolor[2 * idx] = q1.w; a.dL_dcolor[2 * idx + 1] = q2.x;
+    put2(a.dL_dcolor, idx, q1.w, q2.x);
     if (a.dL_ddepths) a.dL_ddepths[idx] = gdep;
-    if (a.dL_dbasis_u1) { a.dL_dbasis_u1[3 * idx] = du1.x; a.dL_dbasis_u1[3 * idx + 1] = du1.y; a.dL_dbasis_u1[3 * idx + 2] = du1.z; }
-    if (a.dL_dbasis_u2) { a.dL_dbasis_u2[3 * idx] = du2.x; a.dL_dbasis_u2[3 * idx + 1] = du2.y; a.dL_dbasis_u2[3 * idx + 2] = du2.z; }
+    if (a.dL_dbasis_u1) put3(a.dL_dbasis_u1, idx, du1.x, du1.y, du1.z);
+    if (a.dL_dbasis_u2) put3(a.dL_dbasis_u2, idx, du2.x, du2.y, du2.z);
 
     // conic -> covariance, with the reference's 1/(denom^2 + 1e-7) damping (R3/cr/backward.cu:237)
     const float denom = __fsub_rn(__fmul_rn(ca, cc), __fmul_rn(cb, cb));
@@ -543,14 +527,13 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     da *= inv_d2; dc *= inv_d2; db *= inv_d2;                         // :254-256
 
     // dL/dSigma, packed upper triangle with doubled off-diagonals (:262-272)
-    float* gS = a.dL_dcov3D + 6 * (size_t)idx;
     const float S00 = t1.x * t1.x * da + t1.x * t2.x * db + t2.x * t2.x * dc;
     const float S11 = t1.y * t1.y * da + t1.y * t2.y * db + t2.y * t2.y * dc;
     const float S22 = t1.z * t1.z * da + t1.z * t2.z * db + t2.z * t2.z * dc;
     const float S01 = 2.f * t1.x * t1.y * da + (t1.x * t2.y + t1.y * t2.x) * db + 2.f * t2.x * t2.y * dc;
     const float S02 = 2.f * t1.x * t1.z * da + (t1.x * t2.z + t1.z * t2.x) * db + 2.f * t2.x * t2.z * dc;
     const float S12 = 2.f * t1.z * t1.y * da + (t1.y * t2.z + t1.z * t2.y) * db + 2.f * t2.y * t2.z * dc;
-    if (a.dL_dcov3D) { gS[0] = S00; gS[1] = S01; gS[2] = S02; gS[3] = S11; gS[4] = S12; gS[5] = S22; }   // NULL: only the scale / rotation path wants it
+    if (a.dL_dcov3D) { put3(a.dL_dcov3D, 2 * (size_t)idx, S00, S01, S02); put3(a.dL_dcov3D, 2 * (size_t)idx + 1, S11, S12, S22); }   // NULL: only the scale / rotation path wants it
 
     // dL/dt_i = 2 (Sigma t_i) d{a,c} + (Sigma t_j) db ; dL/du_i = A^T dL/dt_i + direct part (:281-307)
     const float3 gt1 = add3(scale3(St1, 2.f * da), scale3(St2, db));
@@ -579,7 +562,7 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
     const float i1 = uu1 > 0.f ? frcp(uu1) : 0.f, i2 = uu2 > 0.f ? frcp(uu2) : 0.f;
     const float3 gs = add3(scale3(u1, gx * i1), scale3(u2, gy * i2));
-    if (a.dL_dsphere) { a.dL_dsphere[3 * idx] = gs.x; a.dL_dsphere[3 * idx + 1] = gs.y; a.dL_dsphere[3 * idx + 2] = gs.z; }
+    if (a.dL_dsphere) put3(a.dL_dsphere, idx, gs.x, gs.y, gs.z);
     const float id3 = frcp(d3);
     const float dgs = dot3(d, gs);
     float3 v;
@@ -587,54 +570,114 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     v.y = g_mean.y + (n2 * gs.y - d.y * dgs) * id3 + gdep * dir.y;
     v.z = g_mean.z + (n2 * gs.z - d.z * dgs) * id3 + gdep * dir.z;
     const float3 gw = view_to_world(vm, v);                            // transformVec4x3Transpose (:525)
-    a.dL_dmean3D[3 * idx] = gw.x; a.dL_dmean3D[3 * idx + 1] = gw.y; a.dL_dmean3D[3 * idx + 2] = gw.z;
+    put3(a.dL_dmean3D, idx, gw.x, gw.y, gw.z);
 
     if (!a.scales) {
-        for (int k = 0; k < 3; k++) a.dL_dscale[3 * idx + k] = 0.f;
-        for (int k = 0; k < 4; k++) a.dL_drot[4 * idx + k] = 0.f;
+        put3(a.dL_dscale, idx, 0.f, 0.f, 0.f);
+        put4(a.dL_drot, idx, 0.f, 0.f, 0.f, 0.f);
     } else {
         // Sigma = sum_k s_k^2 r_k r_k^T, G = symmetric gradient (off-diagonals halved, :415-419)
-        if (!have_sr) {
-            const float m = a.scale_modifier;
-            sc = f3(m * a.scales[3 * idx], m * a.scales[3 * idx + 1], m * a.scales[3 * idx + 2]);
-            q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
-        }
         Sym3 G; G.xx = S00; G.xy = 0.5f * S01; G.xz = 0.5f * S02; G.yy = S11; G.yz = 0.5f * S12; G.zz = S22;
         float3 c0, c1, c2;
         quat_columns(q, c0, c1, c2);
         const float3 h0 = symmul(G, c0), h1 = symmul(G, c1), h2 = symmul(G, c2);
         // dL/ds_k = 2 s_k r_k^T G r_k  (w.r.t. the MODIFIED scale, as the reference, :428-432)
-        a.dL_dscale[3 * idx] = 2.f * sc.x * dot3(c0, h0);
-        a.dL_dscale[3 * idx + 1] = 2.f * sc.y * dot3(c1, h1);
-        a.dL_dscale[3 * idx + 2] = 2.f * sc.z * dot3(c2, h2);
+        put3(a.dL_dscale, idx, 2.f * sc.x * dot3(c0, h0), 2.f * sc.y * dot3(c1, h1), 2.f * sc.z * dot3(c2, h2));
         // F[k][c] = dL/dR[c][k] = 2 s_k^2 (G r_k)[c]
         const float3 F0 = scale3(h0, 2.f * sc.x * sc.x), F1 = scale3(h1, 2.f * sc.y * sc.y), F2 = scale3(h2, 2.f * sc.z * sc.z);
         const float F00 = F0.x, F01 = F0.y, F02 = F0.z, F10 = F1.x, F11 = F1.y, F12 = F1.z, F20 = F2.x, F21 = F2.y, F22 = F2.z;
         const float r = q.x, x = q.y, y = q.z, z = q.w;
-        float* gq = a.dL_drot + 4 * (size_t)idx;                      // :440-447, no normalisation Jacobian
-        gq[0] = 2.f * z * (F01 - F10) + 2.f * y * (F20 - F02) + 2.f * x * (F12 - F21);
-        gq[1] = 2.f * y * (F10 + F01) + 2.f * z * (F20 + F02) + 2.f * r * (F12 - F21) - 4.f * x * (F22 + F11);
-        gq[2] = 2.f * x * (F10 + F01) + 2.f * r * (F20 - F02) + 2.f * z * (F12 + F21) - 4.f * y * (F22 + F00);
-        gq[3] = 2.f * r * (F01 - F10) + 2.f * x * (F20 + F02) + 2.f * y * (F12 + F21) - 4.f * z * (F11 + F00);
+        // :440-447, no normalisation Jacobian
+        put4(a.dL_drot, idx, 2.f * z * (F01 - F10) + 2.f * y * (F20 - F02) + 2.f * x * (F12 - F21),
+             2.f * y * (F10 + F01) + 2.f * z * (F20 + F02) + 2.f * r * (F12 - F21) - 4.f * x * (F22 + F11),
+             2.f * x * (F10 + F01) + 2.f * r * (F20 - F02) + 2.f * z * (F12 + F21) - 4.f * y * (F22 + F00),
+             2.f * r * (F01 - F10) + 2.f * x * (F20 + F02) + 2.f * y * (F12 + F21) - 4.f * z * (F11 + F00));
     }
 }
 
-// A second backward on the same forward buffers (retain_graph) must start from zeroed lines again; whether it is the second is
-// known on the device only (the dirty word travels with the buffer), so the decision is taken there: clean = every workgroup
-// reads one word and retires.
-__global__ void __launch_bounds__(256) k_zero_if_dirty(const uint32_t* __restrict__ dirty, float4* __restrict__ acc, size_t n4) {
-    if (*dirty == 0u) return;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) acc[i] = z;
-}
-void launch_zero_if_dirty(const uint32_t* dirty, float* acc, size_t n, hipStream_t s) {
-    const size_t n4 = n / 4;                                           // n is a multiple of 16
-    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 2048);
-    if (blocks) hipLaunchKernelGGL(k_zero_if_dirty, dim3(blocks), dim3(256), 0, s, dirty, reinterpret_cast<float4*>(acc), n4);
+// One WAVE per region of LG_REGION consecutive Gaussians: the region's touched ones were listed by k_zero_touched (region-local
+// offsets, their count), and the wave runs the chain on them, 64 at a time.  Every wave of the launch has work of the same kind: with
+// the list compacted inside a 256-thread block instead (one wave of four working, ~40 of its lanes), a block lived as long as that
+// one wave's three memory round trips and the launch took 77 us for 0.33 M rows (tools/micro/gauss_bwd_bench.cpp).
+__global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int region = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int base = region * LG_REGION;
+    if (base >= a.P) return;
+    const int cnt = (int)a.tcount[region];
+    for (int j = lane; j < cnt; j += 64) gb_row(a, base + (int)a.tlist[base + j]);
 }
 
+// First launch of every backward, one thread per Gaussian, one block per region of LG_REGION:
+//   * the packed gradient line of each touched Gaussian is cleared (a second backward on the same forward buffers -- retain_graph --
+//     starts from zeroed lines like the first): a wave looks at the marks of its 64 Gaussians (one coalesced 64-byte read) and clears
+//     the marked ones' lines LINE float4 at a time, sixteen (eight) lanes per 64-byte (128-byte) line -- whole-line stores, nothing
+//     for the unmarked;
+//   * the region's touched Gaussians are listed (region-local offsets in index order + their count) for k_gaussian_backward;
+//   * every gradient row of every Gaussian is zeroed, whole lines at a time (the reference's torch::zeros, R3/rasterize_points.cu:163-175);
+//     k_gaussian_backward then overwrites the touched ones' rows.  (Zeroing only the untouched rows in that launch left partially
+//     written lines behind for the touched rows to complete later: 95 us against 75 in the micro-benchmark.)
+template <int LINE>
+__global__ void __launch_bounds__(LG_REGION) k_zero_touched(const uint8_t* __restrict__ touched, float4* __restrict__ acc, size_t P,
+                                                           uint8_t* __restrict__ tlist, uint16_t* __restrict__ tcount, const ZeroRows zr) {
+    __shared__ uint32_t s_wcnt[LG_REGION / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t base = (size_t)blockIdx.x * LG_REGION;
+    const size_t i = base + tid;
+    const bool mark = i < P && touched[i] != 0;
+    const unsigned long long m0 = __ballot(mark);
+    if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(m0);
+    {
+        unsigned long long m = m0;
+        const size_t wbase = i - (size_t)lane;
+        constexpr int PER = 64 / LINE;                                 // lines cleared per store instruction
+        const int sub = lane / LINE, part = lane % LINE;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (m) {
+            // the next PER marked Gaussians of the wave: lane group `sub` takes the sub-th of them
+            unsigned long long mm = m;
+            int mine = -1;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int j = mm ? __builtin_ctzll(mm) : -1;
+                if (k == sub) mine = j;
+                mm &= mm - 1ull;
+            }
+            m = mm;
+            if (mine >= 0) acc[(wbase + (size_t)mine) * LINE + part] = z;
+        }
+    }
+    if (i < P) {
+        for (int k = 0; k < zr.n; k++) {                               // (wave-uniform: the pointers and widths are scalar loads from the arguments)
+            float* q = zr.p[k];
+            switch (zr.w[k]) {                                         // (uniform over the launch)
+                case 1: q[i] = 0.f; break;
+                case 2: put2(q, i, 0.f, 0.f); break;
+                case 3: put3(q, i, 0.f, 0.f, 0.f); break;
+                case 4: put4(q, i, 0.f, 0.f, 0.f, 0.f); break;
+                case 6: put3(q, 2 * i, 0.f, 0.f, 0.f); put3(q, 2 * i + 1, 0.f, 0.f, 0.f); break;
+                default: for (int c = 0; c < zr.w[k]; c += 3) put3(q, (size_t)(zr.w[k] / 3) * i + c / 3, 0.f, 0.f, 0.f); break;   // 9
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int v = 0; v < LG_REGION / 64; v++) { off += v < wv ? s_wcnt[v] : 0u; total += s_wcnt[v]; }
+    if (mark) tlist[base + off + (uint32_t)__popcll(m0 & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    if (tid == 0) tcount[blockIdx.x] = (uint16_t)total;
+}
+void launch_zero_touched(const uint8_t* touched, float4* acc, int line_f4, size_t P, uint8_t* tlist, uint16_t* tcount, const ZeroRows& zr, hipStream_t s) {
+    const unsigned blocks = (unsigned)((P + LG_REGION - 1) / LG_REGION);
+    if (!blocks) return;
+    if (line_f4 == 8) hipLaunchKernelGGL(k_zero_touched<8>, dim3(blocks), dim3(LG_REGION), 0, s, touched, acc, P, tlist, tcount, zr);
+    else hipLaunchKernelGGL(k_zero_touched<4>, dim3(blocks), dim3(LG_REGION), 0, s, touched, acc, P, tlist, tcount, zr);
+}
+void launch_touch_all(uint8_t* touched, size_t P, hipStream_t s) { (void)hipMemsetAsync(touched, 1, P, s); }
+
 void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_gaussian_backward, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const unsigned regions = (unsigned)((a.P + LG_REGION - 1) / LG_REGION);
+    hipLaunchKernelGGL(k_gaussian_backward, dim3((regions + 3) / 4), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -367,8 +367,8 @@ __device__ __forceinline__ int park_compact(float4* s_rec, float4* s_oprow, cons
 // One workgroup = (patch, segment).  T_ONLY: pass 1.  Otherwise pass 2.
 template <bool T_ONLY, bool V2 = false>
 __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
-    __shared__ float4 s_rec[4 * LG_CHUNK];
-    __shared__ float4 s_oprow[LG_CHUNK + 2];                           // the entry's opacity per pixel row of this patch, 0 outside its row span (+2: the second form's look-ahead reads)
+    __shared__ float4 s_rec[4 * LG_CHUNK + 2];                         // (+2: the second forms' look-ahead reads run two slots past the last component)
+    __shared__ float4 s_oprow[LG_CHUNK + 2];                           // the entry's opacity per pixel row of this patch, 0 outside its row span (+2: as above)
     const int lane = threadIdx.x;
     const int S = a.S;
     const int wpt = a.grid.waves_per_tile;
@@ -415,9 +415,11 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     uint32_t c_done = 0;                                               // chunks whose flags pass 1 has written
     if (__ballot(!w.done) != 0ull && n > 0) {
         auto entry_valid = [&](uint32_t k) { return k < n && (T_ONLY || !fl || fl[k] != 0); };
+        uint32_t g_fetched = 0u;                                       // the Gaussian of the entry this lane fetched last (pass 1 marks it as touched with its flag)
         auto fetch = [&](uint32_t k, bool& have) {
             const uint32_t g = k < n ? a.point_list[sr.x + k] : 0u;    // not waiting for the flag
             have = entry_valid(k);
+            g_fetched = g;
             return gather_record(a.rec, a.rowspan, g, have);
         };
         bool have;
@@ -425,6 +427,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
         if (!T_ONLY && V2) { have = have_first; st = gather_record(a.rec, a.rowspan, g_first, have); }
         else st = fetch((uint32_t)lane, have);
         for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t g_mine = g_fetched;                         // entry c * 64 + lane's
             __syncthreads();
             unsigned long long todo = __ballot(have);                  // entries of this chunk worth visiting
             int cnt = 0;
@@ -446,7 +449,9 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
             }
             if (T_ONLY && fl) {
                 const uint32_t k = c * LG_CHUNK + lane;
-                if (k < n) fl[k] = (uint8_t)((w.took >> lane) & 1ull);
+                const bool took = (w.took >> lane) & 1ull;
+                if (k < n) fl[k] = (uint8_t)took;
+                if (a.touched && took && k < n) a.touched[g_mine] = 1;  // (same value from every patch that takes it: a plain byte store)
                 c_done = c + 1;
             }
         }
@@ -485,7 +490,7 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
 // the product pass 2 and k_render_alive form over the segments in front of the tail is the transmittance the tail starts from.
 template <bool FIRST, bool V2 = false>
 __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs a, const int G) {
-    __shared__ float4 s_rec[4 * LG_CHUNK];
+    __shared__ float4 s_rec[4 * LG_CHUNK + 2];                         // (+2: walk_full_v2's look-ahead reads)
     __shared__ float4 s_oprow[LG_CHUNK + 2];
     const int lane = threadIdx.x;
     const int S = a.S;
@@ -515,10 +520,12 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
     const v2f qxy = v2f{px.q.x, px.q.y};
     uint8_t* flp = a.flags ? a.flags + (size_t)sub * a.R : nullptr;
 
+    uint32_t g_fetched = 0u;                                           // FIRST: the Gaussian of the entry this lane fetched last (marked as touched with its flag)
     auto fetch = [&](uint2 sr, uint32_t n, uint32_t c, bool& have) {
         const uint32_t k = c * LG_CHUNK + (uint32_t)lane;
         const uint32_t g = k < n ? a.point_list[sr.x + k] : 0u;        // not waiting for the flag
         have = k < n && (FIRST || !flp || flp[sr.x + k] != 0);
+        g_fetched = g;
         return gather_record(a.rec, a.rowspan, g, have);
     };
     uint2 sr = segment_range(tr, St, s0);
@@ -534,6 +541,7 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
         uint32_t c_done = 0;                                           // FIRST: chunks of this segment whose flags are written
         if (!all_done) {
             for (uint32_t c = 0; c < nchunks; c++) {
+                const uint32_t g_mine = g_fetched;                     // entry c * 64 + lane's
                 __syncthreads();
                 const unsigned long long todo = __ballot(have);
                 int cnt = 0;
@@ -553,7 +561,9 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
                 }
                 if (FIRST && flp) {
                     const uint32_t k = c * LG_CHUNK + lane;
-                    if (k < n) flp[sr.x + k] = (uint8_t)((w.took >> lane) & 1ull);
+                    const bool took = (w.took >> lane) & 1ull;
+                    if (k < n) flp[sr.x + k] = (uint8_t)took;
+                    if (a.touched && took && k < n) a.touched[g_mine] = 1;
                     c_done = c + 1;
                 }
             }
@@ -602,7 +612,7 @@ __global__ void __launch_bounds__(64) k_render_pass2_grouped(const RenderFwdArgs
 // The per-segment planes, the flags and the patch's limit are written exactly as the backward expects them (k_render_backward).
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a) {
-    __shared__ float4 s_rec_all[NW][4 * LG_CHUNK];
+    __shared__ float4 s_rec_all[NW][4 * LG_CHUNK + 2];                 // (+2: the second forms' look-ahead reads stay inside the wave's own slot)
     __shared__ float4 s_oprow_all[NW][LG_CHUNK + 2];                 // (+2: walk_T_only_v2's look-ahead reads)
     __shared__ float s_x[NW][6][64];                                   // per wave: Tpass | C0, C1, D, T_end, T_break of its segment
     __shared__ unsigned long long s_took[NW][8];                       // contribution masks of the chunks of the wave's segment (<= 8 kept)
@@ -645,13 +655,16 @@ __global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a)
             uint32_t c_done = 0;
             if (__ballot(!ws.done) != 0ull && n > 0) {
                 bool have;
+                uint32_t g_fetched = 0u;
                 auto fetch = [&](uint32_t kk, bool& hv) {
                     const uint32_t g = kk < n ? a.point_list[sr.x + kk] : 0u;
                     hv = kk < n;
+                    g_fetched = g;
                     return gather_record(a.rec, a.rowspan, g, hv);
                 };
                 Staged st = fetch((uint32_t)lane, have);
                 for (uint32_t c = 0; c < nchunks; c++) {
+                    const uint32_t g_mine = g_fetched;                 // entry c * 64 + lane's
                     __builtin_amdgcn_wave_barrier();
                     park_record(s_rec, lane, st);
                     s_oprow[lane] = rows_opacity(st.span, st.a3.y, y0);
@@ -666,7 +679,9 @@ __global__ void __launch_bounds__(64 * NW) k_render_fused(const RenderFwdArgs a)
                         else walk_flagged<true>(todo, s_rec, oprow, qxy, px.q.z, c * LG_CHUNK, ws, stop);
                     }
                     const uint32_t kk = c * LG_CHUNK + lane;
-                    if (kk < n) flp[sr.x + kk] = (uint8_t)((ws.took >> lane) & 1ull);
+                    const bool took = (ws.took >> lane) & 1ull;
+                    if (kk < n) flp[sr.x + kk] = (uint8_t)took;
+                    if (a.touched && took && kk < n) a.touched[g_mine] = 1;
                     if (lane == 0 && c < 8) s_took[w][c] = ws.took;
                     c_done = c + 1;
                 }

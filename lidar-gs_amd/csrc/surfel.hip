@@ -92,18 +92,16 @@ struct SfPreArgs {
                            // pixel centre still come from scales / rotations / means3D: R2/cr/rasterizer_impl.cu:332 vs forward.cu:271-325)
     int* radii; int* radii_xy;
     float4* rec; uint32_t* rowspan; uint4* spans; uint32_t* dkey; uint32_t* ids;
-    uint32_t* dirty;       // the geometry buffer's "gradient lines hold sums" word (LG_TOTALS_DIRTY_WORD): cleared here
     unsigned long long* inst_slots;     // [LG_INST_SLOTS][4]: word 0 of each slot = part of the instance total (zeroed by the caller)
     unsigned long long* diag_slots;     // [LG_INST_SLOTS][2]: visible surfels, reference tiles_touched (diagnostics)
     uint32_t* key_span;                 // [LG_INST_SLOTS][2]: ~(smallest), largest range key of the visible surfels (zeroed by the caller), as k_preprocess
     int compact;                        // 4-byte span records (compact_spans)
-    float4* gacc;          // [8P] packed gradient lines of the backward: zeroed here for every surfel with radii > 0
+    uint8_t* touched;      // [P] "some pixel took this surfel" marks of the blend (cleared here; see preprocess.hip k_zero_touched)
 };
 
 template <bool FILTER>
 __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (!FILTER && idx == 0 && a.dirty) *a.dirty = 0u;
     // the beam table is binary-searched five times per surfel: keep it in LDS when it fits (as k_preprocess does)
     constexpr int BEAMS_LDS = 1024;
     __shared__ float s_beams[BEAMS_LDS];
@@ -230,22 +228,11 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
             }
         }
     }
-    // the packed 128-byte gradient lines the backward adds into are zeroed here, not by a 128 B x P fill launch per frame: the wave
-    // writes the 8 KB of its 64 surfels as eight contiguous 1-KB stores
-    {
-        const int lane = threadIdx.x & 63, wbase = idx - lane;
-        if (wbase < a.P) {
-            float4* z = a.gacc + 8 * (size_t)wbase;
-            const size_t room = 8 * (size_t)(a.P - wbase);
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const size_t o = (size_t)k * 64 + lane;
-                if (o < room) z[o] = zero;
-            }
-        }
-    }
+    // The packed 128-byte gradient lines the backward adds into: rounds 2-4 zeroed all P of them here (256 MB at 2 M surfels).  Only the
+    // surfels some pixel's walk takes are ever added to: the blend marks them (one byte each, cleared below), the backward's first
+    // launch clears exactly their lines (preprocess.hip k_zero_touched).
     if (!in_range) return;
+    a.touched[idx] = 0;
     a.dkey[idx] = key;                                                 // (the ids of the range sort are the positions: not written)
     // lidargs_common.h: one gather per Gaussian when the lists are built (4-byte records when the image allows)
     if (a.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(rspan, tiles ? xsp : 0u);
@@ -358,6 +345,7 @@ struct SfFwdArgs {
     float* out_color; float* out_others;
     float* seg; int S; int seg_len;     // [patches][S][SF_SEG_PLANES][64]
     uint8_t* flags; size_t R;           // [waves_per_tile][R]
+    uint8_t* touched;                   // [P] set to 1 for the surfel of every entry whose flag is set
     uint8_t* alive;                     // [patches] segments pass 1 walked (255 = all); nullptr = no gating
     int seg_lo, seg_hi, front;
 };
@@ -463,6 +451,7 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
         bool have = entry_valid(lane);
         SfStaged st = sf_gather(a.point_list, a.rec, a.rowspan, sr.x + lane, have);
         for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t g_mine = st.gid;                            // entry c * 64 + lane's surfel (pass 1 marks it as touched with its flag)
             __syncthreads();
             s_rec[lane] = st.a0; s_rec[SF_CHUNK + lane] = st.a1; s_rec[2 * SF_CHUNK + lane] = st.a2; s_rec[3 * SF_CHUNK + lane] = st.a3;
             s_rec[4 * SF_CHUNK + lane] = st.a4; s_oprow[lane] = rows_opacity(st.span, st.a1.z, y0);
@@ -554,7 +543,9 @@ __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
             }
             if (T_ONLY) {
                 const uint32_t k = c * SF_CHUNK + lane;
-                if (k < n) fl[k] = (uint8_t)((took >> lane) & 1ull);
+                const bool tk = (took >> lane) & 1ull;
+                if (k < n) fl[k] = (uint8_t)tk;
+                if (tk && k < n) a.touched[g_mine] = 1;                 // (same value from every patch that takes it: a plain byte store)
                 c_done = c + 1;
             }
         }
@@ -907,27 +898,42 @@ struct SfGaussBwdArgs {
     int P, W, H;
     const float* view; const float* means3D; const float* scales; const float* rotations; const float* beams; const int* radii;
     const float* transMat;             // transMat_precomp or nullptr: the Tw the blend's backward saw (the per-pair terms reconstructed below)
-    const float* gacc; uint32_t* dirty;
+    const float* gacc; const uint8_t* tlist; const uint16_t* tcount;   // packed sums (lines of touched surfels only) | the touched surfels, region by region
     float* dL_dmean2D; float* dL_dnormal; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D; float* dL_dtransMat;
     float* dL_dtransMat_2dtemp; float* dL_dscale; float* dL_drot; float* depth;
 };
 
+// Sparse (round 5, as k_gaussian_backward in preprocess.hip): only the surfels the blend marked as touched have a gradient.  The
+// backward's first launch (k_zero_touched) zeroed every gradient row and listed the touched surfels region by region; here a block
+// covers four regions: every thread first writes the planar depth of four surfels (an output, not a gradient: R2/cr/backward.cu:670,
+// 0 for a culled one), then each wave runs the chain on the listed surfels of one region and overwrites their rows.
+__device__ __forceinline__ void sf_gb_row(const SfGaussBwdArgs& a, const int idx);
 __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0 && a.dirty) *a.dirty = 1u;                            // the packed lines now hold this backward's sums
-    if (idx >= a.P) return;
-    if (!(a.radii[idx] > 0)) {                                         // every output row is written (zeros here)
-        for (int k = 0; k < 4; k++) { a.dL_dmean2D[4 * idx + k] = 0.f; a.dL_drot[4 * idx + k] = 0.f; }
-        for (int k = 0; k < 3; k++) {
-            a.dL_dmean3D[3 * idx + k] = 0.f;
-            if (a.dL_dnormal) a.dL_dnormal[3 * idx + k] = 0.f;
-            if (a.dL_dtransMat_2dtemp) a.dL_dtransMat_2dtemp[3 * idx + k] = 0.f;
+    const int lane = threadIdx.x & 63;
+    {
+        const float* vm = a.view;
+        const int b0 = blockIdx.x * 4 * LG_REGION;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = b0 + k * 256 + (int)threadIdx.x;
+            if (i >= a.P) break;
+            float dep = 0.f;
+            if (a.radii[i] > 0) {
+                const float3 pw = get3(a.means3D, i);
+                const float px = vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], pz = vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14];
+                dep = sqrtf(px * px + pz * pz);                        // :670 (x, z only, as the reference)
+            }
+            a.depth[i] = dep;
         }
-        if (a.dL_dtransMat) for (int k = 0; k < 9; k++) a.dL_dtransMat[9 * idx + k] = 0.f;
-        a.dL_dcolor[2 * idx] = 0.f; a.dL_dcolor[2 * idx + 1] = 0.f; a.dL_dopacity[idx] = 0.f;
-        a.dL_dscale[2 * idx] = 0.f; a.dL_dscale[2 * idx + 1] = 0.f; a.depth[idx] = 0.f;
-        return;
     }
+    const int region = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int base = region * LG_REGION;
+    if (base >= a.P) return;
+    const int cnt = (int)a.tcount[region];
+    for (int j = lane; j < cnt; j += 64) sf_gb_row(a, base + (int)a.tlist[base + j]);
+}
+
+__device__ __forceinline__ void sf_gb_row(const SfGaussBwdArgs& a, const int idx) {
     const float* vm = a.view;
     // the surfel's 128-byte line as eight 16-byte loads issued together (the slots are read all over the function: left to the
     // compiler they became a dozen 4-/8-/12-byte loads, each a pass over 64 different lines for the wave)
@@ -938,7 +944,7 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
         for (int k = 0; k < 8; k++) { const float4 v = g4[k]; gl[4 * k] = v.x; gl[4 * k + 1] = v.y; gl[4 * k + 2] = v.z; gl[4 * k + 3] = v.w; }
     }
     const float* g = gl;
-    const float3 pw = sf3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const float3 pw = get3(a.means3D, idx);
     const float3 pv = sf3(vm[0] * pw.x + vm[4] * pw.y + vm[8] * pw.z + vm[12], vm[1] * pw.x + vm[5] * pw.y + vm[9] * pw.z + vm[13],
                           vm[2] * pw.x + vm[6] * pw.y + vm[10] * pw.z + vm[14]);
     // the per-pair terms folded into per-surfel coefficients below were evaluated with the blend's Tw (R2/cr/backward.cu:267); the
@@ -949,12 +955,12 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const float pi_f = 3.14159265358979323846f;
     const float ga = fabsf(a.beams[a.H - 1] - a.beams[0]) / ((float)a.H - 1.f);   // grad_alpha (:425)
 
-    a.dL_dcolor[2 * idx] = g[SFA_COL0]; a.dL_dcolor[2 * idx + 1] = g[SFA_COL1];
+    put2(a.dL_dcolor, idx, g[SFA_COL0], g[SFA_COL1]);
     a.dL_dopacity[idx] = g[SFA_OPA];
     const float3 gn = sf3(g[SFA_N0], g[SFA_N1], g[SFA_N2]);
-    if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = gn.x; a.dL_dnormal[3 * idx + 1] = gn.y; a.dL_dnormal[3 * idx + 2] = gn.z; }   // the three intermediates are optional
+    if (a.dL_dnormal) put3(a.dL_dnormal, idx, gn.x, gn.y, gn.z);   // the three intermediates are optional
     const float3 aw = sf3(g[SFA_AW0], g[SFA_AW1], g[SFA_AW2]);
-    if (a.dL_dtransMat_2dtemp) { a.dL_dtransMat_2dtemp[3 * idx] = aw.x; a.dL_dtransMat_2dtemp[3 * idx + 1] = aw.y; a.dL_dtransMat_2dtemp[3 * idx + 2] = aw.z; }
+    if (a.dL_dtransMat_2dtemp) put3(a.dL_dtransMat_2dtemp, idx, aw.x, aw.y, aw.z);
 
     // dL/dmean2D: 3-D branch statistics are abs-linear in |dL/dTw| with per-surfel coefficients (:564-577);
     // |sin(beta_t) cos(alpha_t)| = |Tw.y|/rho_r, |cos(beta_t) cos(alpha_t)| = |Tw.x|/rho_r, ...
@@ -962,10 +968,8 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const float mx3 = pi_f * (fabsf(Tw.y) * aw.x + fabsf(Tw.x) * aw.y);                        // (|..|2pi/W) * rho_r * 0.5 W
     const float my3 = 0.5f * (float)a.H * ga * (fabsf(Tw.z) * fabsf(Tw.x) * irxy * aw.x + fabsf(Tw.z) * fabsf(Tw.y) * irxy * aw.y + rxy * aw.z);
     const float m2x = g[SFA_M2X], m2y = g[SFA_M2Y];
-    a.dL_dmean2D[4 * idx] = mx3 + m2x * 0.5f * (float)a.W;
-    a.dL_dmean2D[4 * idx + 1] = my3 + m2y * 0.5f * (float)a.H;
-    a.dL_dmean2D[4 * idx + 2] = mx3 + g[SFA_M2AX] * 0.5f * (float)a.W;
-    a.dL_dmean2D[4 * idx + 3] = my3 + g[SFA_M2AY] * 0.5f * (float)a.H;
+    put4(a.dL_dmean2D, idx, mx3 + m2x * 0.5f * (float)a.W, my3 + m2y * 0.5f * (float)a.H, mx3 + g[SFA_M2AX] * 0.5f * (float)a.W,
+         my3 + g[SFA_M2AY] * 0.5f * (float)a.H);
 
     // dL/dT rows: 3-D sums + the 2-D branch's Tw terms (:590-598)
     float3 gTw = sf3(g[SFA_TW0], g[SFA_TW1], g[SFA_TW2]);
@@ -981,12 +985,12 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     }
     const float3 gTu = sf3(g[SFA_TU0], g[SFA_TU1], g[SFA_TU2]), gTv = sf3(g[SFA_TV0], g[SFA_TV1], g[SFA_TV2]);
     if (a.dL_dtransMat) {
-        float* gT = a.dL_dtransMat + 9 * (size_t)idx;
-        gT[0] = gTu.x; gT[1] = gTu.y; gT[2] = gTu.z; gT[3] = gTv.x; gT[4] = gTv.y; gT[5] = gTv.z; gT[6] = gTw.x; gT[7] = gTw.y; gT[8] = gTw.z;
+        put3(a.dL_dtransMat, 3 * (size_t)idx, gTu.x, gTu.y, gTu.z); put3(a.dL_dtransMat, 3 * (size_t)idx + 1, gTv.x, gTv.y, gTv.z);
+        put3(a.dL_dtransMat, 3 * (size_t)idx + 2, gTw.x, gTw.y, gTw.z);
     }
 
     // K10': T rows are (Rv L0, Rv L1, p_view)  =>  dL/dL0 = Rv^T dL/dTu, dL/dL1 = Rv^T dL/dTv, dL/dp = Rv^T dL/dTw
-    const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+    const float4 q = get4(a.rotations, idx);
     float3 c0, c1, c2;
     sf_quat_cols(q, c0, c1, c2);
     const float3 dL0 = sf_rot_world(vm, gTu), dL1 = sf_rot_world(vm, gTv), dLp = sf_rot_world(vm, gTw);
@@ -994,26 +998,24 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const float3 nv = sf_rot_view(vm, c2);
     const float cs = -(pv.x * nv.x + pv.y * nv.y + pv.z * nv.z);
     if (!(cs > 0.f)) { dtn.x = -dtn.x; dtn.y = -dtn.y; dtn.z = -dtn.z; }
-    a.depth[idx] = sqrtf(pv.x * pv.x + pv.z * pv.z);                   // :670 (x,z only, as the reference)
     const float s0 = a.scales[2 * idx], s1 = a.scales[2 * idx + 1];   // the backward ignores scale_modifier (:632)
-    a.dL_dscale[2 * idx] = sdot(dL0, c0);
-    a.dL_dscale[2 * idx + 1] = sdot(dL1, c1);
-    a.dL_dmean3D[3 * idx] = dLp.x; a.dL_dmean3D[3 * idx + 1] = dLp.y; a.dL_dmean3D[3 * idx + 2] = dLp.z;
+    put2(a.dL_dscale, idx, sdot(dL0, c0), sdot(dL1, c1));
+    put3(a.dL_dmean3D, idx, dLp.x, dLp.y, dLp.z);
     // quat_to_rotmat_vjp with v_R columns (dL0*s0, dL1*s1, dtn)  (R2/cr/auxiliary.h:274-316)
     const float3 v0 = sf3(dL0.x * s0, dL0.y * s0, dL0.z * s0), v1 = sf3(dL1.x * s1, dL1.y * s1, dL1.z * s1), v2 = dtn;
     const float sn = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     const float w = q.x * sn, x = q.y * sn, y = q.z * sn, z = q.w * sn;
     // v_R[c][r]: column c = v_c, row r = component
     const float R01 = v0.y, R02 = v0.z, R10 = v1.x, R12 = v1.z, R20 = v2.x, R21 = v2.y, R00 = v0.x, R11 = v1.y, R22 = v2.z;
-    float* gq = a.dL_drot + 4 * (size_t)idx;
-    gq[0] = 2.f * (x * (R12 - R21) + y * (R20 - R02) + z * (R01 - R10));
-    gq[1] = 2.f * (-2.f * x * (R11 + R22) + y * (R01 + R10) + z * (R02 + R20) + w * (R12 - R21));
-    gq[2] = 2.f * (x * (R01 + R10) - 2.f * y * (R00 + R22) + z * (R12 + R21) + w * (R20 - R02));
-    gq[3] = 2.f * (x * (R02 + R20) + y * (R12 + R21) - 2.f * z * (R00 + R11) + w * (R01 - R10));
+    put4(a.dL_drot, idx, 2.f * (x * (R12 - R21) + y * (R20 - R02) + z * (R01 - R10)),
+         2.f * (-2.f * x * (R11 + R22) + y * (R01 + R10) + z * (R02 + R20) + w * (R12 - R21)),
+         2.f * (x * (R01 + R10) - 2.f * y * (R00 + R22) + z * (R12 + R21) + w * (R20 - R02)),
+         2.f * (x * (R02 + R20) + y * (R12 + R21) - 2.f * z * (R00 + R11) + w * (R01 - R10)));
 }
 
 void launch_sf_gaussian_backward(const SfGaussBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_sf_gaussian_backward, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const unsigned regions = (unsigned)((a.P + LG_REGION - 1) / LG_REGION);
+    hipLaunchKernelGGL(k_sf_gaussian_backward, dim3((regions + 3) / 4), dim3(256), 0, s, a);
 }
 
 }  // namespace lg

@@ -35,7 +35,7 @@ for _name in ("lidargs_forward", "lidargs_forward_enqueue", "lidargs_backward", 
     getattr(_lib, _name).restype = C.c_int
 _lib.lidargs_profile_stage_name.restype = C.c_char_p
 _lib.lidargs_profile_enable.restype = None
-if _lib.lidargs_abi_version() != 1:
+if _lib.lidargs_abi_version() != 2:
     raise ImportError("diff_lidargs_rasterization: liblidargs_hip.so ABI version mismatch; rebuild it")
 
 
@@ -297,8 +297,8 @@ def profile_summary():
 
 
 def last_counters():
-    """dict(P, V, instances, R_ref, tile_rows, tiles) of the last forward on this thread."""
-    buf = (C.c_longlong * 8)()
-    _lib.lidargs_last_counters(buf, C.c_int(8))
+    """dict(P, V, instances, R_ref, tile_rows, tiles, ..., touched) of the last forward on this thread."""
+    buf = (C.c_longlong * 9)()
+    _lib.lidargs_last_counters(buf, C.c_int(9))
     return dict(P=buf[0], V=buf[1], instances=buf[2], R_ref=buf[3], tile_rows=buf[4], tiles=buf[5], taken_instances=buf[6],
-                segments=buf[7])
+                segments=buf[7], touched=buf[8])

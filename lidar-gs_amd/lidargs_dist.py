@@ -602,7 +602,10 @@ class _RankPlan:
         """The plan for an enqueue-only frame, or None while nothing has been learnt (an ordinary frame, which teaches it)."""
         if not self.rows:
             return None
-        self.check(wait=False)
+        # the status words and the event are shared by every frame in flight: the previous frame's words are read (one event wait, on
+        # a frame that is already a frame old) BEFORE this frame's copy may overwrite them -- a look that returns when the event has not
+        # completed yet, which is the normal state with the host running ahead, would lose that frame's overflow flag
+        self.check(wait=True)
         if self.status is None:
             self.status = torch.zeros(18, dtype=torch.int32).pin_memory()
         return self
@@ -740,10 +743,10 @@ def _shell_backward(module, saved, g_color, g_depth, g_occ):
     sync = module.grad_sync if comm.world > 1 else "none"
     packed = be.pack_rows(g, idx)                                                 # [M, 18]: gradients + the row's global index
     blocked = sync != "reduce_scatter_dense"
+    module.plan.check()                            # every sync mode: a frame over its capacities raises in its own backward (its kernels are queued)
     if sync == "reduce_scatter":
         # 6: the shell's rows go straight to their index-chunk owners; the row index travels as an 18th column (bit pattern)
         send, recv = saved["counts"].splits(comm.rank)
-        module.plan.check()                        # (the forward's status words arrived with the split sizes)
         got = comm.all_to_all_rows(packed[:sum(send)], send, recv)      # (an enqueue-only frame's rows are capacity-sized)
         dense = be.unpack_rows(got, P, blocked=True)
     else:
@@ -939,9 +942,9 @@ def _wedge_backward(module, saved, g_color, g_depth, g_occ):
     g = be.backward_plain(st, (g_color.reshape(2, H * W), g_depth.reshape(H * W), g_occ.reshape(H * W)))
     sync = module.grad_sync if comm.world > 1 else "none"
     packed = be.pack_rows(g, idx)
+    module.plan.check()                            # every sync mode (see _shell_backward)
     if sync == "reduce_scatter":
         send, recv = saved["counts"].splits(comm.rank)
-        module.plan.check()
         got = comm.all_to_all_rows(packed[:sum(send)], send, recv)
         dense = be.unpack_rows_add(got, P)
     else:

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(hip_lib_built):
     lib = ctypes.CDLL(hip_lib_built)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.lidargs_abi_version() == 1
+    assert lib.lidargs_abi_version() == 2
     out = subprocess.run(["nm", "-D", "--defined-only", hip_lib_built], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (lidargs_\w+)", out))
     assert set(names) <= exported

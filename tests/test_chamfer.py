@@ -91,6 +91,8 @@ GRID_CASES = {
     # what the grid search has to get right: (name -> builder of (a, b))
     "far_apart": lambda r: ((r.normal(size=(1, 3000, 3)) * 2 + 500).astype(np.float32), (r.normal(size=(1, 2500, 3)) * 2 - 500).astype(np.float32)),   # nobody settles within the rings: the brute force behind takes over
     "one_far_query": lambda r: (np.concatenate([r.normal(size=(1, 2000, 3)) * 5, [[[900.0, -700.0, 300.0]]]], 1).astype(np.float32), (r.normal(size=(1, 2500, 3)) * 5).astype(np.float32)),
+    "strays": lambda r: (np.concatenate([r.normal(size=(1, 4000, 3)) * 5, r.uniform(-3000, 3000, size=(1, 40, 3))], 1).astype(np.float32),      # 1 % stray returns: searched one by one (round 5), the rest by the grid
+                         np.concatenate([r.normal(size=(1, 3500, 3)) * 5, r.uniform(-3000, 3000, size=(1, 25, 3))], 1).astype(np.float32)),
     "flat": lambda r: (np.concatenate([r.uniform(-60, 60, size=(1, 4000, 2)), np.zeros((1, 4000, 1))], 2).astype(np.float32),
                        np.concatenate([r.uniform(-60, 60, size=(1, 3500, 2)), np.zeros((1, 3500, 1))], 2).astype(np.float32)),
     "line": lambda r: (np.concatenate([r.uniform(-80, 80, size=(1, 3000, 1)), np.full((1, 3000, 2), 1.5)], 2).astype(np.float32),

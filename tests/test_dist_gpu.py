@@ -515,9 +515,8 @@ def test_enqueue_only_rank_frame_over_its_capacity_is_reported(wedges, what, hip
     else:
         mod.plan.instances = 4096
     out1, saved = fwd(mod, *args)
-    bwd(mod, saved, gc, gd, go)
-    with pytest.raises(RuntimeError, match="enqueue-only rank frame"):
-        mod.plan.check()
+    with pytest.raises(RuntimeError, match="enqueue-only rank frame"):      # the frame's own backward reports it, in every sync mode
+        bwd(mod, saved, gc, gd, go)
     assert (mod.plan.rows if what == "rows" else mod.plan.instances) >= (rows if what == "rows" else inst) / 1.3      # grown back
     out2, saved = fwd(mod, *args)                      # the next frame has room again
     g2 = bwd(mod, saved, gc, gd, go)
@@ -590,3 +589,24 @@ def test_bench_two_ranks_over_rccl(hip_lib_built):
                     f"virtual ranks on one GPU)")
     j = _bench("--gpus", "2", "--workload", "cfg2", "--fwd-bwd", "--steps", "5", "--warmup", "2")
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and set(j["cuts"]) == {"shells", "wedges"}
+
+
+@pytest.mark.gpu
+def test_enqueue_only_overflow_survives_a_second_forward(hip_lib_built):
+    """Two forwards with no backward between them (an eval render, or a frame whose backward comes later): the second forward's status
+    copy reuses the pinned words, so the first frame's overflow must be read -- and raised -- before it is queued (round-4 advisor finding:
+    a non-waiting look returned early with the host running ahead, and the flag was overwritten)."""
+    import lidargs_dist
+    kind, P, H, W, seed = "street", 20000, 16, 512, 93
+    st = to_torch(sc.make_scene(kind, P, H, seed, random_view=True))
+    mod = lidargs_dist.ShellRasterizer(make_settings(st, W, H))
+    mod.enqueue_only = True
+    args = (st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
+    with torch.no_grad():
+        lidargs_dist.shell_forward(mod, *args)         # ordinary frame: teaches the plan
+        mod.plan.instances = 4096
+        lidargs_dist.shell_forward(mod, *args)         # over its capacity; nobody looks yet
+        with pytest.raises(RuntimeError, match="enqueue-only rank frame"):
+            lidargs_dist.shell_forward(mod, *args)     # the next frame reads the old status first
+        lidargs_dist.shell_forward(mod, *args)         # capacities were raised: fine again
+        mod.plan.check()
