@@ -60,11 +60,12 @@ def build(force=False, verbose=False):
 
 def _build_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra_all = os.environ.get("LIDARGS_EXTRA_HIPCC_FLAGS", "").split()      # instrumented builds of the tools (e.g. -DLG_LANE_STATS), never the product's
 
     def compile_one(item):
         src, extra = item
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + COMMON + extra + extra_all + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

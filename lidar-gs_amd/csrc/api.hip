@@ -399,7 +399,15 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     // bits -- 2 m .. 80 m is 26 -- and every 8-9 bits less is a pass (three launches) less.  kmin is rounded down to a multiple of 256,
     // so the first pass (the key's own low byte) needs no host knowledge and is queued right behind the totals' copy; the host then
     // reads the span and queues as many more passes as it has bits.
-    if (enqueue_only) {                                                // no host read: all 31 bits of the raw key
+    // Round 5: frames of up to 4 M Gaussians sort in ONE bucket pass + one launch that finishes every bucket in LDS (binning.hip
+    // launch_range_sort_buckets), with the frame's range span folded on the device: queued whole behind the totals' copy.
+    const bool buckets = lg::range_sort_buckets_ok((size_t)P);
+    if (buckets) {
+        lg::launch_range_sort_buckets(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, geom.scratch, geom.totals + LG_TOTALS_KEYSPAN_WORD, span_tail, stream);
+        ids_sorted = geom.id_a;
+        LG_STAGE_CHECK("range sort");
+        g_prof.mark("range_sort", stream);
+    } else if (enqueue_only) {                                         // no host read: all 31 bits of the raw key
         const int side = lg::launch_radix_sort_pairs(geom.key_a, geom.key_b, geom.id_a, geom.id_b, (size_t)P, 31, geom.scratch, stream,
                                                      range_sort_bits(), nullptr, lg::SORT_MAX_RADIX_BITS, true, span_tail);   // (scratch carved for 11-bit digits; ids = positions)
         ids_sorted = side ? geom.id_b : geom.id_a;
@@ -423,7 +431,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     if (!enqueue_only) {
         uint32_t totals_h[LG_TOTALS_READ_WORDS];                           // the slots of 64-bit instance totals the preprocess filled
         LG_HIP((hipError_t)lg::api_read_words_end(LG_TOTALS_READ_WORDS, totals_h));
-        {   // the rest of the range sort: bits [8, bits of (kmax - kmin + 1)) in passes of at most 9 bits; at least one pass, for the tail
+        if (!buckets) {   // the rest of the range sort: bits [8, bits of (kmax - kmin + 1)) in passes of at most 9 bits; at least one pass, for the tail
             uint32_t kinv = 0u, kmax = 0u;
             for (int slot = 0; slot < LG_INST_SLOTS; slot++) {
                 kinv = std::max(kinv, totals_h[LG_TOTALS_KEYSPAN_WORD + 2 * slot]); kmax = std::max(kmax, totals_h[LG_TOTALS_KEYSPAN_WORD + 2 * slot + 1]);
@@ -980,6 +988,10 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
     }
     return nnames;
 }
+
+#ifdef LG_LANE_STATS
+int lidargs_debug_lane_stats(unsigned long long* out, int reset) { lg::lane_stats_read(out, reset); return 16; }
+#endif
 
 int lidargs_last_counters(long long* out, int n) {
     if (g_counters[1] < 0 && g_last_totals_dev && g_counters[0] > 0) {

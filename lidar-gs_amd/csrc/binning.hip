@@ -115,11 +115,43 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t
 // capacity `n` and the blocks behind *n_dev see no keys (their histograms are zero, their scatter retires).
 // The value a pass takes its digit from: the key itself, or (range sort with a bias) key - kmin with the culled key 0xFFFFFFFF mapped
 // just above the largest valid one.
+// Third form (round 5, the MSD pass of the bucketed range sort below): the digit is the key's LINEAR range bucket,
+//     digit = min(BINS - 2, (uint)((range - rmin) * (BINS - 1) / (rmax - rmin))),     culled key -> BINS - 1,
+// with rmin / rmax folded by every block from the slots the preprocess left on the device (no host knowledge).  Monotone in the key
+// (fp32 subtraction, multiplication and truncation are), so the buckets partition the frame's range order.
 struct KeyMap {
     uint32_t kmin, cull; bool on;                                      // by value in the kernel arguments (host-side: KeyBias)
+    const uint32_t* lin_span;                                          // non-NULL: linear buckets; [LG_INST_SLOTS][2] = (~smallest, largest) visible key
     __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return on ? (k == 0xFFFFFFFFu ? cull : k - kmin) : k; }
 };
-static inline KeyMap key_map(const KeyBias* b) { KeyMap m; m.on = b != nullptr; m.kmin = b ? b->kmin : 0u; m.cull = b ? b->cull : 0xFFFFFFFFu; return m; }
+static inline KeyMap key_map(const KeyBias* b) {
+    KeyMap m; m.on = b != nullptr && b->lin_span == nullptr; m.kmin = b ? b->kmin : 0u; m.cull = b ? b->cull : 0xFFFFFFFFu; m.lin_span = b ? b->lin_span : nullptr;
+    return m;
+}
+struct LinMap { float rmin, scale; uint32_t kmin, kmax; };
+// every wave folds the 64 slots itself (two loads per lane, twelve shuffles): no launch, no LDS, no host
+__device__ __forceinline__ LinMap lin_map_load(const uint32_t* __restrict__ span, int lane, int bins) {
+    uint32_t kinv = span[2 * (lane & (LG_INST_SLOTS - 1))], kmx = span[2 * (lane & (LG_INST_SLOTS - 1)) + 1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, o)); kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o)); }
+    LinMap m;
+    m.kmin = ~kinv; m.kmax = kmx;
+    if (m.kmax < m.kmin) { m.kmin = 0u; m.kmax = 0u; }                 // no visible Gaussian: every key is the culled one
+    m.rmin = __uint_as_float(m.kmin);
+    const float w = __uint_as_float(m.kmax) - m.rmin;
+    m.scale = w > 0.f ? (float)(bins - 1) / w : 0.f;
+    return m;
+}
+template <int BINS>
+__device__ __forceinline__ uint32_t lin_digit(const LinMap& m, uint32_t k) {
+    if (k == 0xFFFFFFFFu) return (uint32_t)(BINS - 1);
+    const float x = (__uint_as_float(k) - m.rmin) * m.scale;
+    return min((uint32_t)(BINS - 2), (uint32_t)fmaxf(x, 0.f));
+}
+template <int BINS>
+__device__ __forceinline__ uint32_t key_digit(const KeyMap& km, const LinMap& lin, uint32_t k, int shift) {
+    return km.lin_span ? lin_digit<BINS>(lin, k) : ((km(k) >> shift) & (uint32_t)(BINS - 1));
+}
 
 template <int BITS, int ITEMS, typename KT = uint32_t>
 __global__ void __launch_bounds__(256) k_radix_hist(const KT* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev, int shift,
@@ -136,11 +168,13 @@ __global__ void __launch_bounds__(256) k_radix_hist(const KT* __restrict__ keys,
         k[r] = i < n ? (uint32_t)keys[i] : 0u;
     }
     for (int d = tid; d < BINS; d += 256) cnt[d] = 0;
+    LinMap lin = LinMap();
+    if (km.lin_span) lin = lin_map_load(km.lin_span, lane, BINS);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
-        if (i < n) atomicAdd(&cnt[(km(k[r]) >> shift) & (BINS - 1)], 1u);
+        if (i < n) atomicAdd(&cnt[key_digit<BINS>(km, lin, k[r], shift)], 1u);
     }
     __syncthreads();
     for (int d = tid; d < BINS; d += 256) hist[(size_t)d * nblocks + blockIdx.x] = cnt[d];
@@ -265,6 +299,8 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
         }
     }
     for (int d = lane; d < BINS; d += 64) run[w][d] = 0;
+    LinMap lin = LinMap();
+    if (km.lin_span) lin = lin_map_load(km.lin_span, lane, BINS);
     __syncthreads();
     LG_PHASE_CLK(1);                                  // keys requested, digit bases scanned
 
@@ -273,7 +309,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const bool valid = base + (size_t)r * 64 + lane < n;
-        const uint32_t d = (km(k[r]) >> shift) & (BINS - 1);
+        const uint32_t d = key_digit<BINS>(km, lin, k[r], shift);
         // peers = the lanes holding the same digit: for every digit bit, keep the lanes whose bit equals mine.  With `mine` = the bit
         // spread over a word (0 / ~0), that is peers & ~(ballot ^ mine) -- ONE v_bitop3_b32 per 32 lanes and bit on gfx950
         // (truth table 0x90 = a & ~(b ^ c)) instead of a select, an xor and an and.
@@ -330,7 +366,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         if (base + (size_t)r * 64 + lane < n) {
-            const uint32_t d = (km(k[r]) >> shift) & (BINS - 1);
+            const uint32_t d = key_digit<BINS>(km, lin, k[r], shift);
             const uint32_t p = run[w][d] + pos[r];
             s_key[p] = k[r]; s_val[p] = v[r];
         }
@@ -343,7 +379,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
     if (tail.mode == 0) {
         for (uint32_t i = tid; i < count; i += 256) {
             const uint32_t kk = s_key[i];
-            const uint32_t d = (km(kk) >> shift) & (BINS - 1);
+            const uint32_t d = key_digit<BINS>(km, lin, kk, shift);
             const size_t g = (size_t)gbase[d] + (i - dbase[d]);
             keys_out[g] = (KT)kk; vals_out[g] = s_val[i];
         }
@@ -356,7 +392,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
             const uint32_t i = tid + 256u * (uint32_t)r;
             const uint32_t ii = i < count ? i : 0u;
             const uint32_t kk = s_key[ii];
-            const uint32_t d = (km(kk) >> shift) & (BINS - 1);
+            const uint32_t d = key_digit<BINS>(km, lin, kk, shift);
             g[r] = (size_t)gbase[d] + (ii - dbase[d]);
             v[r] = s_val[ii];
         }
@@ -446,14 +482,12 @@ __device__ __forceinline__ unsigned long long small_sort_peers(uint32_t d, bool 
     }
     return ((unsigned long long)phi << 32) | plo;
 }
-template <typename KT = uint32_t>
-__global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n,
-                                                                            const uint32_t* __restrict__ n_dev, int begin_bit, int end_bit, int max_bits,
-                                                                            int vals_are_positions, const RadixTail tail, const KeyMap km) {
-    constexpr int W = SMALL_SORT_WAVES, MAXB = 8, BINS = 1 << MAXB;
-    __shared__ uint32_t cnt[BINS][W + 1];                              // [digit][wave] counts, then bases (+1: no bank conflicts down a column)
-    __shared__ uint32_t wsum[W];
-    if (n_dev) n = min(n, *n_dev);
+// (the body as a device function: the bucketed range sort below runs it on the sub-range of a bucket too big for its LDS path)
+template <typename KT = uint32_t, int W = SMALL_SORT_WAVES>
+__device__ __forceinline__ void wg_radix_sort(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n, int begin_bit, int end_bit, int max_bits,
+                                              int vals_are_positions, const RadixTail tail, const KeyMap km,
+                                              uint32_t (*cnt)[W + 1], uint32_t* wsum) {
+    constexpr int MAXB = 8, BINS = 1 << MAXB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t per = ((n + W - 1) / W + 63u) & ~63u;               // keys per wave, whole rounds
     const uint32_t lo = min(n, (uint32_t)w * per), hi = min(n, lo + per);
@@ -590,6 +624,16 @@ __global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* 
     }
 }
 
+template <typename KT = uint32_t>
+__global__ void __launch_bounds__(64 * SMALL_SORT_WAVES) k_radix_sort_small(KT* key_a, KT* key_b, uint32_t* val_a, uint32_t* val_b, uint32_t n,
+                                                                            const uint32_t* __restrict__ n_dev, int begin_bit, int end_bit, int max_bits,
+                                                                            int vals_are_positions, const RadixTail tail, const KeyMap km) {
+    __shared__ uint32_t cnt[256][SMALL_SORT_WAVES + 1];                // [digit][wave] counts, then bases (+1: no bank conflicts down a column)
+    __shared__ uint32_t wsum[SMALL_SORT_WAVES];
+    if (n_dev) n = min(n, *n_dev);
+    wg_radix_sort<KT>(key_a, key_b, val_a, val_b, n, begin_bit, end_bit, max_bits, vals_are_positions, tail, km, cnt, wsum);
+}
+
 template <int BITS, typename KT>
 static void radix_pass(const KT* kin, const uint32_t* vin, KT* kout, uint32_t* vout, size_t n, const uint32_t* n_dev, int shift,
                        uint32_t* scratch, hipStream_t s, int scratch_bits, const RadixTail& tail, const KeyBias* bias) {
@@ -672,6 +716,202 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
 int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit, uint32_t* scratch, hipStream_t s,
                               const uint32_t* n_dev) {
     return radix_sort_pairs_t<uint16_t>(key_a, key_b, val_a, val_b, n, end_bit, scratch, s, SORT_RADIX_BITS, n_dev, 0, false, RadixTail(), 0, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bucketed range sort of the P Gaussians (round 5).  The LSD sort above moves all P pairs through HBM once per 8-9 key bits: three
+// passes, nine launches, 107 us of the 2 M-Gaussian frame for 48 MB of necessary traffic.  Here:
+//   1. ONE stable scatter pass (the LSD pass's three launches, with the linear range bucket as the digit: KeyMap::lin_span) cuts the frame
+//      into BUCKET_BINS consecutive range intervals of equal WIDTH -- for surfaces seen from the sensor the count per interval varies
+//      by a small factor over the frame's span, where equal intervals of the key's BITS (an MSD digit) would vary a thousandfold
+//      between 2 m and 80 m;
+//   2. one launch sorts every bucket COMPLETELY, a 512-thread workgroup per bucket: the pairs in registers, stable 8-bit LSD passes
+//      through LDS on key - (the bucket's smallest key) -- 2 passes for a bucket's 13-16 significant bits at 20-80 m, 3 at 2 m --, then
+//      the ids (and the span records they select: the RadixTail) written at their final places.
+// No host knowledge is needed (the frame's range span is folded on the device), so the whole sort is queued behind the preprocess.
+// A bucket with more than BSORT_CAP pairs (a frame whose Gaussians crowd into a thousandth of its range span) is sorted by the same
+// workgroup through global memory (wg_radix_sort on the bucket's sub-range): correct, slower.  The culled Gaussians (key 0xFFFFFFFF) are
+// the last bucket: all keys equal, nothing to sort.
+constexpr int BUCKET_BITS = 10, BUCKET_BINS = 1 << BUCKET_BITS;
+constexpr int BSORT_WAVES = 8, BSORT_ITEMS = 14, BSORT_CAP = 64 * BSORT_WAVES * BSORT_ITEMS;   // 7168 pairs per bucket on the LDS path (66 KB of LDS: two workgroups per CU)
+constexpr uint32_t BSORT_CULL_SLICE = 4096;                              // culled Gaussians written per workgroup of the launch's tail
+constexpr size_t BUCKET_SORT_MAX = (size_t)4 << 20;                    // beyond: the plain LSD passes (buckets of 4 k pairs on average would leave the LDS path no room)
+
+// (its own function, not inlined: the rare path's registers must not count against the LDS path's occupancy)
+__device__ __attribute__((noinline)) void bucket_sort_slow(uint32_t* ka, uint32_t* kb, uint32_t* va, uint32_t* vb, uint32_t n, int bits, uint32_t kmn,
+                                                           uint32_t (*cnt)[BSORT_WAVES + 1], uint32_t* wsum) {
+    KeyMap km; km.kmin = kmn; km.cull = 0u; km.on = true; km.lin_span = nullptr;
+    wg_radix_sort<uint32_t, BSORT_WAVES>(ka, kb, va, vb, n, 0, bits, 8, 0, RadixTail(), km, cnt, wsum);
+}
+__global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) k_bucket_sort(uint32_t* keys, uint32_t* ids, uint32_t* key_tmp, uint32_t* id_tmp,
+                                                                       const uint32_t* __restrict__ tot, uint32_t* ids_out, const RadixTail tail, const uint32_t P) {
+    constexpr int W = BSORT_WAVES, ITEMS = BSORT_ITEMS, BINS = 256;
+    if (blockIdx.x >= (unsigned)(BUCKET_BINS - 1)) {
+        // the culled Gaussians (the last bucket, the frame's last positions): nothing to sort and no record to gather -- "no instances" at
+        // every position, a slice per workgroup (they can be most of a frame: one workgroup walking them all would be the launch's length)
+        const uint32_t nc = tot[BUCKET_BINS - 1], first = P - nc;
+        const uint32_t lo = (blockIdx.x - (unsigned)(BUCKET_BINS - 1)) * BSORT_CULL_SLICE, hi = min(nc, lo + BSORT_CULL_SLICE);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 64 * W) {
+            ids_out[first + i] = ids[first + i];
+            if (tail.mode == 1) static_cast<uint32_t*>(tail.dst)[first + i] = 0xFFFFFFFFu;          // span_pack's "no instances"
+            else if (tail.mode == 2) static_cast<uint2*>(tail.dst)[first + i] = make_uint2(0u, 0u);   // an empty column span
+        }
+        return;
+    }
+    __shared__ uint32_t s_key[BSORT_CAP];
+    __shared__ uint32_t s_val[BSORT_CAP];
+    __shared__ uint32_t cnt[BINS][W + 1];
+    __shared__ uint32_t wsum[W];
+    __shared__ uint32_t s_red[3][W];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned d = blockIdx.x;
+    const uint32_t n = tot[d];
+    if (n == 0) return;                                                // (uniform over the workgroup)
+    // the bucket's first position: the sum of the totals in front of it (at most one per thread)
+    uint32_t part = 0u;
+    for (unsigned j = (unsigned)tid; j < d; j += 64 * W) part += tot[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const bool fits = n <= (uint32_t)BSORT_CAP;
+    // the pairs, in (wave, round, lane) = key order, and the bucket's smallest / largest key
+    const uint32_t per = ((n + W - 1) / W + 63u) & ~63u;               // pairs per wave, whole rounds (LDS path)
+    const uint32_t lo = min(n, (uint32_t)w * per), hi = min(n, lo + per);
+    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+    if (lane == 0) s_red[0][w] = part;
+    __syncthreads();
+    uint32_t start = 0;
+#pragma unroll
+    for (int q = 0; q < W; q++) start += s_red[0][q];
+    uint32_t k[ITEMS], v[ITEMS];
+    if (fits) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t i = lo + (uint32_t)r * 64u + lane;
+            const bool valid = i < hi;
+            k[r] = valid ? keys[start + i] : 0u; v[r] = valid ? ids[start + i] : 0u;
+            if (valid) { kmn = min(kmn, k[r]); kmx = max(kmx, k[r]); }
+        }
+    } else {
+        for (uint32_t i = tid; i < n; i += 64 * W) { const uint32_t kk = keys[start + i]; kmn = min(kmn, kk); kmx = max(kmx, kk); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, o)); kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o)); }
+    if (lane == 0) { s_red[1][w] = kmn; s_red[2][w] = kmx; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < W; q++) { kmn = min(kmn, s_red[1][q]); kmx = max(kmx, s_red[2][q]); }
+    const uint32_t span = kmx - kmn;
+    const int bits = span ? 32 - __builtin_clz(span) : 0;              // significant bits of key - kmn (0: all keys equal -- the culled bucket)
+    const uint32_t* sorted_ids = ids + start;                          // where the bucket's ids stand in final order (global memory), unless `in_lds`
+    bool in_lds = false;
+    if (bits > 0 && !fits) {
+        bucket_sort_slow(keys + start, key_tmp + start, ids + start, id_tmp + start, n, bits, kmn, cnt, wsum);   // brings the pairs home
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else if (bits > 0) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int passes = (bits + 7) / 8;
+        int shift = 0;
+        for (int pass = 0; pass < passes; pass++) {
+            const int left = bits - shift, pl = passes - pass;
+            const int pb = (left + pl - 1) / pl;                       // the remaining bits split evenly over the remaining passes
+            const uint32_t mask = (1u << pb) - 1u;
+            for (int i = tid; i < BINS * (W + 1); i += 64 * W) (&cnt[0][0])[i] = 0u;
+            __syncthreads();
+            uint32_t pos[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                if ((uint32_t)r * 64u >= per) break;                   // (wave-uniform)
+                const bool valid = lo + (uint32_t)r * 64u + lane < hi;
+                const uint32_t dg = valid ? ((k[r] - kmn) >> shift) & mask : 0u;
+                const unsigned long long peers = small_sort_peers(dg, valid);
+                const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                pos[r] = valid ? cnt[dg][w] + rank : 0u;               // one wave owns its column: LDS operations in program order
+                __builtin_amdgcn_wave_barrier();
+                if (valid && rank == 0) cnt[dg][w] += (uint32_t)__popcll(peers);
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            {   // exclusive scan, digit-major then wave-major: thread t owns 4 consecutive (digit, wave) cells
+                constexpr int PER = BINS * W / (64 * W);
+                uint32_t c[PER], tsum = 0;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { const int cell = tid * PER + q; c[q] = cnt[cell / W][cell % W]; tsum += c[q]; }
+                const uint32_t inc = wave_incl_scan(tsum, lane);
+                if (lane == 63) wsum[w] = inc;
+                __syncthreads();
+                uint32_t off = inc - tsum;
+                for (int q = 0; q < w; q++) off += wsum[q];
+#pragma unroll
+                for (int q = 0; q < PER; q++) { const int cell = tid * PER + q; cnt[cell / W][cell % W] = off; off += c[q]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                if ((uint32_t)r * 64u >= per) break;
+                if (lo + (uint32_t)r * 64u + lane < hi) {
+                    const uint32_t dg = ((k[r] - kmn) >> shift) & mask;
+                    const uint32_t p = cnt[dg][w] + pos[r];
+                    s_key[p] = k[r]; s_val[p] = v[r];
+                }
+            }
+            __syncthreads();
+            shift += pb;
+            if (pass + 1 < passes) {
+#pragma unroll
+                for (int r = 0; r < ITEMS; r++) {
+                    if ((uint32_t)r * 64u >= per) break;
+                    const uint32_t i = lo + (uint32_t)r * 64u + lane;
+                    if (i < hi) { k[r] = s_key[i]; v[r] = s_val[i]; }
+                }
+                __syncthreads();                                       // (cnt and the LDS arrays are rewritten by the next pass)
+            }
+        }
+        in_lds = true;
+    }
+    // the ids at their final places, and the record each selects (the RadixTail: the spans in range order)
+    for (uint32_t i0 = tid; i0 < n; i0 += 4 * 64 * W) {
+        uint32_t g[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t i = min(i0 + (uint32_t)q * 64u * W, n - 1u); g[q] = in_lds ? s_val[i] : sorted_ids[i]; }
+        if (tail.mode == 1) {
+            uint32_t x[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = static_cast<const uint32_t*>(tail.src)[g[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) { ids_out[start + i] = g[q]; static_cast<uint32_t*>(tail.dst)[start + i] = x[q]; } }
+        } else if (tail.mode == 2) {
+            uint4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = static_cast<const uint4*>(tail.src)[g[q]];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) { ids_out[start + i] = g[q]; static_cast<uint2*>(tail.dst)[start + i] = make_uint2(x[q].y, x[q].x); } }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) ids_out[start + i] = g[q]; }
+        }
+    }
+}
+
+// LIDARGS_RANGE_SORT_BUCKETS=0: the LSD passes again (A/B, tests)
+bool range_sort_buckets_ok(size_t P) {
+    static const bool on = [] { const char* e = getenv("LIDARGS_RANGE_SORT_BUCKETS"); return !e || atoi(e) != 0; }();
+    static const size_t small_max = [] { const char* e = getenv("LIDARGS_SMALL_SORT_MAX"); const long v = e ? atol(e) : (long)SMALL_SORT_DEFAULT;
+                                         return (size_t)(v < 0 ? 0 : (v > (long)SMALL_SORT_MAX ? (long)SMALL_SORT_MAX : v)); }();
+    static const int small_off = [] { const char* e = getenv("LIDARGS_NO_SMALL_SORT"); return e ? atoi(e) : 0; }();
+    return on && P <= BUCKET_SORT_MAX && (small_off || P > small_max);
+}
+// (key_a, positions) -> ids in range order in id_a, tail.dst = the records of tail.src in range order.  key_b / id_b hold the bucketed
+// pairs; `scratch` as for launch_radix_sort_pairs with scratch_bits = SORT_MAX_RADIX_BITS.  key_span: GeomView totals + LG_TOTALS_KEYSPAN_WORD.
+void launch_range_sort_buckets(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a, uint32_t* id_b, size_t P, uint32_t* scratch, const uint32_t* key_span,
+                               RadixTail tail, hipStream_t s) {
+    if (P == 0) return;
+    KeyBias kb; kb.kmin = 0u; kb.cull = 0xFFFFFFFFu; kb.lin_span = key_span;
+    // (4096-key blocks: with 1024 digits a block's digit runs are 4 keys long, 2 in a half-size block -- every pair a write of its own:
+    //  scatter 36.3 -> 28.7 us, histogram 12.7 -> 10.2 us at 2 M keys)
+    radix_pass_items<BUCKET_BITS, SORT_ITEMS, uint32_t>(key_a, nullptr, key_b, id_b, P, nullptr, 0, scratch, s, SORT_MAX_RADIX_BITS, RadixTail(), &kb);
+    const uint32_t* tot = scratch + ((size_t)1 << SORT_MAX_RADIX_BITS) * sort_blocks(P);       // where the pass left the digit totals (radix_pass_items)
+    const unsigned cull_blocks = (unsigned)((P + BSORT_CULL_SLICE - 1) / BSORT_CULL_SLICE);     // (as many as a frame of culled Gaussians only would need: the others leave at once)
+    hipLaunchKernelGGL(k_bucket_sort, dim3(BUCKET_BINS - 1 + cull_blocks), dim3(64 * BSORT_WAVES), 0, s, key_b, id_b, key_a, id_a, tot, id_a, tail, (uint32_t)P);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -309,6 +309,9 @@ struct PreprocessParams {
                                          // enqueue-only rank frames) and are culled before any of their attributes is read
 };
 
+#ifdef LG_LANE_STATS
+void lane_stats_read(unsigned long long* out, int reset);              // render.hip (instrumented builds only: tools/lane_stats.py)
+#endif
 // helpers exported by api.hip for the other entry-point files
 int api_fail(int code, const char* msg);
 int api_check_launch(hipStream_t s, int debug, const char* what);
@@ -383,7 +386,7 @@ struct RadixTail { const void* src = nullptr; void* dst = nullptr; int mode = 0;
 // bias (nullable): the passes sort on key - bias->kmin, with 0xFFFFFFFF (a culled Gaussian) mapped to bias->cull, so that end_bit only
 // has to cover the frame's key SPAN.  With kmin a multiple of 256 the low byte of key - kmin is the key's own low byte: a first pass
 // over bits [0, 8) needs no bias and can be queued before the host knows the span.
-struct KeyBias { uint32_t kmin, cull; };
+struct KeyBias { uint32_t kmin, cull; const uint32_t* lin_span = nullptr; };   // lin_span (device, binning.hip KeyMap): linear range buckets instead
 int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit,
                             uint32_t* scratch, hipStream_t s, int max_bits = 0, const uint32_t* n_dev = nullptr, int scratch_bits = 0,
                             bool vals_are_positions = false,    // true: the values are 0..n-1 and val_a is never read
@@ -400,7 +403,12 @@ void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, in
                         uint32_t* zero = nullptr, int n_zero = 0, bool prezeroed = false);
 int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a, uint32_t* val_b, size_t n, int end_bit, uint32_t* scratch, hipStream_t s,
                               const uint32_t* n_dev = nullptr);
-int radix_sort_result_side(size_t n, int end_bit);   // side the two functions above (default digit width, no tail) leave the result on
+int radix_sort_result_side(size_t n, int end_bit);
+// the range sort of the P Gaussians as one bucket pass + one launch that sorts every bucket completely (binning.hip): ids in range order
+// -> id_a, the tail's records in range order -> tail.dst; no host knowledge needed.  `ok`: P is in the range this form is used for.
+bool range_sort_buckets_ok(size_t P);
+void launch_range_sort_buckets(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a, uint32_t* id_b, size_t P, uint32_t* scratch, const uint32_t* key_span,
+                               RadixTail tail, hipStream_t s);   // side the two functions above (default digit width, no tail) leave the result on
 
 #ifdef __HIPCC__
 // blockIdx -> (patch, segment): segment-fastest, with S ODD.  Workgroups are dealt round-robin to the 8 XCDs (b % 8) and

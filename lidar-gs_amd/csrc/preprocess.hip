@@ -605,7 +605,11 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const int base = region * LG_REGION;
     if (base >= a.P) return;
     const int cnt = (int)a.tcount[region];
-    for (int j = lane; j < cnt; j += 64) gb_row(a, base + (int)a.tlist[base + j]);
+    int off = (int)a.tlist[base + lane];                               // with the count, not behind it (the list is padded: any slot may be read)
+    for (int j = lane; j < cnt; j += 64) {
+        gb_row(a, base + off);
+        if (j + 64 < cnt) off = (int)a.tlist[base + j + 64];
+    }
 }
 
 // First launch of every backward, one thread per Gaussian, one block per region of LG_REGION:

@@ -41,6 +41,26 @@ namespace lg {
 
 #define LG_CHUNK 64
 
+// Lane statistics of the walks (tools/lane_stats.py; compiled in with -DLG_LANE_STATS only, the product build has none): per walked
+// entry, how many of the wave's 64 pixels take it, and how many of its four 16-pixel rows hold one that does.
+#ifdef LG_LANE_STATS
+__device__ unsigned long long lg_lane_stats[16];
+__device__ __forceinline__ void lane_stat(int base, unsigned long long m) {
+    if (threadIdx.x % 64 == 0) {
+        const int rows = ((m & 0xFFFFull) != 0) + ((m & 0xFFFF0000ull) != 0) + ((m & 0xFFFF00000000ull) != 0) + ((m >> 48) != 0);
+        atomicAdd(&lg_lane_stats[base], 1ull); atomicAdd(&lg_lane_stats[base + 1], (unsigned long long)__popcll(m));
+        atomicAdd(&lg_lane_stats[base + 2], (unsigned long long)rows); atomicAdd(&lg_lane_stats[base + 3], m ? 1ull : 0ull);
+    }
+}
+void lane_stats_read(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lg_lane_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lg_lane_stats), z, sizeof z); }
+}
+#define LG_LANE_STAT(base, m) lane_stat(base, m)
+#else
+#define LG_LANE_STAT(base, m) do { } while (0)
+#endif
+
 // (u1-part, u2-part) pairs: the splat record interleaves the two tangent directions so that everything the two projections
 // share is one packed-fp32 operation (v_pk_fma_f32 / v_pk_mul_f32) on adjacent registers, without moves to pair them up.
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -233,6 +253,7 @@ __device__ __forceinline__ void walk_T_only_v2(const int cnt, const float4* s_re
         const float alpha = fminf(0.99f, r.op * __expf(pw));
         const bool hit = alpha >= 1.0f / 255.0f;
         hitmask = __ballot(hit);
+        LG_LANE_STAT(0, hitmask);
         return hit ? 1.f - alpha : 1.f;
     };
     float T = w.T;
@@ -317,6 +338,7 @@ __device__ __forceinline__ void walk_full_v2(const int cnt, const float4* s_rec,
         const float wt = ok ? a * Tw : 0.f;
         C01 += v2f{r.r3.z, r.r3.w} * wt; D += r.r3.x * wt;             // :615-617
         const bool blended = wt > 0.f;
+        LG_LANE_STAT(4, __ballot(blended));
         last = blended ? __float_as_uint(r.r3.y) : last;
         Tw = ok ? test : -fabsf(Tw);
         if (TRACK) {
@@ -1125,6 +1147,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
             const float G = __expf(pw);
             const float alpha_raw = fminf(0.99f, op * G);
             const bool contrib = alpha_raw >= 1.0f / 255.0f;
+            LG_LANE_STAT(8, __ballot(contrib));
             if (__ballot(contrib) != 0ull) {                           // wave-uniform
                 // A pixel that does not blend this entry treats it as an alpha = 0 entry: T / (1 - 0) = T, the "colour
                 // behind" recurrences commit the previous entry (the same operation, just earlier) and then carry

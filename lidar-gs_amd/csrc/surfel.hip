@@ -930,7 +930,11 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const int base = region * LG_REGION;
     if (base >= a.P) return;
     const int cnt = (int)a.tcount[region];
-    for (int j = lane; j < cnt; j += 64) sf_gb_row(a, base + (int)a.tlist[base + j]);
+    int off = (int)a.tlist[base + lane];                               // with the count, not behind it (the list is padded)
+    for (int j = lane; j < cnt; j += 64) {
+        sf_gb_row(a, base + off);
+        if (j + 64 < cnt) off = (int)a.tlist[base + j + 64];
+    }
 }
 
 __device__ __forceinline__ void sf_gb_row(const SfGaussBwdArgs& a, const int idx) {

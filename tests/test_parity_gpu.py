@@ -52,6 +52,44 @@ def test_forward_backward_matches_oracle(case, hip_lib_built):
     _compare_all(hip, ref, GRAD_KEYS_SR)
 
 
+RANGE_SORT_CASES = ["duplicate_ranges", "crowded_bucket", "one_bucket", "two_ranges_only", "mostly_culled"]
+
+
+@pytest.mark.parametrize("case", RANGE_SORT_CASES)
+def test_bucketed_range_sort_on_inputs_built_against_it(case, hip_lib_built):
+    """The range sort of frames above 4096 Gaussians is one bucket pass on the LINEAR range + one launch that finishes every bucket in LDS
+    (binning.hip, round 5).  The per-tile order it must produce is (range bits, index) -- R3/cr/rasterizer_impl.cu:103-106, :317-322 -- and
+    every pixel of the image depends on it.  Inputs built against it: thousands of Gaussians at bit-identical ranges (the stable order
+    among equal keys is the index order), a bucket far over the LDS path's 7168 pairs (20 000 Gaussians inside 2 cm of range beside two
+    outliers that stretch the span: sorted through global memory by one workgroup), every Gaussian in ONE bucket at one identical range,
+    a span with only two distinct keys, and a frame whose Gaussians are mostly culled (the last bucket: the launch's tail of slices)."""
+    H, W, seed = 16, 512, 71
+    rng = np.random.default_rng(seed)
+    scene = sc.make_scene("shell", 30_000 if case != "crowded_bucket" else 24_000, H, seed, random_view=False)
+    m = scene["means3D"].astype(np.float64)
+    r = np.linalg.norm(m, axis=1, keepdims=True)
+    if case == "duplicate_ranges":
+        # ranges snapped to 40 values: points in the x-y plane direction scaled so that |p| (fp32, as the kernel evaluates it) repeats
+        target = np.round(r / 1.5) * 1.5 + 3.0
+        m = m / r * target
+    elif case == "crowded_bucket":
+        target = 20.0 + rng.uniform(0.0, 0.02, size=r.shape)
+        m = m / r * target
+        m[0] = m[0] / np.linalg.norm(m[0]) * 2.5; m[1] = m[1] / np.linalg.norm(m[1]) * 78.0
+    elif case == "one_bucket":
+        m = m / r * 17.0
+    elif case == "two_ranges_only":
+        m = m / r * np.where(rng.random(r.shape) < 0.5, 9.0, 31.0)
+    elif case == "mostly_culled":
+        m = m / r * np.where(rng.random(r.shape) < 0.8, 200.0, r)          # 80 % behind lidar_far
+    scene["means3D"] = m.astype(np.float32)
+    scene["opacities"] = (scene["opacities"] * np.float32(0.25)).astype(np.float32)     # deep lists stay unsaturated: the order shows in every pixel
+    grads = sc.upstream_grads(H, W, seed)
+    ref = oracle_forward_backward(scene, W, H, grads)
+    hip = hip_forward_backward(scene, W, H, grads)
+    _compare_all(hip, ref, GRAD_KEYS_SR)
+
+
 def test_cov3d_precomp_path(hip_lib_built):
     """cov3D_precomp instead of scales/rotations (R3/cr/forward.cu:307-310, backward :520)."""
     P, H, W, seed = 5_000, 16, 512, 5
@@ -168,10 +206,12 @@ print("OK")
                                  {"LIDARGS_FUSED": "0"}, {"LIDARGS_FUSED_WAVES": "4"}, {"LIDARGS_FUSED_WAVES": "16"},
                                  {"LIDARGS_FUSED": "1", "LIDARGS_SEG_LEN": "128", "LIDARGS_MAX_SEGMENTS": "33"}, {"LIDARGS_FUSED": "0", "LIDARGS_HEAD": "1"},
                                  {"LIDARGS_TILE_KEY32": "1"}, {"LIDARGS_NO_SMALL_SORT": "1"}, {"LIDARGS_RANGE_SORT_FULL": "1"},
-                                 {"LIDARGS_FUSED": "0", "LIDARGS_WORK_LISTS": "0"}, {"LIDARGS_SMALL_SORT_MAX": "16384"}, {}],
+                                 {"LIDARGS_FUSED": "0", "LIDARGS_WORK_LISTS": "0"}, {"LIDARGS_SMALL_SORT_MAX": "16384"}, {"LIDARGS_RANGE_SORT_BUCKETS": "0"},
+                                 {"LIDARGS_RANGE_SORT_BUCKETS": "0", "LIDARGS_RANGE_SORT_FULL": "1"}, {}],
                          ids=["head5", "head2_rounds26", "nohead_seg128", "pass2_groups_of_3", "sort_blocks_4096", "sort_digits_11",
                               "five_launch_forward", "fused_4_waves", "fused_16_waves", "fused_on_128_entry_segments", "unfused_head",
-                              "tile_keys_32_bit", "no_single_launch_sort", "range_sort_all_31_bits", "backward_on_the_slot_grid", "single_launch_sort_up_to_16k", "defaults"])
+                              "tile_keys_32_bit", "no_single_launch_sort", "range_sort_all_31_bits", "backward_on_the_slot_grid", "single_launch_sort_up_to_16k",
+                              "range_sort_lsd_passes", "range_sort_lsd_all_31_bits", "defaults"])
 def test_plan_variants_are_invisible(env, hip_lib_built):
     """The segment plan is an internal choice too: round 1 as the complete walk of the list heads (what the big frames take by default:
     k_render_pass2_grouped<true>, here forced onto the 64-entry plan with heads of 5 and 2 segments), pass 2 over groups of segments
