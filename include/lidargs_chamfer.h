@@ -29,6 +29,18 @@ int lidargs_chamfer_backward(int B, int n, int m, const float* xyz1, const float
                              const float* grad_dist2, const int* idx1, const int* idx2, float* grad_xyz1, float* grad_xyz2,
                              void* stream);
 
+/* PointsMeter.update on the device (/root/reference/utils/lidar_utils.py:253-282: the evaluation metric of train.py:354-372).  The reference
+ * moves both range images to the host, back-projects their non-empty pixels with numpy (pano_to_lidar, :171-232), uploads the two clouds
+ * for the chamfer kernel and reads means and the F-score (extern/fscore.py:4-18) off the result.  Here: pred, truth f32[H*W] device-resident
+ * range images (divided by `scale` as the reference does, :255-256), beam_inclinations f32[H] on the device (ascending, as everywhere) or NULL
+ * for the (fov_up, fov) intrinsics in degrees (:193-195); out f32[6] on the device = (dist1.mean() + dist2.mean(), F-score, precision,
+ * recall, points of the prediction, points of the truth) at squared-distance `threshold` (the reference's 0.05).  An empty cloud gives the
+ * reference's NaN means and an F-score of 0.  Nothing is read back: the clouds' sizes stay on the device.  scratch:
+ * lidargs_points_meter_scratch_bytes(H, W) bytes of device memory. */
+size_t lidargs_points_meter_scratch_bytes(int H, int W);
+int lidargs_points_meter(int H, int W, const float* pred, const float* truth, float scale, const float* beam_inclinations, float fov_up,
+                         float fov, float threshold, float* out, char* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

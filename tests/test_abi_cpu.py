@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(hip_lib_built):
     names = _declared_functions()
     assert {"lidargs_forward", "lidargs_backward", "lidargs_visible_filter", "lidargs_mark_visible", "lidargs_forward_shell",
             "lidargs_render_shell", "lidargs_backward_shell", "lidargs_last_error", "lidargs_abi_version", "lidargs_ng_forward_select",
-            "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_surfel_forward", "lidargs_shell_select", "lidargs_image_loss", "lidargs_scaling_reg", "lidargs_chamfer_forward", "lidargs_chamfer_backward"} <= set(names)
+            "lidargs_ng_forward_decode", "lidargs_ng_backward", "lidargs_surfel_forward", "lidargs_shell_select", "lidargs_image_loss", "lidargs_scaling_reg", "lidargs_chamfer_forward", "lidargs_chamfer_backward", "lidargs_points_meter"} <= set(names)
     lib = ctypes.CDLL(hip_lib_built)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
