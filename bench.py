@@ -118,27 +118,37 @@ def reference_dataflow_bytes(P, V, R_ref, N, T):
     return fwd, bwd, 68 * R_ref + 24 * N, 68 * R_ref + 24 * N + 84 * V
 
 
-def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None, tile_key_bytes=2):
+def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None, tile_key_bytes=2, touched=None, bwd_entries=None):
     """ALGORITHMIC bytes of each launch in ITS OWN units: R = the instances this frame binned (R'),
     V = visible Gaussians, N = pixels.  rec = bytes gathered per list entry (id 4 + record 64/80 + row span 4), pix = per-pixel
     planes.  `stage` = the lidargs_profile stage that brackets the launch(es); `launches` = launches inside that stage.
-    The blends are priced on `taken` = the (16x4 patch, instance) pairs some pixel really takes (the contribution flags pass 1
+    The FORWARD blends are priced on `taken` = the (16x4 patch, instance) pairs some pixel really takes (the contribution flags pass 1
     writes, counted on the host after the timed region): every correct blend must fetch each of them once, while the
     instances BEHIND a patch's saturation point are never needed -- pricing those (R') made a launch that rightly skips them
-    look faster than the memory system (r02_a: cfg4 1.9 'of peak')."""
+    look faster than the memory system (r02_a: cfg4 1.9 'of peak').  Round 5: the BACKWARD blend is priced on `bwd_entries` = the list
+    entries it gathers (per patch and segment the flagged entries in front of the last blended one: lidargs_last_counters[9], counted by
+    a diagnostic launch of the same selection) -- pass 1's flags restart from T = 1 in every segment and are a superset three times that
+    size (round 4: the launch's counter traffic was 0.58 of bytes priced on them) -- and on `touched` = the Gaussians whose packed
+    gradient line it can add to; the per-Gaussian backward likewise on the touched ones plus the zero rows of everybody."""
     Rb = taken if taken else R                      # no flags (single-segment frames): every binned instance is walked
+    Eb = bwd_entries if (bwd_entries and bwd_entries > 0) else Rb
+    Tg = touched if (touched is not None and touched >= 0) else V
     rec = 88 if surfel else 68                                  # 3-D: SURVEY 8d's 68 B/instance (id + 64-B record; the row span rides in it)
     pix_f = 56 if surfel else 24                                # surfel: 2 + 7 output planes, 3 accum planes, 2 count planes
-    acc = 128 if surfel else 84                                 # per visible Gaussian: the raster-gradient line the backward blend fills
+    line = 128 if surfel else 64                                # the packed gradient line the backward blend adds into, per touched Gaussian
     pin = 40 if surfel else 44
+    rows = 68                                                   # gradient rows every Gaussian receives (3-D: 3+4+2+1+3+4 floats; surfel: 4+4+3+2+1+2 + the depth)
     kb = tile_key_bytes                                         # 2 when the frame has <= 65536 tiles (every BASELINE size), else 4
+    bucketed = 4096 < P <= (4 << 20)                            # binning.hip range_sort_buckets_ok
     t = [
         dict(kernel="k_sf_preprocess" if surfel else "k_preprocess", stage="preprocess", launches=1, bound="hbm",
-             bytes=(pin + 36 + (128 if surfel else 64)) * P + (88 if surfel else 76) * V,
-             units=f"{pin} B in + 36 B (radii, radii_xy, key, id, spans) out + the {128 if surfel else 64}-B gradient line it zeroes per Gaussian, + record / row span / colours per visible one"),
-        dict(kernel="range sort of the Gaussians (hist + prefix + scatter per pass; the last pass gathers the span records)", stage="range_sort",
-             launches="3 per pass", bound="hbm", bytes=4 * 20 * P + 8 * P,
-             units="per pass 4 B key read by the histogram + 8 B pair read + 8 B pair written per Gaussian (priced at 4 passes), + the span gather of the last one"),
+             bytes=(pin + 37) * P + (88 if surfel else 76) * V,
+             units=f"{pin} B in + 37 B (radii, radii_xy, key, id, spans, the touched mark) out per Gaussian, + record / row span / colours per visible one"),
+        dict(kernel="range sort of the Gaussians (" + ("one linear-bucket pass: hist + prefix + scatter, + one launch that sorts every bucket in LDS and gathers the span records" if bucketed
+                                                        else "hist + prefix + scatter per pass; the last pass gathers the span records") + ")", stage="range_sort",
+             launches=4 if bucketed else "3 per pass", bound="hbm", bytes=(36 * P) if bucketed else (4 * 20 * P + 8 * P),
+             units=("bucket pass: 4 B key read by the histogram + 4 B key read + 8 B pair written; bucket sort: 8 B pair read, 4 B id + 4 B span record written, 4 B span gathered = 36 B per Gaussian" if bucketed
+                    else "per pass 4 B key read by the histogram + 8 B pair read + 8 B pair written per Gaussian (priced at 4 passes), + the span gather of the last one")),
         dict(kernel="span block sums + scan of the block sums (+ the 2-KB totals read-back)", stage="scan+readback", launches=2, bound="hbm", bytes=4 * P,
              units="4 B span record per Gaussian read in range order"),
         dict(kernel="k_emit_instances", stage="emit", launches=1, bound="hbm", bytes=8 * P + (kb + 4) * R,
@@ -149,11 +159,13 @@ def raster_kernel_table(P, V, R, N, stages, surfel=False, taken=None, tile_key_b
              units=f"{kb} B tile key per instance in, 8 B range per tile out"),
         dict(kernel="forward blend group (reference K7): T-only walks + alive + full walk + combine", stage=("render_pass1", "render_pass2", "render_combine"),
              launches="4-7 by plan", bound="hbm", bytes=rec * Rb + pix_f * N, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel (SURVEY 8d K7 on what the frame takes)"),
+        dict(kernel="k_zero_touched", stage="bwd_zero", launches=1, bound="hbm", bytes=(2 + rows) * P + line * Tg,
+             units=f"1 B mark in + 1 B list out + the {rows} B of gradient rows zeroed per Gaussian, + the {line}-B packed line cleared per touched one"),
         dict(kernel="k_sf_render_backward" if surfel else "k_render_backward", stage="render_bwd", launches=1, bound="hbm",
-             bytes=rec * Rb + pix_f * N + acc * V, units=f"{rec} B per taken (patch, instance) pair + {pix_f} B per pixel + {acc} B per visible Gaussian (SURVEY 8d K8 on what the frame takes)"),
+             bytes=rec * Eb + pix_f * N + 2 * line * Tg, units=f"{rec} B per list entry the launch gathers + {pix_f} B per pixel + the {line}-B packed line read and written per touched Gaussian (SURVEY 8d K8 on what the frame blends)"),
         dict(kernel="k_sf_gaussian_backward" if surfel else "k_gaussian_backward", stage="gaussian_bwd", launches=1, bound="hbm",
-             bytes=(pin + 4 + 68) * P + (128 if surfel else 64) * V,
-             units="inputs + radii in, every gradient row somebody receives out per Gaussian (68 B: the covariance / transMat intermediates are not materialised), + the packed gradient line per visible one"),
+             bytes=(pin + line + rows + 1) * Tg + ((4 + 12 + 4) * P if surfel else 0),
+             units=f"per touched Gaussian: {pin} B inputs + the {line}-B packed line in, {rows} B of gradient rows out" + (" ; per surfel: radius + centre in, planar depth out" if surfel else "")),
     ]
     ms = lambda st: sum(stages.get(x, (0.0, 0))[0] for x in (st if isinstance(st, tuple) else (st,)))
     out = []
@@ -197,6 +209,23 @@ def committed_profile(kind, workload):
         if j.get("workload", "cfg3") == workload:
             best = (f, j)
     return best
+
+
+def profile_provenance(kind, workload, basename):
+    """Where a looked-up counter value comes from: the profile file, the build (a content hash of csrc/ + the headers: build_hip.build_id,
+    stamped by the profile tools) and box it was taken on, and this run's build -- a line priced on a profile of another build says so."""
+    prof = committed_profile(kind, workload)
+    if prof is None:
+        return basename
+    f, j = prof
+    here = None
+    try:
+        import build_hip
+        here = build_hip.build_id()
+    except Exception:
+        pass
+    return {"file": os.path.basename(f), "profile_build_id": j.get("build_id"), "box": j.get("box"), "this_build_id": here,
+            "same_build": (j.get("build_id") == here) if (here and j.get("build_id")) else None}
 
 
 def pmc_lookup(kind, workload, kernel_names, field):
@@ -398,9 +427,11 @@ def roofline_object(table, workload, blend_kernels_pmc, ref_flow=None):
     names = blend_kernels_pmc.get(dom["kernel"])
     if names:
         tr, src = pmc_lookup("traffic", workload, names, "hbm_bytes_per_launch_corrected")
-        roof["traffic"], roof["traffic_profile"] = tr, src
+        roof["traffic"], roof["traffic_profile"] = tr, profile_provenance("traffic", workload, src)
         if tr:
             roof["traffic_GBs"] = tr / (dom["ms"] * 1e-3) / 1e9
+            roof["frac_by_counters"] = roof["traffic_GBs"] / HBM_PEAK_GBS      # counter bytes of the committed profile / THIS run's launch time / peak
+            roof["traffic_over_algorithmic"] = tr / dom["bytes"]
         insts, src2 = pmc_lookup("sq", workload, names, "SQ_INSTS_VALU")
         if insts:
             roof["compute"] = valu_roof(names if isinstance(names, list) else names["any_of"], insts, dom["ms"])
@@ -416,6 +447,7 @@ def roofline_object(table, workload, blend_kernels_pmc, ref_flow=None):
             if tr:
                 k["traffic"] = tr
                 k["traffic_over_algorithmic"] = tr / k["bytes"]
+                k["frac_by_counters"] = tr / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             insts, _src = pmc_lookup("sq", workload, names, "SQ_INSTS_VALU")
             if insts:
                 vr = valu_roof(names if isinstance(names, list) else names["any_of"], insts, k["ms"])
@@ -474,7 +506,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     V = int((radii > 0).sum())
     cnt = base_C.last_counters()
     info["R"] = int(cnt["instances"])
-    table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]))
+    table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]), touched=int(cnt.get("touched", -1)))
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
                  "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"],
                  "forward blend group (reference K7): T-only walks + alive + full walk + combine":
@@ -905,6 +937,66 @@ def bench_chamfer(args):
     print(json.dumps(out))
 
 
+def bench_points_meter(args):
+    """SURVEY section 8 row f3, second half: PointsMeter.update (utils/lidar_utils.py:253-282) on one 64 x 2650 frame -- range images in,
+    chamfer distance and F-score out -- as one native call on device-resident images, beside the reference's dataflow on the same
+    box (images to the host, numpy back-projection, clouds back to the device, the chamfer kernel, results read back)."""
+    import numpy as np
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    import chamfer_3D
+    import points_meter
+    import lidargs_scenes as sc
+    from oracle import range_view
+    H, W = 64, 2650
+    rng = np.random.default_rng(5)
+    beams = np.ascontiguousarray(sc.beam_table(H, "waymo"), dtype=np.float32)
+    truth = (rng.gamma(2.0, 9.0, size=(H, W)) + 2.0).astype(np.float32); truth[rng.random((H, W)) < 0.2] = 0.0
+    pred = (truth * (1.0 + 0.005 * rng.normal(size=(H, W)))).astype(np.float32); pred[rng.random((H, W)) < 0.1] = 0.0
+    tp, tt, tb = torch.from_numpy(pred).cuda(), torch.from_numpy(truth).cuda(), torch.from_numpy(beams).cuda()
+    for _ in range(max(2, args.warmup // 3)):
+        out = points_meter.points_metrics(tp, tt, beam_inclinations=tb)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = max(5, args.steps)
+    for _ in range(steps):
+        out = points_meter.points_metrics(tp, tt, beam_inclinations=tb)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    o = out.cpu().numpy()
+    n, m = int(o[4]), int(o[5])
+    res = {"metric": "PointsMeter.update evaluations per second (range images -> chamfer distance + F-score)", "value": 1.0 / t, "unit": "evaluations/s", "n_gpus": 1,
+           "steps": steps, "warmup": max(2, args.warmup // 3), "ms_per_step": t * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"points_meter: one {H}x{W} frame, {n} predicted and {m} ground-truth returns, threshold 0.05", "chamfer_distance": float(o[0]),
+                      "f_score": float(o[1])},
+           "roofline": {"bound": "hbm", "kernel": "flags + scan + back-projection + the grid search (x2) + the means: ~30 small launches", "achieved": (8.0 * H * W + 2 * 12.0 * (n + m) + 8.0 * (n + m)) / t / 1e9,
+                        "peak": 8000.0, "unit": "GB/s", "frac": (8.0 * H * W + 2 * 12.0 * (n + m) + 8.0 * (n + m)) / t / 1e9 / 8000.0, "traffic": None,
+                        "algorithmic_bytes": "the two images in, 12 B per point and direction through the search, 8 B per point of results: latency-bound far below any roof"}}
+    if not args.no_cpu_baseline:
+        # the reference's dataflow, its chamfer kernel replaced by ours (its CUDA extension cannot run here): what update() costs when the
+        # images leave the device
+        def reference_dataflow():
+            p, q = tp.detach().cpu().numpy(), tt.detach().cpu().numpy()
+            c1 = range_view.pano_to_points(p, np.zeros_like(p), beams)[:, :3]; c2 = range_view.pano_to_points(q, np.zeros_like(q), beams)[:, :3]
+            x1, x2 = torch.FloatTensor(c1[None, ...]).cuda(), torch.FloatTensor(c2[None, ...]).cuda()
+            d1, d2 = torch.empty(1, x1.shape[1], device="cuda"), torch.empty(1, x2.shape[1], device="cuda")
+            i1, i2 = torch.empty(1, x1.shape[1], dtype=torch.int32, device="cuda"), torch.empty(1, x2.shape[1], dtype=torch.int32, device="cuda")
+            chamfer_3D.forward(x1, x2, d1, d2, i1, i2)
+            return float((d1.mean() + d2.mean()).cpu())
+        reference_dataflow()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            cd = reference_dataflow()
+        tr = (time.perf_counter() - t0) / 5
+        res["cpu_baseline"] = {"value": 1.0 / tr, "unit": "evaluations/s", "cores": 1, "kind": "port",
+                               "sample": f"5 evaluations of the reference's dataflow on this box: .cpu().numpy(), numpy pano_to_lidar (oracle/range_view.py), upload, the native chamfer kernel, "
+                                         f".cpu() -- {tr * 1e3:.2f} ms each (chamfer distance {cd:.6f})"}
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res))
+
+
 def _flush_c_stdio():
     """RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that buffer is only written at
     process exit, i.e. AFTER the JSON line.  Flushing it early keeps the JSON line the last thing on stdout."""
@@ -952,7 +1044,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3",
-                    help="cfg3 (headline) | cfg2 (forward only, as BASELINE.json states it) | cfg4 | cfg5 | render_fps | decode | loss | train_step | chamfer")
+                    help="cfg3 (headline) | cfg2 (forward only, as BASELINE.json states it) | cfg4 | cfg5 | render_fps | decode | loss | train_step | chamfer | points_meter")
     ap.add_argument("--fwd-only", action="store_true", help="time the rasterizer forward alone (default for cfg2)")
     ap.add_argument("--fwd-bwd", action="store_true", help="forward + backward also for cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -984,6 +1076,8 @@ def main():
         return bench_train_step(args)
     if args.workload == "chamfer":
         return bench_chamfer(args)
+    if args.workload == "points_meter":
+        return bench_points_meter(args)
     if args.workload == "render_fps":
         return bench_render_fps(args)
     import lidargs_scenes as sc
@@ -1228,7 +1322,8 @@ def main():
             # roofline: every launch (group) priced on what IT processes (R' = the instances this frame binned), the longest single
             # launch on top; the reference data flow's bytes (R_ref 16x1 instances) against our time are kept apart, they are a
             # speed-up statement, not a fraction of any roof
-            table = raster_kernel_table(P, cnt["V"], cnt["instances"], N_pix, stages, taken=cnt["taken_instances"])
+            table = raster_kernel_table(P, cnt["V"], cnt["instances"], N_pix, stages, taken=cnt["taken_instances"], touched=cnt.get("touched", -1),
+                                        bwd_entries=cnt.get("backward_entries", -1))
             fwd_b, bwd_b, _k7, _k8 = reference_dataflow_bytes(P, cnt["V"], cnt["R_ref"], N_pix, T_ref)
             ref_bytes = fwd_b if fwd_only else fwd_b + bwd_b
             ref_flow = {"frame_bytes_of_the_reference_dataflow": ref_bytes, "GBs_at_our_frame_time": ref_bytes / (ms_per_step * 1e-3) / 1e9,
@@ -1251,7 +1346,8 @@ def main():
             # no PMC profile exists for a rank's sub-frame, so HBM fractions only
             try:
                 n_own = N_pix // world if args.shard == "wedges" else N_pix
-                table = raster_kernel_table(int(cnt["P"]), int(cnt["V"]), int(cnt["instances"]), n_own, stages, taken=int(cnt["taken_instances"]))
+                table = raster_kernel_table(int(cnt["P"]), int(cnt["V"]), int(cnt["instances"]), n_own, stages, taken=int(cnt["taken_instances"]),
+                                            touched=int(cnt.get("touched", -1)), bwd_entries=int(cnt.get("backward_entries", -1)))
                 out["roofline"] = roofline_object(table, "sharded-" + args.workload, {})
                 out["roofline"]["note"] = f"rank 0 of {world}: {int(cnt['P'])} Gaussians selected, {int(cnt['instances'])} instances binned"
             except Exception as e:      # the headline number must not depend on the diagnostics

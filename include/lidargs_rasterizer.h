@@ -485,7 +485,9 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
  * 16x1 tiles_touched (what SURVEY.md 8d's byte formula is written in), [4]=tile rows TH,
  * [5]=number of tiles, [6]=instances that at least one pixel of their patch took in pass 1 (-1 if the
  * T-only pass did not run), [7]=segments per list, [8]=Gaussians some pixel's walk took (the only ones with a gradient: the backward
- * clears, adds to and reads the packed sums of these alone; -1 if unknown).  Values [1], [3], [6], [8] are read back on demand. */
+ * clears, adds to and reads the packed sums of these alone; -1 if unknown), [9]=list entries the backward blend gathers (per patch and
+ * segment the flagged entries in front of its last blended one; -1 if unknown: surfel variant, no instances).  Values [1], [3], [6], [8],
+ * [9] are read back (or counted by a diagnostic launch) on demand. */
 int lidargs_last_counters(long long* out, int n);
 
 /* Test hook (no reference counterpart as an entry point): the tile rect the two preprocess kernels give a Gaussian -- getRect_lidar,

@@ -32,6 +32,30 @@ SOURCES = {
 }
 
 
+def build_id():
+    """A content hash of everything the library is built from (csrc/, the public headers, this file): the same on every box that holds the
+    same sources -- what the profile tools stamp their summaries with and bench.py compares against (the GPU boxes have no .git)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + sorted(
+        os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))) + [os.path.abspath(__file__)]
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def box_id():
+    """The GPU's unique id as rocm-smi prints it (the boxes all call themselves `runc`), or None."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+        for line in out.splitlines():
+            if "Unique ID" in line:
+                return line.split(":")[-1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

@@ -30,6 +30,7 @@ thread_local const uint8_t* g_last_flags = nullptr; thread_local size_t g_last_f
 thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals (geometry buffer)
 thread_local const uint8_t* g_last_touched = nullptr; thread_local size_t g_last_touched_P = 0;   // the last forward's touched marks (geometry buffer)
 thread_local long long g_touched_count = -1;
+thread_local lg::RenderBwdArgs g_last_bwd_view; thread_local bool g_last_bwd_view_ok = false; thread_local long long g_bwd_entries = -1;   // what the last plain forward's backward will walk
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -266,6 +267,7 @@ void api_note_forward(long long P, long long R, int TH, int tiles, int S, const 
     g_last_flags = flags; g_last_flags_R = (size_t)R; g_last_flags_stride = flags_stride; g_last_flags_planes = flags_planes;
     g_last_totals_dev = (uint32_t*)totals;
     g_last_touched = nullptr; g_last_touched_P = 0; g_touched_count = -1;
+    g_last_bwd_view_ok = false; g_bwd_entries = -1;
 }
 void api_note_touched(const uint8_t* touched, size_t P) { g_last_touched = touched; g_last_touched_P = P; g_touched_count = -1; }
 int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }
@@ -569,6 +571,14 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_last_flags = ra.flags; g_last_flags_R = R; g_last_flags_stride = Rp; g_last_flags_planes = grid.waves_per_tile;
     g_last_totals_dev = geom.totals;             // R_ref / V are summed lazily in lidargs_last_counters (the diagnostic slots)
     g_last_touched = geom.touched; g_last_touched_P = (size_t)P; g_touched_count = -1;
+    {   // the selection a backward on these buffers will make (backward_impl builds the same view): for lidargs_last_counters only
+        lg::RenderBwdArgs& v = g_last_bwd_view;
+        v = lg::RenderBwdArgs();
+        v.walk.cnt = nullptr; v.grid = grid; v.ranges = img.ranges; v.seg = bin.seg; v.S = S; v.seg_len = plan.seg_len; v.R = Rp;
+        v.alive = (fused || pass1_gated(plan, S)) ? bin.alive : nullptr;
+        v.flags = (fused || S > 1 || is_shell) ? bin.flags : nullptr;
+        g_last_bwd_view_ok = R != 0 && !transmittance_pass; g_bwd_entries = -1;
+    }
     return rendered;
 }
 
@@ -1026,6 +1036,10 @@ int lidargs_last_counters(long long* out, int n) {
     int k = 0;
     for (; k < n && k < 8; k++) out[k] = g_counters[k];
     if (k < n) out[k++] = g_touched_count;                             // [8]
+    if (k < n) {                                                       // [9]
+        if (g_bwd_entries < 0 && g_last_bwd_view_ok) g_bwd_entries = lg::count_backward_entries(g_last_bwd_view);
+        out[k++] = g_bwd_entries;
+    }
     return k;
 }
 

@@ -488,6 +488,7 @@ struct RenderBwdArgs {
     WorkList walk;                 // the list k_render_combine filled; cnt == nullptr: the slot grid
 };
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s);
+long long count_backward_entries(const RenderBwdArgs& a);             // diagnostics: the list entries that launch gathers (synchronises; -1 on failure)
 
 struct GaussBwdArgs {
     int P; float scale_modifier; const float* view;   // device pointer

@@ -1238,6 +1238,44 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     }
 }
 
+// Diagnostics (lidargs_last_counters, outside any timed region): the list entries k_render_backward gathers for a frame -- per (patch,
+// segment) the flagged entries in front of the segment's last blended one, exactly its own selection (above: n_max, the flags, the
+// patch's limit).  What bench.py prices the launch's algorithmic bytes on.
+__global__ void __launch_bounds__(64) k_count_backward_entries(const RenderBwdArgs a, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const int S = a.S, wpt = a.grid.waves_per_tile;
+    int patch, seg;
+    if (!block_patch_segment(blockIdx.x, a.grid.window_patches(), S, patch, seg)) return;
+    patch = a.grid.global_patch(patch);
+    const int tile = patch / wpt, sub = patch - tile * wpt;
+    const size_t stride = LG_SEG_PLANES * 64;
+    const uint2 tr = a.ranges[tile];
+    const int St = segment_count(tr, S, a.seg_len);
+    const int limit = a.alive ? (int)a.alive[patch] : 255;
+    if (seg >= St || seg >= limit) return;
+    uint32_t n_max = reinterpret_cast<const uint32_t*>(a.seg + (size_t)patch * S * stride + lane)[(size_t)seg * stride + LG_SEG_LAST * 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
+    if (n_max == 0) return;
+    const uint2 sr = segment_range(tr, St, seg);
+    const uint8_t* fl = a.flags ? a.flags + (size_t)sub * a.R + sr.x : nullptr;
+    uint32_t c = 0;
+    for (uint32_t k = lane; k < n_max; k += 64) c += (!fl || fl[k] != 0) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+long long count_backward_entries(const RenderBwdArgs& a) {
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof *d) != hipSuccess) return -1;
+    unsigned long long h = 0;
+    (void)hipMemset(d, 0, sizeof *d);
+    hipLaunchKernelGGL(k_count_backward_entries, dim3(segment_grid(a.grid.window_patches(), a.S)), dim3(64), 0, nullptr, a, d);
+    const bool ok = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? (long long)h : -1;
+}
+
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {
     const unsigned blocks = a.walk.cnt ? (unsigned)LG_WORK_REGIONS * a.walk.cap : segment_grid(a.grid.window_patches(), a.S);
     if (walk2() & 4) hipLaunchKernelGGL(k_render_backward<true>, dim3(blocks), dim3(64), 0, s, a);

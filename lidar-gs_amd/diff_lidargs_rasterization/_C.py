@@ -298,7 +298,7 @@ def profile_summary():
 
 def last_counters():
     """dict(P, V, instances, R_ref, tile_rows, tiles, ..., touched) of the last forward on this thread."""
-    buf = (C.c_longlong * 9)()
-    _lib.lidargs_last_counters(buf, C.c_int(9))
+    buf = (C.c_longlong * 10)()
+    _lib.lidargs_last_counters(buf, C.c_int(10))
     return dict(P=buf[0], V=buf[1], instances=buf[2], R_ref=buf[3], tile_rows=buf[4], tiles=buf[5], taken_instances=buf[6],
-                segments=buf[7], touched=buf[8])
+                segments=buf[7], touched=buf[8], backward_entries=buf[9])

@@ -13,7 +13,10 @@ Derived per launch where the inputs exist:
 import json
 import re
 import sqlite3
+import os
 import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lidar-gs_amd"))
+import build_hip  # noqa: E402  (build_id / box_id: what bench.py checks a looked-up profile against)
 
 workload, command, dbs = sys.argv[1], sys.argv[2], sys.argv[3:]
 acc = {}
@@ -27,7 +30,7 @@ for path in dbs:
         if not k.startswith("lg::"):
             continue
         acc.setdefault(k, {}).setdefault(c, []).append(float(v))
-res = {"workload": workload, "command": command,
+res = {"workload": workload, "command": command, "build_id": build_hip.build_id(), "box": build_hip.box_id(),
        "note": "rocprofv3 --kernel-trace --pmc <SQ counters>, one or more passes; per-launch means. SQ counters count wave-level events "
                "(SQ_INSTS_VALU = wave64 VALU instructions issued).", "kernels": {}}
 for k in sorted(acc):

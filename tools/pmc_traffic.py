@@ -8,7 +8,10 @@ Values of one dispatch are summed over counter instances first, then averaged ov
 import json
 import re
 import sqlite3
+import os
 import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lidar-gs_amd"))
+import build_hip  # noqa: E402  (build_id / box_id: what bench.py checks a looked-up profile against)
 
 
 def per_kernel(path, counter):
@@ -26,7 +29,7 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {"workload": sys.argv[4] if len(sys.argv) > 4 else "cfg3",      # bench.py picks the profile of the workload it runs
-       "command": sys.argv[3] if len(sys.argv) > 3 else "",
+       "command": sys.argv[3] if len(sys.argv) > 3 else "", "build_id": build_hip.build_id(), "box": build_hip.box_id(),
        "note": "KB units as reported by rocprofv3; 'corrected' doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
                "(calibrated there on wide coalesced streams; the blend kernels issue 16-B-per-lane gathers, so treat the corrected read "
                "side as an upper bound). WRITE_SIZE is uncalibrated.",
