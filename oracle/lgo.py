@@ -30,6 +30,52 @@ def build(force=False):
     return _SO
 
 
+def _restypes(L):
+    L.lgo_forward.restype = C.c_void_p
+    L.lgo_forward_ex.restype = C.c_void_p
+    L.lgo_backward_ex.restype = C.c_int
+    L.sfo_forward.restype = C.c_void_p
+    L.sfo_forward_tm.restype = C.c_void_p
+    L.sfo_state_array.restype = C.c_void_p
+    L.sfo_last_error.restype = C.c_char_p
+    L.lgo_state_array.restype = C.c_void_p
+    L.lgo_last_error.restype = C.c_char_p
+    L.lgo_num_rendered.restype = C.c_int
+    L.lgo_backward.restype = C.c_int
+    L.lgo_bench_frames.restype = C.c_double
+    L.sfo_num_rendered.restype = C.c_int
+    return L
+
+
+_lib_fma = None
+
+
+class fma_build:
+    """`with lgo.fma_build(): ...` -- inside, every oracle call runs the SAME restatement compiled with multiply-add contraction
+    (-ffp-contract=fast -mfma: what nvcc's default -fmad=true does to the reference): a second conforming evaluation of the reference
+    source, for the band of tests/util.py oracle_envelope.  Unavailable (host without FMA): the block runs on the plain build."""
+
+    def __enter__(self):
+        global _lib, _lib_fma
+        lib()
+        self.saved = _lib
+        if _lib_fma is None:
+            so = os.path.join(_HERE, "liblidargs_oracle_fma.so")
+            try:
+                subprocess.check_call(["make", "-s", "-C", _HERE, "liblidargs_oracle_fma.so"])
+                _lib_fma = _restypes(C.CDLL(so))
+            except Exception:
+                _lib_fma = False
+        if _lib_fma:
+            _lib = _lib_fma
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -8,8 +8,9 @@ Small scenes: P < 6000, W < 700 (the oracle takes a fraction of a second); mid s
 The JSON: scenes run, entries compared, radii mismatches, soft / flip entries against what the budgets allow, and every scene whose
 parity() assertion failed (none is expected: a failure is a finding, not a crash of the sweep).  Round 5: a scene over a count budget is
 then judged against the reference's OWN band (util.envelope_verdict: the oracle re-run four times with every cos / sin / atan2 / tan /
-exp result moved inside its CUDA-libdevice error bound) -- `failed_scenes_outside_the_reference_band` lists the scenes where HIP is off
-somewhere the oracle does not move, or lies outside the five-run envelope by more than half a local width: that list is the finding."""
+exp result moved inside its CUDA-libdevice error bound and once with the backward's atomics summed in reverse order) --
+`failed_scenes_outside_the_reference_band` lists the scenes where HIP is off somewhere the oracle does not move, or lies outside the
+six-run envelope by more than one local width: that list is the finding."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests")):
@@ -124,7 +125,7 @@ def one(seed, mid):
             ok, st = envelope_verdict(hip, base, lo, hi, list(lo.keys()))
             desc["inside_reference_band"] = bool(ok)
             desc["band"] = {k: dict(hip_over=v["hip_over"], of_those_where_the_oracle_moves=v["hip_over_where_oracle_moves_half"],
-                                    worst_outside_in_widths=round(v["worst_outside_anywhere"], 3)) for k, v in st.items() if v["hip_over"]}
+                                    worst_outside_in_widths=round(v["worst_outside_in_widths"], 3)) for k, v in st.items() if v["hip_over"]}
         except Exception as e2:                                        # (a judgement that could not be made is reported as such)
             desc["inside_reference_band"] = None; desc["band_error"] = repr(e2)[:200]
     log = util.PARITY_LOG[n0:]
