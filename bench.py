@@ -272,11 +272,13 @@ def sort_pmc_groups(tiles):
     tb = max(1, math.ceil(math.log2(max(2, tiles))))
     t_passes = (tb + 7) // 8
     t_bits = (tb + t_passes - 1) // t_passes
-    r_passes = 4
-    sort_kernels = ["lg::k_radix_hist<", "lg::k_radix_scatter<", "lg::k_radix_digit_prefix<", "lg::k_radix_chunk_prefix"]
+    r_passes = 1                                           # the bucketed range sort: one digit pass (frames above 4 M Gaussians run more)
+    sort_kernels = ["lg::k_radix_hist<", "lg::k_radix_scatter<", "lg::k_radix_digit_prefix<", "lg::k_radix_chunk_prefix", "lg::k_bucket_sort"]
 
     def weight(for_tile_sort):
         def w(name):
+            if "k_bucket_sort" in name:                    # the bucketed range sort's second launch
+                return 0.0 if for_tile_sort else 1.0
             m = re.search(r"k_radix_(?:hist|scatter)<(\d+),", name)
             if m is None:                                  # digit / chunk prefix: shared by pass count
                 return (t_passes if for_tile_sort else r_passes) / float(t_passes + r_passes)
@@ -285,8 +287,9 @@ def sort_pmc_groups(tiles):
                 return 0.5                                 # widths overlap: cannot be told apart by name
             return 1.0 if narrow == for_tile_sort else 0.0
         return w
-    return {"range sort of the Gaussians (hist + prefix + scatter per pass; the last pass gathers the span records)":
-                {"any_of": sort_kernels, "per_frame": "k_preprocess", "weight": weight(False)},
+    rs = {"any_of": sort_kernels, "per_frame": "k_preprocess", "weight": weight(False)}
+    return {"range sort of the Gaussians (hist + prefix + scatter per pass; the last pass gathers the span records)": rs,
+            "range sort of the Gaussians (one linear-bucket pass: hist + prefix + scatter, + one launch that sorts every bucket in LDS and gathers the span records)": rs,
             "tile sort of the instances (hist + prefix + scatter per pass)":
                 {"any_of": sort_kernels, "per_frame": "k_preprocess", "weight": weight(True)},
             "span block sums + scan of the block sums (+ the 2-KB totals read-back)":
@@ -508,7 +511,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     info["R"] = int(cnt["instances"])
     table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]), touched=int(cnt.get("touched", -1)))
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
-                 "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"],
+                 "k_sf_gaussian_backward": ["lg::k_sf_gaussian_backward"], "k_zero_touched": ["lg::k_zero_touched"],
                  "forward blend group (reference K7): T-only walks + alive + full walk + combine":
                      {"any_of": ["lg::k_sf_render_forward<", "lg::k_sf_alive", "lg::k_sf_combine"], "per_frame": "k_sf_combine"},
                  "k_emit_instances": ["lg::k_emit_instances"], "k_tile_ranges": ["lg::k_tile_ranges"]}
@@ -1330,7 +1333,7 @@ def main():
                         "note": "SURVEY 8d formula on R_ref (16x1 instances the reference would bin) / our frame time: above the 8000 GB/s "
                                 "peak means the frame is faster than that data flow could be at HBM speed; NOT a roofline fraction"}
             pmc_names = {"k_render_backward": ["lg::k_render_backward"], "k_preprocess": ["lg::k_preprocess<false>"],
-                         "k_gaussian_backward": ["lg::k_gaussian_backward"], "k_emit_instances": ["lg::k_emit_instances"],
+                         "k_gaussian_backward": ["lg::k_gaussian_backward"], "k_emit_instances": ["lg::k_emit_instances"], "k_zero_touched": ["lg::k_zero_touched"],
                          "k_tile_ranges": ["lg::k_tile_ranges"],
                          "forward blend group (reference K7): T-only walks + alive + full walk + combine":
                              {"any_of": ["lg::k_render_forward<", "lg::k_render_pass2_grouped", "lg::k_render_alive", "lg::k_render_combine", "lg::k_render_fused"],

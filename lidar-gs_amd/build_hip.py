@@ -47,10 +47,11 @@ def build_id():
 def box_id():
     """The GPU's unique id as rocm-smi prints it (the boxes all call themselves `runc`), or None."""
     try:
+        import re
         out = subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
-        for line in out.splitlines():
-            if "Unique ID" in line:
-                return line.split(":")[-1].strip()
+        m = re.search(r"Unique ID:\s*(0x[0-9a-fA-F]+|\w+)", out)
+        if m:
+            return m.group(1)
     except Exception:
         pass
     return None

@@ -199,9 +199,13 @@ void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive
     const int S = ra.S;
     const int* r = plan.rounds;
     const int n = plan.n_rounds;
-    ra.alive = nullptr; ra.front = 0;
+    ra.alive = nullptr; ra.front = 0; ra.alive_out = nullptr;
     int lo = 0;
     if (head) *head = 0;
+    // A single gated round (the 64-entry plan): the round behind it decides the gate inside its own launch (render.hip k_render_forward,
+    // alive_out) -- one launch and its gap less than with k_render_alive in between.  LIDARGS_ALIVE_LAUNCH=1: the separate launch (A/B).
+    static const bool alive_launch = [] { const char* e = getenv("LIDARGS_ALIVE_LAUNCH"); return e && atoi(e) != 0; }();
+    const bool inline_gate = !alive_launch && n == 1 && r[0] < S && !(head && plan.head);
     for (int i = 0; i < n && r[i] < S; i++) {
         ra.seg_lo = lo; ra.seg_hi = r[i];
         if (i == 0 && head && plan.head && !ra.T_in && !ra.transmittance_only && ra.flags) {
@@ -210,12 +214,14 @@ void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive
         } else {
             lg::launch_render_pass1(ra, stream);   // gated on the limits the previous rounds left (none in the first)
         }
-        ra.alive = alive; ra.front = r[i];
-        lg::launch_render_alive(ra, stream);
+        ra.front = r[i];
+        if (inline_gate) { ra.alive = nullptr; ra.alive_out = alive; }
+        else { ra.alive = alive; lg::launch_render_alive(ra, stream); }
         lo = r[i];
     }
     ra.seg_lo = lo; ra.seg_hi = S;
     lg::launch_render_pass1(ra, stream);
+    ra.alive = alive; ra.alive_out = nullptr;
     ra.seg_lo = 0; ra.seg_hi = S;
 }
 
@@ -466,7 +472,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         const unsigned long long R64 = TH == 4 ? inst[0] : (TH == 8 ? inst[1] : (TH == 16 ? inst[2] : inst[3]));
         if (R64 > (unsigned long long)std::numeric_limits<int>::max() - 4ull) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "forward: instance count overflows int%s");
         R = (size_t)R64;
-        lg::launch_instance_offsets(geom.span_sorted, pp.compact != 0, TH, geom.block_off, geom.totals, (size_t)P, stream);
+        lg::launch_instance_offsets(geom.span_sorted, pp.compact != 0, TH, geom.block_off, geom.totals, (size_t)P, stream, false);   // (the host has R from the preprocess's totals; the emit adds the block sums up itself)
         LG_STAGE_CHECK("instance scan");
     } else {
         TH = fixed_tile_rows;
@@ -507,7 +513,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
         uint32_t* const k_in = flip ? bin.tile_b : bin.tile_a; uint32_t* const k_out = flip ? bin.tile_a : bin.tile_b;
         uint32_t* const v_in = flip ? bin.val_b : bin.val_a; uint32_t* const v_out = flip ? bin.val_a : bin.val_b;
         lg::launch_emit_instances(ids_sorted, geom.block_off, geom.span_sorted, pp.compact != 0, (size_t)P, grid,
-                                  k_in, v_in, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16, img.ranges);
+                                  k_in, v_in, stream, enqueue_only ? (uint32_t)Rp : 0xFFFFFFFFu, key16, img.ranges, !enqueue_only);
         LG_STAGE_CHECK("emit");
         g_prof.mark("emit", stream);
         const int side = key16 ? lg::launch_radix_sort_pairs16(reinterpret_cast<uint16_t*>(k_in), reinterpret_cast<uint16_t*>(k_out), v_in, v_out, R,

@@ -949,13 +949,13 @@ __global__ void __launch_bounds__(256) k_span_block_sums(const void* __restrict_
     if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 // spans in range order + exclusive block offsets in `block_off` (scan_blocks(P) words) + the instance total in *total_out
-void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s) {
+void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s, bool scan) {
     int sh = 0;
     while ((1 << sh) < TH) sh++;
     const size_t nb = scan_blocks(P);
     if (compact) hipLaunchKernelGGL(k_span_block_sums<true>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
     else hipLaunchKernelGGL(k_span_block_sums<false>, dim3((unsigned)nb), dim3(256), 0, s, span_sorted, sh, block_off, P);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, block_off, nb, total_out);
+    if (scan) hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, block_off, nb, total_out);   // (otherwise the emit adds the sums up itself)
 }
 
 // Load-balanced expansion: each wave owns 64 range-consecutive Gaussians at a time and writes their
@@ -966,7 +966,7 @@ template <bool COMPACT, typename KT = uint32_t>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* __restrict__ ids_sorted, const uint32_t* __restrict__ block_off,
                                                                const void* __restrict__ span_sorted_, size_t P, int th_shift, int tiles_x,
                                                                KT* __restrict__ inst_tile, uint32_t* __restrict__ inst_val, uint32_t cap,
-                                                               uint2* __restrict__ ranges, uint32_t tiles) {
+                                                               uint2* __restrict__ ranges, uint32_t tiles, const int sums_unscanned) {
     // every tile's list range starts out empty, as the reference pre-zeroes `ranges` (R3/cr/rasterizer_impl.cu:324): k_tile_ranges, two
     // sorts later, writes the non-empty ones.  (It used to zero the tiles a step of the sorted keys skips, one thread per step: a far range
     // shell's frame, whose lists leave a thousand tiles empty in a row, spent 42 us there.)
@@ -987,8 +987,19 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
         x0 = sp.x & 0xFFFFu; nx = (sp.x >> 16) - x0;
         ty0 = (sp.y & 0xFFFFu) >> th_shift;
     }
+    // sums_unscanned: block_off holds the blocks' instance COUNTS and this block adds up the ones in front of it itself (<= 2 loads per
+    // thread at 2 M Gaussians) -- the single-workgroup scan launch between the block sums and this one (k_scan_partials) is gone
+    __shared__ uint32_t s_pre[SCAN_BLOCK / 64];
+    uint32_t pre = 0;
+    if (sums_unscanned) {
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += SCAN_BLOCK) pre += block_off[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+        if (lane == 0) s_pre[w] = pre;
+    }
     __syncthreads();
-    uint32_t wave_base = block_off[blockIdx.x];
+    uint32_t wave_base = sums_unscanned ? 0u : block_off[blockIdx.x];
+    if (sums_unscanned) for (int q = 0; q < SCAN_BLOCK / 64; q++) wave_base += s_pre[q];
     for (int q = 0; q < w; q++) wave_base += s_tot[q];
     const uint32_t wave_total = __shfl(inc, 63);
     const uint32_t lo = valid ? inc - cnt : 0xFFFFFFFFu;               // local exclusive prefix (+inf past the end)
@@ -1035,22 +1046,23 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
 }
 
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
-                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap, bool key16, uint2* ranges) {
+                           uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap, bool key16, uint2* ranges, bool sums_unscanned) {
+    const int su = sums_unscanned ? 1 : 0;
     const uint32_t tiles = ranges ? (uint32_t)grid.num_tiles() : 0u;
     int sh = 0;
     while ((1 << sh) < grid.TH) sh++;
     if (key16) {
         uint16_t* t16 = reinterpret_cast<uint16_t*>(inst_tile);
         if (compact) hipLaunchKernelGGL((k_emit_instances<true, uint16_t>), dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                                        P, sh, grid.tiles_x, t16, inst_val, cap, ranges, tiles);
+                                        P, sh, grid.tiles_x, t16, inst_val, cap, ranges, tiles, su);
         else hipLaunchKernelGGL((k_emit_instances<false, uint16_t>), dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                                P, sh, grid.tiles_x, t16, inst_val, cap, ranges, tiles);
+                                P, sh, grid.tiles_x, t16, inst_val, cap, ranges, tiles, su);
         return;
     }
     if (compact) hipLaunchKernelGGL(k_emit_instances<true>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                                    P, sh, grid.tiles_x, inst_tile, inst_val, cap, ranges, tiles);
+                                    P, sh, grid.tiles_x, inst_tile, inst_val, cap, ranges, tiles, su);
     else hipLaunchKernelGGL(k_emit_instances<false>, dim3((unsigned)scan_blocks(P)), dim3(SCAN_BLOCK), 0, s, ids_sorted, block_off, span_sorted,
-                            P, sh, grid.tiles_x, inst_tile, inst_val, cap, ranges, tiles);
+                            P, sh, grid.tiles_x, inst_tile, inst_val, cap, ranges, tiles, su);
 }
 
 // R3/cr/rasterizer_impl.cu:117-139 identifyTileRanges on 32-bit tile keys.  The reference pre-zeroes `ranges` (:324) so that tiles

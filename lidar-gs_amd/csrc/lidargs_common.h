@@ -393,11 +393,14 @@ int launch_radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, u
                             RadixTail tail = RadixTail(), int begin_bit = 0, const KeyBias* bias = nullptr);
 void launch_finish_totals(const uint32_t* totals, const unsigned long long* slots, uint32_t cap, uint32_t* status, hipStream_t s);
 // block instance offsets + the instance total from the spans in range order (filled by the range sort's last pass); compact: span_pack
-void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s);
+// scan = false: block_off is left holding the blocks' instance COUNTS (launch_emit_instances(..., sums_unscanned = true) adds them up itself;
+// *total_out is then not written)
+void launch_instance_offsets(const void* span_sorted, bool compact, int TH, uint32_t* block_off, uint32_t* total_out, size_t P, hipStream_t s, bool scan = true);
 // key16: the tile keys are 16-bit (the array is the same allocation, half used): every image with at most 65536 list tiles
 void launch_emit_instances(const uint32_t* ids_sorted, const uint32_t* block_off, const void* span_sorted, bool compact, size_t P, TileGrid grid,
                            uint32_t* inst_tile, uint32_t* inst_val, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, bool key16 = false,
-                           uint2* ranges = nullptr);   // ranges: the launch also clears every tile's list range (then launch_tile_ranges(..., prezeroed = true))
+                           uint2* ranges = nullptr,    // ranges: the launch also clears every tile's list range (then launch_tile_ranges(..., prezeroed = true))
+                           bool sums_unscanned = false);
 // zero / n_zero: words this launch also clears (the work lists' counters: nothing before the blends touches them)
 void launch_tile_ranges(const uint32_t* tile_sorted, size_t R, uint2* ranges, int tiles, hipStream_t s, const uint32_t* R_dev = nullptr, bool key16 = false,
                         uint32_t* zero = nullptr, int n_zero = 0, bool prezeroed = false);
@@ -458,6 +461,8 @@ struct RenderFwdArgs {
     int seg_lo, seg_hi;       // segment slots [seg_lo, seg_hi) this launch covers
     int front;                // launch_render_alive: the segment the finished round ends at
     uint8_t* alive;           // [patches] (nullptr = no gating): number of segments pass 1 walked (255 = all of them)
+    uint8_t* alive_out = nullptr; // pass 1, the round behind `front` segments: every workgroup decides its patch's gate itself and the round's
+                                  // first segment's workgroup writes the limit here (instead of a k_render_alive launch in between)
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
     WorkList fill;            // k_render_combine: the backward's work list (cnt == nullptr: none)
