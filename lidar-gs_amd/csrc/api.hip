@@ -199,13 +199,9 @@ void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive
     const int S = ra.S;
     const int* r = plan.rounds;
     const int n = plan.n_rounds;
-    ra.alive = nullptr; ra.front = 0; ra.alive_out = nullptr;
+    ra.alive = nullptr; ra.front = 0;
     int lo = 0;
     if (head) *head = 0;
-    // A single gated round (the 64-entry plan): the round behind it decides the gate inside its own launch (render.hip k_render_forward,
-    // alive_out) -- one launch and its gap less than with k_render_alive in between.  LIDARGS_ALIVE_LAUNCH=1: the separate launch (A/B).
-    static const bool alive_launch = [] { const char* e = getenv("LIDARGS_ALIVE_LAUNCH"); return e && atoi(e) != 0; }();
-    const bool inline_gate = !alive_launch && n == 1 && r[0] < S && !(head && plan.head);
     for (int i = 0; i < n && r[i] < S; i++) {
         ra.seg_lo = lo; ra.seg_hi = r[i];
         if (i == 0 && head && plan.head && !ra.T_in && !ra.transmittance_only && ra.flags) {
@@ -214,14 +210,12 @@ void run_pass1_rounds(lg::RenderFwdArgs& ra, const SegPlan& plan, uint8_t* alive
         } else {
             lg::launch_render_pass1(ra, stream);   // gated on the limits the previous rounds left (none in the first)
         }
-        ra.front = r[i];
-        if (inline_gate) { ra.alive = nullptr; ra.alive_out = alive; }
-        else { ra.alive = alive; lg::launch_render_alive(ra, stream); }
+        ra.alive = alive; ra.front = r[i];
+        lg::launch_render_alive(ra, stream);
         lo = r[i];
     }
     ra.seg_lo = lo; ra.seg_hi = S;
     lg::launch_render_pass1(ra, stream);
-    ra.alive = alive; ra.alive_out = nullptr;
     ra.seg_lo = 0; ra.seg_hi = S;
 }
 

@@ -461,8 +461,6 @@ struct RenderFwdArgs {
     int seg_lo, seg_hi;       // segment slots [seg_lo, seg_hi) this launch covers
     int front;                // launch_render_alive: the segment the finished round ends at
     uint8_t* alive;           // [patches] (nullptr = no gating): number of segments pass 1 walked (255 = all of them)
-    uint8_t* alive_out = nullptr; // pass 1, the round behind `front` segments: every workgroup decides its patch's gate itself and the round's
-                                  // first segment's workgroup writes the limit here (instead of a k_render_alive launch in between)
     int run_pass1;            // run the T-only pass (needed when S > 1 or for a shell's phase 1)
     int transmittance_only;   // phase 1 of the multi-GPU shell render: only T_pass is produced
     WorkList fill;            // k_render_combine: the backward's work list (cnt == nullptr: none)

@@ -401,22 +401,9 @@ __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     const int tile = patch / wpt, sub = patch - tile * wpt;
     const uint2 tr = a.ranges[tile];
     const int St = segment_count(tr, S, a.seg_len);
-    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
-    if (T_ONLY && a.front > 0 && a.alive_out) {
-        // The gate of this round, decided by every workgroup for its own patch instead of by a launch in between (k_render_alive): the
-        // patch stays open behind the `front` segments the previous round walked if some pixel's transmittance through them (the
-        // product of their T-only walks from 1) is still >= 1e-4 and its list goes on.  The workgroup of the round's first segment
-        // records the limit for pass 2, the combine and the backward.
-        const float* sb = a.seg + (size_t)patch * S * (LG_SEG_PLANES * 64) + LG_SEG_TPASS * 64 + lane;
-        float T = 1.f;
-        const int kf = min(a.front, St);
-        for (int k = 0; k < kf; k++) T *= sb[(size_t)k * (LG_SEG_PLANES * 64)];
-        const bool open = St > a.front && __ballot(px.inside && T >= 0.0001f) != 0ull;
-        if (seg == a.seg_lo && lane == 0) a.alive_out[patch] = open ? 255 : (uint8_t)min(a.front, 254);
-        if (!open) return;
-    }
     if (seg >= St) return;
     if (a.alive && seg >= (int)a.alive[patch]) return;                  // every pixel saturated before this segment (never walked)
+    const PixelSetup px = pixel_setup(a.grid, a.coltab, a.rowtab, tile, sub, lane);
     const uint2 sr = segment_range(tr, St, seg);
     const uint32_t n = sr.y - sr.x;
     float* segbase = a.seg + ((size_t)patch * S + seg) * (LG_SEG_PLANES * 64);
