@@ -689,6 +689,8 @@ __global__ void __launch_bounds__(NG_BLOCK) k_ng_backward_mfma(int N, NgModel m,
     out[(5 + T2) * 1024 + lane] = s_db2[lane]; out[(5 + T2) * 1024 + 64 + lane] = s_db2[64 + lane];
 }
 
+#include "neural_gaussians_t16.inc"
+
 // ---- decode on the matrix pipe -----------------------------------------------------------------------------------------------------
 // k_ng_decode with the three MLPs as tile products (ng_mfma_recompute, the backward's own recompute: the same f32 fma chains in
 // the same order, so the backward re-derives exactly the activations the forward used).  A wave = 64 anchors; its outputs are
@@ -1038,15 +1040,23 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
     return 0;
 }
 
-static int ng_persistent_waves() {
+static int ng_cus() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return 4 * cus;                                                    // one wave per SIMD
+    return cus;
 }
+// k <= 6: k_ng_backward_t16 (16x16x4 tiles, one workgroup of eight waves per CU, one partial row per workgroup); k = 8, 10 (its LDS does
+// not hold their delta2 rows for eight waves) and LIDARGS_NG_BACKWARD_T16=0 (A/B, test variant): k_ng_backward_mfma, one wave per SIMD
+static bool ng_use_t16(int k) {
+    if (k > 6) return false;
+    const char* e = getenv("LIDARGS_NG_BACKWARD_T16");
+    return !(e && e[0] == '0');
+}
+static int ng_partial_rows(int k) { return ng_use_t16(k) ? ng_cus() : 4 * ng_cus(); }
 int lidargs_ng_backward_partials(int n_offsets, int* waves, int* floats_per_wave) {
     const int k = n_offsets;
     if (!(k == 4 || k == 5 || k == 6 || k == 8 || k == 10) || !waves || !floats_per_wave) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_partials: bad argument");
-    *waves = ng_persistent_waves();
+    *waves = ng_partial_rows(k);
     *floats_per_wave = (5 + 3 + (7 * k + 31) / 32) * 1024 + 128;
     return 0;
 }
@@ -1065,10 +1075,18 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
     if (scratch_bytes < lidargs_ng_scratch_bytes(N, m.k)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_mfma: scratch too small");
     lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)m.k, &s);
     const float3 cam = make_float3(cam_center[0], cam_center[1], cam_center[2]);
-    const int waves = ng_persistent_waves();
-    NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward_mfma<K>, dim3(waves), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset,
-                                        scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
-                                        dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials));
+    const int waves = ng_partial_rows(m.k);
+#define NG_T16_LAUNCH(K_) hipLaunchKernelGGL(lg::k_ng_backward_t16<K_>, dim3(waves), dim3(64 * NGT_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, \
+                                        scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity, \
+                                        dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials)
+    if (ng_use_t16(m.k)) {
+        if (m.k == 4) NG_T16_LAUNCH(4); else if (m.k == 5) NG_T16_LAUNCH(5); else NG_T16_LAUNCH(6);
+    } else {
+        NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward_mfma<K>, dim3(waves), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset,
+                                            scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
+                                            dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials));
+    }
+#undef NG_T16_LAUNCH
     NG_HIP(hipGetLastError());
     return 0;
 }
