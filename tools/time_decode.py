@@ -45,6 +45,9 @@ def timeit(fn, fwd_only=False):
 hip = lambda: generate_neural_gaussians(camera, pc, vmask, is_training=True)
 eager = lambda: ngt.generate(pc._anchor_feat, pc._anchor, pc._offset, pc.get_scaling, params, camera.camera_center, vmask, flags)
 M = run(hip)
+if len(sys.argv) > 4 and sys.argv[4] == "hip":          # the fused path alone (profiling runs: tools/pmc_decode.sh)
+    print(f"anchor decode N={N} k={k}: {M} Gaussians out; forward+backward HIP {timeit(hip):.3f} ms")
+    sys.exit(0)
 with torch.no_grad():
     f_hip, f_eager = timeit(hip, True), timeit(eager, True)
 b_hip, b_eager = timeit(hip), timeit(eager)
