@@ -1078,20 +1078,10 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
     const int waves = ng_partial_rows(m.k);
 #define NG_T16_LAUNCH(K_) hipLaunchKernelGGL(lg::k_ng_backward_t16<K_>, dim3(waves), dim3(64 * NGT_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, \
                                         scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity, \
-                                        dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials)
+                                        dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials, stagger)
     if (ng_use_t16(m.k)) {
-#ifdef LG_NG_T16_DIAG
-        const char* sk = getenv("LIDARGS_NG_T16_SKIP");
-        const int skip = sk ? atoi(sk) : 0;
-#define NG_T16_SKIP(S_) hipLaunchKernelGGL((lg::k_ng_backward_t16<6, S_>), dim3(waves), dim3(64 * NGT_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, \
-                                        scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity, \
-                                        dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials)
-        if (m.k == 6 && skip) {
-            switch (skip) { case 1: NG_T16_SKIP(1); break; case 2: NG_T16_SKIP(2); break; case 4: NG_T16_SKIP(4); break; case 8: NG_T16_SKIP(8); break;
-                            case 16: NG_T16_SKIP(16); break; case 30: NG_T16_SKIP(30); break; default: NG_T16_SKIP(31); break; }
-            return 0;
-        }
-#endif
+        const char* sg = getenv("LIDARGS_NG_T16_STAGGER");
+        const int stagger = sg ? atoi(sg) : 0;
         if (m.k == 4) NG_T16_LAUNCH(4); else if (m.k == 5) NG_T16_LAUNCH(5); else NG_T16_LAUNCH(6);
     } else {
         NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward_mfma<K>, dim3(waves), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset,
