@@ -1052,7 +1052,9 @@ static bool ng_use_t16(int k) {
     const char* e = getenv("LIDARGS_NG_BACKWARD_T16");
     return !(e && e[0] == '0');
 }
-static int ng_partial_rows(int k) { return ng_use_t16(k) ? ng_cus() : 4 * ng_cus(); }
+// LIDARGS_NG_T16_PASSES=1: the four MLPs in one launch (A/B); default two launches (see k_ng_backward_t16)
+static bool ng_t16_two_pass() { const char* e = getenv("LIDARGS_NG_T16_PASSES"); return !(e && e[0] == '1'); }
+static int ng_partial_rows(int k) { return ng_use_t16(k) ? (ng_t16_two_pass() ? 2 : 1) * ng_cus() : 4 * ng_cus(); }
 int lidargs_ng_backward_partials(int n_offsets, int* waves, int* floats_per_wave) {
     const int k = n_offsets;
     if (!(k == 4 || k == 5 || k == 6 || k == 8 || k == 10) || !waves || !floats_per_wave) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_partials: bad argument");
@@ -1076,13 +1078,17 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
     lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)m.k, &s);
     const float3 cam = make_float3(cam_center[0], cam_center[1], cam_center[2]);
     const int waves = ng_partial_rows(m.k);
-#define NG_T16_LAUNCH(K_) hipLaunchKernelGGL(lg::k_ng_backward_t16<K_>, dim3(waves), dim3(64 * NGT_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, \
+#define NG_T16_LAUNCH(K_, P_) hipLaunchKernelGGL((lg::k_ng_backward_t16<K_, P_>), dim3(ng_cus()), dim3(64 * NGT_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, \
                                         scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity, \
                                         dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials, stagger)
     if (ng_use_t16(m.k)) {
         const char* sg = getenv("LIDARGS_NG_T16_STAGGER");
         const int stagger = sg ? atoi(sg) : 0;
-        if (m.k == 4) NG_T16_LAUNCH(4); else if (m.k == 5) NG_T16_LAUNCH(5); else NG_T16_LAUNCH(6);
+        if (ng_t16_two_pass()) {
+            if (m.k == 4) { NG_T16_LAUNCH(4, 1); NG_T16_LAUNCH(4, 2); } else if (m.k == 5) { NG_T16_LAUNCH(5, 1); NG_T16_LAUNCH(5, 2); } else { NG_T16_LAUNCH(6, 1); NG_T16_LAUNCH(6, 2); }
+        } else {
+            if (m.k == 4) NG_T16_LAUNCH(4, 0); else if (m.k == 5) NG_T16_LAUNCH(5, 0); else NG_T16_LAUNCH(6, 0);
+        }
     } else {
         NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_backward_mfma<K>, dim3(waves), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset,
                                             scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity,
