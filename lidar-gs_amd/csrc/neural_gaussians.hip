@@ -1085,7 +1085,7 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
         const char* sg = getenv("LIDARGS_NG_T16_STAGGER");
         const int stagger = sg ? atoi(sg) : 0;
         if (ng_t16_two_pass()) {
-            if (m.k == 4) { NG_T16_LAUNCH(4, 1); NG_T16_LAUNCH(4, 2); } else if (m.k == 5) { NG_T16_LAUNCH(5, 1); NG_T16_LAUNCH(5, 2); } else { NG_T16_LAUNCH(6, 1); NG_T16_LAUNCH(6, 2); }
+            if (m.k == 4) { NG_T16_LAUNCH(4, 2); NG_T16_LAUNCH(4, 1); } else if (m.k == 5) { NG_T16_LAUNCH(5, 2); NG_T16_LAUNCH(5, 1); } else { NG_T16_LAUNCH(6, 2); NG_T16_LAUNCH(6, 1); }
         } else {
             if (m.k == 4) NG_T16_LAUNCH(4, 0); else if (m.k == 5) NG_T16_LAUNCH(5, 0); else NG_T16_LAUNCH(6, 0);
         }

@@ -3,5 +3,5 @@
 R=$GRAFT_REPO_ROOT
 cd $R
 LIDARGS_EXTRA_HIPCC_FLAGS="-DLG_NG_T16_DIAG $*" python lidar-gs_amd/build_hip.py --force > /dev/null
-timeout 120 python tools/time_decode.py 666667 6 3 hip 2>&1 | grep "^t16" | tail -4
+timeout 120 python tools/time_decode.py 666667 6 3 hip 2>&1 | grep "^t16" | tail -8
 python lidar-gs_amd/build_hip.py --force > /dev/null
