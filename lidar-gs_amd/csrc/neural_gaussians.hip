@@ -934,6 +934,19 @@ int ng_model(const lidargs_ng_model* in, lg::NgModel* out) {
     }
     return 0;
 }
+// k <= 6: the forward's two MLP launches on 16x16x4 tiles (k_ng_opacity_t16 / k_ng_decode_t16: persistent workgroups of twelve waves, weights in
+// LDS); k = 8, 10 and LIDARGS_NG_FORWARD_T16=0 (A/B, test variant): the 32x32x2 kernels, one wave per workgroup
+static bool ng_forward_t16(int k) {
+    if (k > 6) return false;
+    const char* e = getenv("LIDARGS_NG_FORWARD_T16");
+    return !(e && e[0] == '0');
+}
+static int ng_forward_grid(int N) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int need = ((N + 31) / 32 + NGF_WAVES - 1) / NGF_WAVES;
+    return need < cus ? (need > 0 ? need : 1) : cus;
+}
 #define NG_DISPATCH(K_, CALL) switch (K_) { case 4: { constexpr int K = 4; CALL; } break; case 5: { constexpr int K = 5; CALL; } break; \
     case 6: { constexpr int K = 6; CALL; } break; case 8: { constexpr int K = 8; CALL; } break; default: { constexpr int K = 10; CALL; } break; }
 #define NG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return lg::api_fail(LIDARGS_ERR_HIP, hipGetErrorString(e_)); } while (0)
@@ -964,6 +977,12 @@ static int ng_forward_select(int N, const lidargs_ng_model* model, const uint8_t
     if (per_lane || !m.W2T[0]) {
         NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_opacity<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, s.vis_flags,
                                             s.vis_idx, neural_opacity, mask, s.sel_flags));
+    } else if (ng_forward_t16(m.k)) {
+        const int grid = ng_forward_grid(N);
+#define NG_OPA_T16(K_) hipLaunchKernelGGL(lg::k_ng_opacity_t16<K_>, dim3(grid), dim3(64 * NGF_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, s.vis_flags, \
+                                            s.vis_idx, neural_opacity, mask, s.sel_flags)
+        if (m.k == 4) NG_OPA_T16(4); else if (m.k == 5) NG_OPA_T16(5); else NG_OPA_T16(6);
+#undef NG_OPA_T16
     } else {
         NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_opacity_mfma<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, s.vis_flags,
                                             s.vis_idx, neural_opacity, mask, s.sel_flags));
@@ -1007,6 +1026,12 @@ int lidargs_ng_forward_decode(int N, const lidargs_ng_model* model, const float*
     if (per_lane || !m.W2T[0] || !m.W2T[1] || !m.W2T[2] || !m.W2T[3]) {     // the matrix-pipe decode reads the transposed second-layer weights
     NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_decode<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset, scaling,
                                         s.vis_flags, s.vis_idx, s.sel_flags, s.slot, neural_opacity, out_xyz, out_color, out_opacity, out_scaling, out_rot));
+    } else if (ng_forward_t16(m.k)) {
+        const int grid = ng_forward_grid(N);
+#define NG_DEC_T16(K_) hipLaunchKernelGGL(lg::k_ng_decode_t16<K_>, dim3(grid), dim3(64 * NGF_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, scaling, \
+                                        s.vis_flags, s.vis_idx, s.sel_flags, s.slot, neural_opacity, out_xyz, out_color, out_opacity, out_scaling, out_rot)
+        if (m.k == 4) NG_DEC_T16(4); else if (m.k == 5) NG_DEC_T16(5); else NG_DEC_T16(6);
+#undef NG_DEC_T16
     } else {
     NG_DISPATCH(m.k, hipLaunchKernelGGL(lg::k_ng_decode_mfma<K>, dim3((N + 63) / 64), dim3(64), 0, stream, N, m, cam, anchor_feat, anchor, offset, scaling,
                                         s.vis_flags, s.vis_idx, s.sel_flags, s.slot, neural_opacity, out_xyz, out_color, out_opacity, out_scaling, out_rot));

@@ -119,6 +119,34 @@ def test_decode_gemm_fed_backward_still_matches(hip_lib_built, monkeypatch):
         parity("d" + k, r["g_" + k], exp["g_" + k], rtol=5e-4)
 
 
+@pytest.mark.parametrize("env", [{"LIDARGS_NG_T16_PASSES": "1"}, {"LIDARGS_NG_BACKWARD_T16": "0"}], ids=["t16_one_launch", "mfma_32x32"])
+@pytest.mark.parametrize("case", ["a", "b", "random_k4"])
+def test_decode_backward_variants_match(env, case, hip_lib_built, monkeypatch):
+    """The backward runs as two launches of k_ng_backward_t16 (16x16x4 tiles, k <= 6) by default.  The same kernel as one launch
+    (LIDARGS_NG_T16_PASSES=1) and round 4's k_ng_backward_mfma (32x32x2 tiles, LIDARGS_NG_BACKWARD_T16=0: the path k = 8, 10 take) stay
+    selectable: same gradients against the reference's golden cases and the oracle, same partial-row layout for the reduction."""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    if case in ("a", "b"):
+        p, cam, vis, exp = load_case(case)
+        ups = [exp["up_" + k] for k in ("xyz", "color", "opacity", "scaling", "rot")]
+        ref = {k: exp["g_" + k] for k in ("anchor_feat", "anchor", "offset", "scaling") + tuple(PARAM_KEYS)}
+    else:
+        p, cam, vis, rng = random_case(5000, 4, 13, (True, False, False))
+        f = ng.forward(p, cam, vis)
+        M = f["xyz"].shape[0]
+        ups = [rng.normal(size=s).astype(np.float32) for s in ((M, 3), (M, 2), (M, 1), (M, 3), (M, 4))]
+        g = ng.backward(p, f, *ups)
+        ref = {k: g[k] for k in ("anchor_feat", "anchor", "offset", "scaling") + tuple(PARAM_KEYS)}
+    r = run_hip(p, cam, vis, ups)
+    if case == "random_k4" and int((r["mask"] != f["mask"]).sum()):
+        pytest.skip("an opacity within rounding of 0 landed on the other side of the mask: the upstream rows do not line up")
+    for k in ("anchor_feat", "anchor", "offset", "scaling"):
+        parity("d" + k, r["g_" + k], ref[k])
+    for k in PARAM_KEYS:
+        parity("d" + k, r["g_" + k], ref[k], rtol=5e-4)
+
+
 def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_built, monkeypatch):
     """A caller of the C ABI that passes no W2T gets the one-anchor-per-lane decode (k_ng_decode): same outputs as the golden case
     (forward only: the backward needs W2T)."""
