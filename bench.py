@@ -690,10 +690,11 @@ def bench_decode(args):
         ev[0].record(); torch.autograd.backward(list(outs), ups); ev[1].record()
         torch.cuda.synchronize()
         t_bwd += ev[0].elapsed_time(ev[1]) / 10 * 1e-3
-    # matrix-pipe side of the backward: 1064 v_mfma_f32_32x32x2_f32 per 64-anchor tile (counters: 11.08 M per launch at
-    # 666 k anchors), 4096 flop each, against the 157.3 TFLOP/s dense f32 MFMA peak (MI355X_MICROARCH.md)
-    mfma_insts = ((n_vis + 63) // 64) * 1064
-    mfma_flop = mfma_insts * 4096.0
+    # matrix-pipe side of the backward (round 5: two launches of k_ng_backward_t16): 788 v_mfma_f32_16x16x4_f32 per 32-anchor tile (272 in
+    # the covariance launch, 516 in the heads'; counters: 16.4 M per step at 666 k anchors), 2048 flop each, against the 157.3 TFLOP/s
+    # dense f32 MFMA peak (MI355X_MICROARCH.md)
+    mfma_insts = ((n_vis + 31) // 32) * 788
+    mfma_flop = mfma_insts * 2048.0
     # algorithmic bytes: inputs once per visible anchor + the bool mask, outputs once, and the same again (+ upstream gradients,
     # dense input gradients) for the backward; the per-anchor activations the weight-gradient GEMMs read are NOT counted
     fwd_b = N + n_vis * (128 + 12 + 12 * k + 24) + n_vis * k * 5 + M * 52
@@ -706,11 +707,13 @@ def bench_decode(args):
            "roofline": {"bound": "hbm", "kernel": "k_ng_opacity + k_ng_decode + k_ng_backward + weight-gradient GEMMs (whole step)",
                         "achieved": (fwd_b + bwd_b) / t_hip / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (fwd_b + bwd_b) / t_hip / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "mfma": {"bound": "mfma", "kernel": "k_ng_backward_mfma (the backward call: kernel + partial-sum fold + autograd glue)",
+                        "mfma": {"bound": "mfma", "kernel": "k_ng_backward_t16 x 2 (the backward call: both launches + partial-sum fold + autograd glue)",
                                  "achieved": mfma_flop / t_bwd / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": mfma_flop / t_bwd / 1e12 / 157.3,
                                  "mfma_instructions_per_launch": mfma_insts, "backward_ms": t_bwd * 1e3,
-                                 "note": "f32-in / f32-accumulate v_mfma_f32_32x32x2_f32, 4096 flop per instruction; the products are a third of "
-                                         "the launch, the per-anchor VALU stage and its LDS round trips the rest (DESIGN.md section 7, EXPERIMENTS.md 6b)"}}}
+                                 "note": "f32-in / f32-accumulate v_mfma_f32_16x16x4_f32, 2048 flop per instruction (round 4's 32x32x2 form issued "
+                                         "1064 x 4096 flop per 64 anchors: 1.35 x the flops for the same result, so fractions across rounds compare by "
+                                         "backward_ms, not by frac); the rest of the launches is the tile's memory round trips and the per-anchor "
+                                         "stage (DESIGN.md section 7, EXPERIMENTS.md round 5)"}}}
     if not args.no_cpu_baseline:
         from oracle import neural_gaussians as ng
         from oracle import neural_gaussians_torch as ngt
@@ -851,8 +854,9 @@ def bench_train_step(args):
     t_step = (time.perf_counter() - t0) / args.steps
     for _ in range(5):
         step(True)
-    # the step's longest launch, k_ng_backward_mfma, timed by HIP events on the op's stream around its C-ABI call (5 more steps): its
-    # matrix-pipe side against the dense f32 MFMA peak (1064 v_mfma_f32_32x32x2_f32 per 64-anchor tile, 4096 flop each)
+    # the step's longest call, the decode's backward (two launches of k_ng_backward_t16), timed by HIP events on the op's stream around its
+    # C-ABI call (5 more steps): its matrix-pipe side against the dense f32 MFMA peak (788 v_mfma_f32_16x16x4_f32 per 32-anchor tile, 2048
+    # flop each)
     import neural_gaussians as ngmod
     real_call = ngmod._lib.lidargs_ng_backward_mfma
     spans = []
@@ -875,11 +879,12 @@ def bench_train_step(args):
     finally:
         ngmod._lib = ngmod._lib_real
     t_bwd_kernel = sum(a.elapsed_time(b) for a, b in spans) / max(1, len(spans)) * 1e-3
-    mfma_insts = ((N + 63) // 64) * 1064
-    mfma = {"bound": "mfma", "kernel": "k_ng_backward_mfma (the step's longest launch; HIP events around its C-ABI call inside the step)",
-            "achieved": mfma_insts * 4096.0 / t_bwd_kernel / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": mfma_insts * 4096.0 / t_bwd_kernel / 1e12 / 157.3,
+    mfma_insts = ((N + 31) // 32) * 788
+    mfma = {"bound": "mfma", "kernel": "k_ng_backward_t16 x 2 (the step's longest call; HIP events around its C-ABI call inside the step)",
+            "achieved": mfma_insts * 2048.0 / t_bwd_kernel / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": mfma_insts * 2048.0 / t_bwd_kernel / 1e12 / 157.3,
             "traffic": None, "ms": t_bwd_kernel * 1e3, "mfma_instructions_per_launch": mfma_insts,
-            "note": "f32-in / f32-accumulate tile products; they are a third of the launch, the per-anchor VALU stage and its LDS round trips the rest"}
+            "note": "f32-in / f32-accumulate 16x16x4 tile products (round 4: 32x32x2 tiles, 1.35 x the flops for the same result, 885 us); the rest of "
+                    "the two launches is the tile's memory round trips and the per-anchor stage"}
     print(json.dumps({
         "metric": "training-step core (decode + rasterize + loss, fwd+bwd) per second", "value": 1.0 / t_step, "unit": "steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "strong",

@@ -81,10 +81,12 @@ int lidargs_ng_backward(int N, int n_visible, const lidargs_ng_model* model, con
                         float* dL_dscaling_in, float* act_x, float* act_h, float* delta1, float* delta2,
                         char* scratch, size_t scratch_bytes, void* stream);
 
-/* Backward on the matrix pipe (v_mfma_f32_32x32x2_f32, exact f32): recompute, back-propagation and the weight gradients of the four
+/* Backward on the matrix pipe (f32 in, f32 accumulate: v_mfma_f32_16x16x4_f32 for k <= 6, v_mfma_f32_32x32x2_f32 for k = 8, 10): recompute, back-propagation and the weight gradients of the four
  * MLPs as 32-row tile products; nothing per-anchor is written for a GEMM to read.  Same inputs and dense outputs as
  * lidargs_ng_backward; instead of act_x / act_h / delta1 / delta2 the kernel's persistent waves write partial sums:
- * partials f32[waves][floats_per_wave] (sizes from lidargs_ng_backward_partials), and the SUM OVER WAVES is
+ * partials f32[waves][floats_per_wave] (sizes from lidargs_ng_backward_partials; `waves` = the number of partial ROWS: round 4 one per
+ * wave, 4 x CUs; round 5 (k <= 6: 16x16x4 tiles, two launches) one per workgroup and launch, 2 x CUs -- a caller sizes the array and
+ * calls lidargs_ng_reduce_weight_grads with whatever this function reports), and the SUM OVER WAVES is
  *   tiles  f32[5 + T2][32][32], T2 = 3 + ceil(7k/32):
  *     tile m (m = 0 opacity, 1 covariance, 2 colour, 3 ray-drop)  [t][q]  dW1_m[t][q], q = 0..31
  *     tile 4   [t][8 m + j]   dW1_m[t][32 + j], j = 0..3, and db1_m[t] at j = 4 (input 36 is the constant 1)

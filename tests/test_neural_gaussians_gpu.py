@@ -147,6 +147,22 @@ def test_decode_backward_variants_match(env, case, hip_lib_built, monkeypatch):
         parity("d" + k, r["g_" + k], ref[k], rtol=5e-4)
 
 
+def test_forward_tile_forms_agree_bit_for_bit(hip_lib_built, monkeypatch):
+    """The forward's MLPs run on 16x16x4 tiles (k_ng_opacity_t16 / k_ng_decode_t16, k <= 6) by default and on 32x32x2 tiles with
+    LIDARGS_NG_FORWARD_T16=0 (the path k = 8, 10 take).  Both are the same f32 fma chain per output -- bias first, inputs in ascending
+    order -- so the mask (opacity > 0) and every output agree bit for bit; k = 6 with a visibility mask and k = 5 (an odd offset count:
+    the halves of an anchor's lane pair own 3 + 2 offsets)."""
+    for N, k, seed, flags in ((9000, 6, 31, (True, True, True)), (4000, 5, 32, (False, True, False)), (3000, 4, 33, (True, False, True))):
+        p, cam, vis, _rng = random_case(N, k, seed, flags)
+        monkeypatch.setenv("LIDARGS_NG_FORWARD_T16", "1")
+        t16 = run_hip(p, cam, vis, None)
+        monkeypatch.setenv("LIDARGS_NG_FORWARD_T16", "0")
+        wide = run_hip(p, cam, vis, None)
+        assert np.array_equal(t16["mask"], wide["mask"])
+        for key in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
+            assert np.array_equal(t16[key], wide[key]), (k, key, float(np.abs(t16[key] - wide[key]).max()))
+
+
 def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_built, monkeypatch):
     """A caller of the C ABI that passes no W2T gets the one-anchor-per-lane decode (k_ng_decode): same outputs as the golden case
     (forward only: the backward needs W2T)."""
