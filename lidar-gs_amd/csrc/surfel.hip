@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(64) k_sf_combine(const SfFwdArgs a) {
     float T_final = 1.f, T_start = 1.f;
     uint32_t last = 0, med_c = 0;
     bool stopped = false;
-    // two segments per step: their thirty loads are issued together (every plane below St was written by pass 2), and a pixel whose
+    // four segments per step (two until round 5: 34 -> see EXPERIMENTS): their sixty loads are issued together (every plane below St was written by pass 2), and a pixel whose
     // walk has ended simply stops taking them; the patch leaves once all of its pixels have
     struct Seg { float tend, m1, m2, dist, c0, c1, d, n0, n1, n2, med, tpass, tbreak; uint32_t l, mc; };
     auto load = [&](int k) {
@@ -626,10 +626,12 @@ __global__ void __launch_bounds__(64) k_sf_combine(const SfFwdArgs a) {
         T_start = use ? T_start * g.tpass : T_start;                       // what pass 2 started the next segment from
         stopped = stopped || (use && g.tbreak < 0.0001f);
     };
-    for (int k0 = 0; k0 < St; k0 += 2) {
-        const Seg g0 = load(k0), g1 = load(min(k0 + 1, St - 1));
+    for (int k0 = 0; k0 < St; k0 += 4) {
+        const Seg g0 = load(k0), g1 = load(min(k0 + 1, St - 1)), g2 = load(min(k0 + 2, St - 1)), g3 = load(min(k0 + 3, St - 1));
         fold(g0, k0, true);
         fold(g1, k0 + 1, k0 + 1 < St);
+        fold(g2, k0 + 2, k0 + 2 < St);
+        fold(g3, k0 + 3, k0 + 3 < St);
         if (__ballot(!stopped) == 0ull) break;
     }
     const size_t N = (size_t)a.grid.W * a.grid.H;
