@@ -147,11 +147,12 @@ def test_decode_backward_variants_match(env, case, hip_lib_built, monkeypatch):
         parity("d" + k, r["g_" + k], ref[k], rtol=5e-4)
 
 
-def test_forward_tile_forms_agree_bit_for_bit(hip_lib_built, monkeypatch):
+def test_forward_tile_forms_agree(hip_lib_built, monkeypatch):
     """The forward's MLPs run on 16x16x4 tiles (k_ng_opacity_t16 / k_ng_decode_t16, k <= 6) by default and on 32x32x2 tiles with
-    LIDARGS_NG_FORWARD_T16=0 (the path k = 8, 10 take).  Both are the same f32 fma chain per output -- bias first, inputs in ascending
-    order -- so the mask (opacity > 0) and every output agree bit for bit; k = 6 with a visibility mask and k = 5 (an odd offset count:
-    the halves of an anchor's lane pair own 3 + 2 offsets)."""
+    LIDARGS_NG_FORWARD_T16=0 (the path k = 8, 10 take).  Both accumulate bias first, inputs in ascending order; the matrix pipe adds the
+    four products of a 16x16x4 step in its own order, so outputs may differ in the last bit (measured: 1 ulp on a few colours) -- the mask
+    (opacity > 0) agrees on these cases and every output agrees to 2e-6; k = 6 with a visibility mask, k = 5 (an odd offset count: the
+    halves of an anchor's lane pair own 3 + 2 offsets) and k = 4."""
     for N, k, seed, flags in ((9000, 6, 31, (True, True, True)), (4000, 5, 32, (False, True, False)), (3000, 4, 33, (True, False, True))):
         p, cam, vis, _rng = random_case(N, k, seed, flags)
         monkeypatch.setenv("LIDARGS_NG_FORWARD_T16", "1")
@@ -160,8 +161,8 @@ def test_forward_tile_forms_agree_bit_for_bit(hip_lib_built, monkeypatch):
         wide = run_hip(p, cam, vis, None)
         assert np.array_equal(t16["mask"], wide["mask"])
         for key in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity"):
-            assert np.array_equal(t16[key], wide[key]), (k, key, float(np.abs(t16[key] - wide[key]).max()))
-
+            d = float(np.abs(t16[key].astype(np.float64) - wide[key]).max())
+            assert d <= 2e-6 * max(1.0, float(np.abs(wide[key]).max())), (k, key, d)
 
 def test_decode_without_transposed_weights_uses_the_per_lane_kernel(hip_lib_built, monkeypatch):
     """A caller of the C ABI that passes no W2T gets the one-anchor-per-lane decode (k_ng_decode): same outputs as the golden case
