@@ -604,8 +604,11 @@ __global__ void __launch_bounds__(256) k_gaussian_backward(const GaussBwdArgs a)
     const int region = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int base = region * LG_REGION;
     if (base >= a.P) return;
-    const int cnt = (int)a.tcount[region];
-    int off = (int)a.tlist[base + lane];                               // with the count, not behind it (the list is padded: any slot may be read)
+    // the list slot with the count, not behind it (the list is padded: any slot may be read).  Left to itself the compiler sinks the slot's
+    // load below the test on the count -- two round trips where one does --, so both values pass through an empty asm statement
+    int off = (int)a.tlist[base + lane];
+    int cnt = (int)a.tcount[region];
+    asm volatile("" : "+v"(off), "+v"(cnt));
     for (int j = lane; j < cnt; j += 64) {
         gb_row(a, base + off);
         if (j + 64 < cnt) off = (int)a.tlist[base + j + 64];

@@ -931,8 +931,9 @@ __global__ void __launch_bounds__(256) k_sf_gaussian_backward(const SfGaussBwdAr
     const int region = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int base = region * LG_REGION;
     if (base >= a.P) return;
-    const int cnt = (int)a.tcount[region];
-    int off = (int)a.tlist[base + lane];                               // with the count, not behind it (the list is padded)
+    int off = (int)a.tlist[base + lane];                               // with the count, not behind it (the list is padded); through an empty asm
+    int cnt = (int)a.tcount[region];                                   // statement, or the compiler sinks the slot's load below the test on the count
+    asm volatile("" : "+v"(off), "+v"(cnt));
     for (int j = lane; j < cnt; j += 64) {
         sf_gb_row(a, base + off);
         if (j + 64 < cnt) off = (int)a.tlist[base + j + 64];
