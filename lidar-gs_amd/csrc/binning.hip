@@ -784,12 +784,20 @@ __global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_
     for (int q = 0; q < W; q++) start += s_red[0][q];
     uint32_t k[ITEMS], v[ITEMS];
     if (fits) {
+        // every pair is requested before the first is looked at, from an index any lane may read (its own, or the bucket's last): with the
+        // smallest / largest key folded inside the loading loop each round waited for its key before the next was asked for -- fourteen
+        // round trips one behind the other (ISA of the first form: `G | G w1` x 14)
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const uint32_t i = lo + (uint32_t)r * 64u + lane;
-            const bool valid = i < hi;
-            k[r] = valid ? keys[start + i] : 0u; v[r] = valid ? ids[start + i] : 0u;
+            const uint32_t ic = i < n ? i : n - 1u;
+            k[r] = keys[start + ic]; v[r] = ids[start + ic];
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const bool valid = lo + (uint32_t)r * 64u + lane < hi;
             if (valid) { kmn = min(kmn, k[r]); kmx = max(kmx, k[r]); }
+            else { k[r] = 0u; v[r] = 0u; }
         }
     } else {
         for (uint32_t i = tid; i < n; i += 64 * W) { const uint32_t kk = keys[start + i]; kmn = min(kmn, kk); kmx = max(kmx, kk); }
