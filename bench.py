@@ -1005,6 +1005,73 @@ def bench_points_meter(args):
     print(json.dumps(res))
 
 
+def bench_anchor_growing(args):
+    """SURVEY section 8 row f4, second half: GaussianModel.anchor_growing (scene/gaussian_model.py:677-775) at 1.2 M anchors x 6 offsets --
+    the three levels (voxel edges 16 / 4 / 1 voxel sizes, thresholds x1 / x2 / x4) as three native calls, beside the reference's own op
+    sequence (torch.unique + the chunked candidate-voxel x anchor equality scan + scatter max) run by torch on the same GPU."""
+    import numpy as np
+    assert args.gpus == 1 and torch.cuda.is_available()
+    import build_hip
+    build_hip.build()
+    import anchor_growing as ag
+    import lidargs_scenes as sc
+    c = sc.anchor_scene(1_200_000, 6, 21)
+    N, k, F = c["N"], c["k"], c["feat"].shape[1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    anchor, offset, scaling, feat, grads, om = t(c["anchor"]), t(c["offset"]), torch.exp(t(c["scaling"])), t(c["feat"]), t(c["grads"]), t(c["offset_mask"])
+    g = torch.Generator(device="cuda").manual_seed(7)
+    rands = [torch.rand(N * k, device="cuda", generator=g) for _ in range(3)]
+    levels = [(0.0005 * 2 ** i, 0.5 ** (i + 1), c["voxel"] * (16 // 4 ** i)) for i in range(3)]      # scene/gaussian_model.py:682, :688, :703-704 with arguments/__init__.py:55-57, :155
+
+    def step():
+        return [ag.grow_level(anchor, offset, scaling, feat, grads, om, rands[i], *levels[i]) for i in range(3)]
+    warm = max(2, args.warmup // 5)
+    for _ in range(warm):
+        res = step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = max(5, args.steps // 10)
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    tt = (time.perf_counter() - t0) / steps
+    counts = [r[2] for r in res]
+    C, V, U = (sum(x[j] for x in counts) for j in range(3))
+    # what a level has to move: 9 B per offset through the mask (gradient, mask byte, random draw), 48 B per candidate (its offset row, its anchor's
+    # position and scaling row), 12 B per anchor through the probe, F floats per candidate in and per new anchor out, 12 B per new anchor
+    alg = 3 * (9.0 * N * k + 12.0 * N) + 48.0 * C + 4.0 * F * C + (12.0 + 4.0 * F) * U
+    out = {"metric": "anchor_growing evaluations per second (three levels, 1.2 M anchors x 6 offsets)", "value": 1.0 / tt, "unit": "evaluations/s", "n_gpus": 1,
+           "steps": steps, "warmup": warm, "ms_per_step": tt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32/u64 keys, f32 quantisation",
+           "data": "synthetic",
+           "config": {"workload": f"anchor_growing: {N} anchors x {k} offsets, voxel 0.01 m, levels (threshold, keep-probability, voxel edge) = "
+                                  + ", ".join("(%.4g, %.3g, %.2f)" % (a, 1 - b, s_) for a, b, s_ in levels),
+                      "per_level_candidates_voxels_new": counts},
+           "roofline": {"bound": "hbm", "kernel": "k_ag_mark (x3: the 7.2 M-offset mask pass) + the hash-set passes", "achieved": alg / tt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": alg / tt / 1e9 / 8000.0, "traffic": None,
+                        "algorithmic_bytes": "per level 9 B per offset + 12 B per anchor; 48 B + 4 F B per candidate; (12 + 4 F) B per new anchor; two host reads per level (counts size the buffers)"}}
+    if not args.no_cpu_baseline:
+        # the reference's dataflow on this GPU (kind "port": its op sequence restated with the same torch ops, oracle/anchor_growing_torch.py)
+        from oracle import anchor_growing as oag
+        from oracle import anchor_growing_torch as agt
+        ref = lambda chunked: [agt.grow_level(anchor, offset, scaling, feat, grads, om, rands[i], *levels[i], k, chunked=chunked) for i in range(3)]
+        r0 = ref(True); torch.cuda.synchronize()
+        t0 = time.perf_counter(); r0 = ref(True); torch.cuda.synchronize(); tr = time.perf_counter() - t0
+        same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and tuple(a[2]) == tuple(b[2]) for a, b in zip(res, r0))
+        out["framework_ops_same_gpu"] = {"ms": tr * 1e3, "speedup": tr / tt, "identical_outputs": bool(same),
+                                         "what": "torch.unique(dim=0) + the reference's chunked (candidate voxel x anchor) equality scan in chunks of 4096 anchors + scatter amax, torch-ROCm on this GPU"}
+        # host cores: the numpy oracle on the same three levels
+        act = np.exp(c["scaling"]).astype(np.float32)
+        t0 = time.perf_counter()
+        for i in range(3):
+            cand = oag.candidate_mask(c["grads"], c["offset_mask"], rands[i].cpu().numpy(), levels[i][0], levels[i][1], N * k)
+            oag.grow_level(c["anchor"], c["offset"], act, c["feat"], cand, levels[i][2], exact_division=False)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "evaluations/s", "cores": 1, "kind": "port",
+                               "sample": f"one evaluation (the same three levels, the same inputs) with oracle/anchor_growing.py (numpy: sort-based unique, isin, maximum.at), {tc:.2f} s"}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def _flush_c_stdio():
     """RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that buffer is only written at
     process exit, i.e. AFTER the JSON line.  Flushing it early keeps the JSON line the last thing on stdout."""
@@ -1052,7 +1119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3",
-                    help="cfg3 (headline) | cfg2 (forward only, as BASELINE.json states it) | cfg4 | cfg5 | render_fps | decode | loss | train_step | chamfer | points_meter")
+                    help="cfg3 (headline) | cfg2 (forward only, as BASELINE.json states it) | cfg4 | cfg5 | render_fps | decode | loss | train_step | chamfer | points_meter | anchor_growing")
     ap.add_argument("--fwd-only", action="store_true", help="time the rasterizer forward alone (default for cfg2)")
     ap.add_argument("--fwd-bwd", action="store_true", help="forward + backward also for cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1086,6 +1153,8 @@ def main():
         return bench_chamfer(args)
     if args.workload == "points_meter":
         return bench_points_meter(args)
+    if args.workload == "anchor_growing":
+        return bench_anchor_growing(args)
     if args.workload == "render_fps":
         return bench_render_fps(args)
     import lidargs_scenes as sc

@@ -29,6 +29,7 @@ SOURCES = {
     "lidar_loss.hip": [],
     "chamfer.hip": ["-ffp-contract=off"],        # the squared distance must round as the reference writes it: the argmin index is compared bit for bit
     "surfel.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],   # ray/plane hit point cancels ~3 digits: round as the reference writes it
+    "anchor_growing.hip": ["-ffp-contract=off"],   # anchor + offset * scaling is two roundings in torch: the voxel an offset falls into is compared bit for bit
 }
 
 

@@ -257,3 +257,18 @@ def sweep_case(seed, mid=None):
         scene["opacities"] = (scene["opacities"] * np.float32(0.008)).astype(np.float32)
     grads = upstream_grads(H, W, seed % 1000)
     return scene, W, H, grads, kw, dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, **kw)
+
+
+def anchor_scene(N, k, seed, voxel=0.01, feat_dim=32):
+    """Inputs of anchor growing (tests/test_anchor_growing.py, bench.py --workload anchor_growing): N street-like
+    anchors on the voxel grid (the reference's initialisation leaves them there, scene/gaussian_model.py:274), k offsets each of up to a
+    few dozen voxels, log-space scalings, features, and accumulated gradient norms drawn so that the three levels' thresholds
+    (0.0005, 0.001, 0.002) select ~3 %, ~0.35 % and ~0.003 % of the offsets."""
+    rng = np.random.default_rng(seed)
+    M = N + N // 8
+    cells = np.unique(np.round(np.stack([rng.uniform(-60, 60, M), rng.uniform(-12, 12, M), rng.normal(-1.5, 0.4, M)], 1) / voxel), axis=0)
+    anchor = (cells[rng.permutation(cells.shape[0])[:N]] * voxel).astype(np.float32)
+    N = anchor.shape[0]
+    return dict(N=N, k=k, voxel=voxel, anchor=anchor, offset=rng.uniform(-1, 1, (N, k, 3)).astype(np.float32),
+                scaling=np.log(rng.uniform(0.02, 0.4, (N, 6))).astype(np.float32), feat=rng.normal(size=(N, feat_dim)).astype(np.float32),
+                grads=rng.exponential(0.0002, N * k).astype(np.float32), offset_mask=rng.random(N * k) > 0.3)

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "lidargs_rasterizer.h")
 HEADERS = [HEADER, os.path.join(ROOT, "include", "lidargs_neural_gaussians.h"), os.path.join(ROOT, "include", "lidargs_loss.h"),
-           os.path.join(ROOT, "include", "lidargs_chamfer.h")]
+           os.path.join(ROOT, "include", "lidargs_chamfer.h"), os.path.join(ROOT, "include", "lidargs_anchor_growing.h")]
 
 
 def _declared_functions():
