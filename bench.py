@@ -507,7 +507,10 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     base_C.profile_enable(False)
     stages = base_C.profile_summary()
     V = int((radii > 0).sum())
+    base_C.counters_enable(True)            # one more frame, outside the timed region, that ends with the counting launches
+    step(); torch.cuda.synchronize()
     cnt = base_C.last_counters()
+    base_C.counters_enable(False)
     info["R"] = int(cnt["instances"])
     table = raster_kernel_table(P, V, info["R"], H * W, stages, surfel=True, taken=int(cnt["taken_instances"]), touched=int(cnt.get("touched", -1)))
     pmc_names = {"k_sf_render_backward": ["lg::k_sf_render_backward"], "k_sf_preprocess": ["lg::k_sf_preprocess<false>"],
@@ -1231,8 +1234,13 @@ def main():
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
-        return dict(elapsed=el, stages=_C.profile_summary(), cnt=_C.last_counters(),
-                    allocs=int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0))
+        allocs = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0)
+        stages = _C.profile_summary()
+        _C.counters_enable(True)            # one more frame, outside the timed region, that ends with the counting launches (lidargs_last_counters)
+        step(); barrier()
+        cnt = _C.last_counters()
+        _C.counters_enable(False)
+        return dict(elapsed=el, stages=stages, cnt=cnt, allocs=allocs)
 
     cuts = {}
     if not sharded:
@@ -1312,8 +1320,12 @@ def main():
             for _ in range(16):
                 eager2()
             torch.cuda.synchronize()
-            res["stages"], res["cnt"] = _C.profile_summary(), _C.last_counters()
+            res["stages"] = _C.profile_summary()
             _C.profile_enable(False)
+            _C.counters_enable(True)
+            eager2(); torch.cuda.synchronize()
+            res["cnt"] = _C.last_counters()
+            _C.counters_enable(False)
     else:
         import math
         import torch.distributed as dist

@@ -35,10 +35,13 @@ extern "C" {
 #endif
 
 /* flags */
-#define LIDARGS_AG_EXACT_DIVISION 1 /* quotient x / cur_size as an IEEE division (what torch's CPU kernel computes and the golden fixture
-                                       pins); default 0: x * (1 / cur_size) with the reciprocal rounded to float32 -- what torch's DEVICE
-                                       kernel computes for `tensor / python_scalar` (ATen BinaryDivTrueKernel.cu), i.e. what the reference
-                                       computes where it really runs */
+#define LIDARGS_AG_EXACT_DIVISION 1 /* quotient x / float32(cur_size) as an IEEE division (what torch's CPU kernel computes and the golden
+                                       fixture pins); default 0: x * float32(1.0 / cur_size), the reciprocal of the Python DOUBLE rounded to
+                                       float32 -- what torch's DEVICE kernel computes for `tensor / python_scalar` (ATen
+                                       BinaryDivTrueKernel.cu), i.e. what the reference computes where it really runs.  Measured bit for bit
+                                       against torch-ROCm on the MI355X for eight voxel sizes (tools/div_convention.py,
+                                       profiles/r06_div_convention.txt): 4 M quotients each, 0 differences; the IEEE quotient puts 7-600 of
+                                       them into another voxel, the float32 reciprocal 44-900 where 1/float32(s) != float32(1/s) */
 
 /* Bytes of the fixed scratch buffer: the candidate list (one word per offset that existed at the start) + counters. */
 size_t lidargs_ag_scratch_bytes(int N0, int n_offsets);
@@ -52,8 +55,10 @@ size_t lidargs_ag_scratch_bytes(int N0, int n_offsets);
  *   grads          f32[N0*k]     norm of the accumulated offset gradient (:779-780)
  *   offset_mask    u8[N0*k]      torch.bool (:781)
  *   rand           f32[N0*k]     the uniform draws of :687, or NULL = keep every candidate
- *   grad_threshold, rand_threshold, cur_size   the level's three scalars, already rounded to float32 (torch casts the Python double to the
- *                  tensor's dtype for the compares and the quotient)
+ *   grad_threshold, rand_threshold   the level's compare scalars, already rounded to float32 (torch casts the Python double to the
+ *                  tensor's dtype for a compare)
+ *   cur_size       voxel_size * size_factor (:704) as the Python DOUBLE: the quotient's reciprocal is taken from it before rounding
+ *                  (see LIDARGS_AG_EXACT_DIVISION); new_anchor = float32(voxel) * float32(cur_size)
  *   alloc_work     called at most once: working memory (hash set, sort buffers), free after the call returns
  *   alloc_anchor / alloc_feat   called at most once each, only when U > 0, with exactly U*3*4 and U*F*4 bytes: the outputs
  *                  new_anchor f32[U,3] (candidate_anchor, :730) and new_feat f32[U,F] (:742), rows in torch.unique's order
@@ -61,7 +66,7 @@ size_t lidargs_ag_scratch_bytes(int N0, int n_offsets);
  */
 int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, const float* anchor, const float* offset, const float* scaling,
                                  const float* anchor_feat, const float* grads, const uint8_t* offset_mask, const float* rand,
-                                 float grad_threshold, float rand_threshold, float cur_size, int flags, char* scratch, size_t scratch_bytes,
+                                 float grad_threshold, float rand_threshold, double cur_size, int flags, char* scratch, size_t scratch_bytes,
                                  lidargs_alloc_fn alloc_work, void* work_user, lidargs_alloc_fn alloc_anchor, void* anchor_user,
                                  lidargs_alloc_fn alloc_feat, void* feat_user, int* counts_host, void* stream);
 

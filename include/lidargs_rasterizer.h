@@ -487,7 +487,10 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
  * T-only pass did not run), [7]=segments per list, [8]=Gaussians some pixel's walk took (the only ones with a gradient: the backward
  * clears, adds to and reads the packed sums of these alone; -1 if unknown), [9]=list entries the backward blend gathers (per patch and
  * segment the flagged entries in front of its last blended one; -1 if unknown: surfel variant, no instances).  Values [1], [3], [6], [8],
- * [9] are read back (or counted by a diagnostic launch) on demand. */
+ * [9] live on the device: they are counted by small launches queued at the end of the forward itself, into a page the library owns, ONLY
+ * while lidargs_counters_enable(1) is in force on the calling thread (otherwise they read -1); lidargs_last_counters then waits for
+ * those launches.  Nothing about the caller's buffers is remembered between calls. */
+void lidargs_counters_enable(int on);
 int lidargs_last_counters(long long* out, int n);
 
 /* Test hook (no reference counterpart as an entry point): the tile rect the two preprocess kernels give a Gaussian -- getRect_lidar,

@@ -33,7 +33,8 @@ def _f32c(t):
 def grow_level(anchor, offset, scaling, anchor_feat, grads, offset_mask, rand, grad_threshold, rand_threshold, cur_size, n_initial=None, flags=0):
     """One level (the loop body :683-745 up to the constant fills).  anchor [N,3], offset [N,k,3], scaling = get_scaling [N,6],
     anchor_feat [N,F]; grads / offset_mask / rand cover the first `n_initial` anchors' offsets (default: all N).  The three scalars are
-    Python floats; they are rounded to float32 here, as torch does when it compares / divides a float32 tensor by a Python scalar.
+    Python floats: the two thresholds are rounded to float32 (as torch does for a compare), cur_size travels as a double (torch's device
+    kernel multiplies by float32(1.0 / cur_size)).
     Returns (new_anchor [U,3], new_feat [U,F], (candidates, distinct voxels, U))."""
     _base._require_device(anchor, "anchor")
     dev = anchor.device
@@ -58,7 +59,7 @@ def grow_level(anchor, offset, scaling, anchor_feat, grads, offset_mask, rand, g
     p = _base._ptr
     with torch.cuda.device(dev):
         rc = _lib.lidargs_anchor_growing_level(C.c_int(N), C.c_int(N0), C.c_int(k), C.c_int(F), p(anchor), p(offset), p(scaling), p(anchor_feat), p(grads), p(om),
-                                               p(rnd), C.c_float(grad_threshold), C.c_float(rand_threshold), C.c_float(cur_size), C.c_int(flags), p(scratch),
+                                               p(rnd), C.c_float(grad_threshold), C.c_float(rand_threshold), C.c_double(cur_size), C.c_int(flags), p(scratch),
                                                C.c_size_t(nb), work.cb, work.user, out_a.cb, out_a.user, out_f.cb, out_f.user, counts, _base._stream(dev))
     work.take()
     ta, tf = out_a.take(), out_f.take()

@@ -7,7 +7,7 @@
 //
 // Here the same sets come from hashing, in HBM-bound passes over the inputs:
 //   k_ag_mark       N0*k offsets: the mask (:683-688), the candidates' positions (:698) and voxels (:709) -> list of candidate slots
-//                   (wave-aggregated append), their count and voxel bounding box                     [host read: count, box]
+//                   (block-aggregated append), their count and voxel bounding box                     [host read: count, box]
 //   k_ag_insert     candidates -> 64-bit voxel key packed to the box (x most significant: the key's order is torch.unique's row order),
 //                   atomicCAS insert into an open-addressing set of >= 2 C slots; each candidate remembers its slot
 //   k_ag_probe      the N existing anchors quantised the same way (:706) probe the set: a hit marks the voxel dead (:714-729)
@@ -17,8 +17,8 @@
 //   k_ag_features   C*F threads: atomicMax of an order-preserving integer image of anchor_feat[anchor of candidate][f] into new_feat[r][f]
 //   k_ag_unmap      the image back to floats, in place
 // Arithmetic that decides a voxel is written exactly as torch evaluates it: float32 product then sum for the position (no
-// contraction: this file is built with -ffp-contract=off), the quotient either as x * (1 / cur_size) (torch's device kernel for
-// tensor / python scalar) or as an IEEE division (torch's CPU kernel; LIDARGS_AG_EXACT_DIVISION), round half to even, cast.
+// contraction: this file is built with -ffp-contract=off), the quotient either as x * float32(1 / cur_size), the reciprocal taken in double (torch's device kernel for
+// tensor / python scalar, measured on this GPU: tools/div_convention.py, profiles/r06_div_convention.txt) or as an IEEE division (torch's CPU kernel; LIDARGS_AG_EXACT_DIVISION), round half to even, cast.
 #include "lidargs_common.h"
 #include "../../include/lidargs_rasterizer.h"
 #include "../../include/lidargs_anchor_growing.h"
@@ -57,16 +57,25 @@ __device__ __forceinline__ uint32_t ag_hash(unsigned long long k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return (uint32_t)k;
 }
-// wave-aggregated append: returns this lane's position (valid lanes only)
-__device__ __forceinline__ uint32_t ag_append(bool valid, uint32_t* counter) {
-    const unsigned long long m = __ballot(valid);
-    if (m == 0) return 0;
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int leader = __builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
-    base = __shfl(base, leader);
-    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+// Block-aggregated append (256 threads): thread t brings `n` items (its own count), gets the position of its first one.  ONE global
+// atomic per block: with a wave-level append every wave of a 7.2 M-thread launch hit the same counter word (measured: 0.8 ms for a
+// 65-MB pass that needs 15 us).
+__device__ __forceinline__ uint32_t ag_block_append(uint32_t n, uint32_t* counter, uint32_t* s_wave /* [5] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t0 = s_wave[0], t1 = s_wave[1], t2 = s_wave[2], t3 = s_wave[3], tot = t0 + t1 + t2 + t3;
+        const uint32_t base = tot ? atomicAdd(counter, tot) : 0u;
+        s_wave[0] = base; s_wave[1] = base + t0; s_wave[2] = base + t0 + t1; s_wave[3] = base + t0 + t1 + t2;
+    }
+    __syncthreads();
+    const uint32_t pos = s_wave[wave] + incl - n;
+    __syncthreads();                                                     // (s_wave may be reused by the caller)
+    return pos;
 }
 
 __global__ void k_ag_init(uint32_t* hdr) {
@@ -74,26 +83,39 @@ __global__ void k_ag_init(uint32_t* hdr) {
     if (t < AG_HDR) hdr[t] = (t >= 1 && t <= 3) ? (uint32_t)INT_MAX : (t >= 4 && t <= 6) ? (uint32_t)INT_MIN : 0u;
 }
 
+#define AG_MARK_ITEMS 16     // offsets per thread of the mask pass: 4096 per block, 1758 blocks at 7.2 M offsets
 __global__ void __launch_bounds__(256) k_ag_mark(AgLevel p, const float* __restrict__ anchor, const float* __restrict__ offset, const float* __restrict__ scaling,
                                                  const float* __restrict__ grads, const uint8_t* __restrict__ omask, const float* __restrict__ rnd,
                                                  uint32_t* __restrict__ hdr, uint32_t* __restrict__ list) {
     __shared__ int s_box[6];
+    __shared__ uint32_t s_wave[5];
     if (threadIdx.x < 6) s_box[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : INT_MIN;
-    __syncthreads();
     const size_t slots = (size_t)p.N0 * p.k;
-    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
-    bool cand = false;
-    if (s < slots) {
-        cand = grads[s] >= p.thr && omask[s] != 0;                       // :683-684 (a NaN gradient is no candidate: the compare is false)
-        if (cand && rnd) cand = rnd[s] > p.rthr;                        // :687-689
+    const size_t base = (size_t)blockIdx.x * (256 * AG_MARK_ITEMS) + threadIdx.x;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int it = 0; it < AG_MARK_ITEMS; it++) {
+        const size_t s = base + (size_t)it * 256;
+        bool cand = false;
+        if (s < slots) {
+            cand = grads[s] >= p.thr && omask[s] != 0;                   // :683-684 (a NaN gradient is no candidate: the compare is false)
+            if (cand && rnd) cand = rnd[s] > p.rthr;                    // :687-689
+        }
+        bits |= (cand ? 1u : 0u) << it;
     }
-    const uint32_t pos = ag_append(cand, hdr);
-    if (cand) {
-        list[pos] = (uint32_t)s;
+    uint32_t pos = ag_block_append((uint32_t)__builtin_popcount(bits), hdr, s_wave);
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (uint32_t b = bits; b; b &= b - 1) {
+        const size_t s = base + (size_t)__builtin_ctz(b) * 256;
+        list[pos++] = (uint32_t)s;
         int g[3];
         ag_candidate_voxel(p, (uint32_t)s, anchor, offset, scaling, g);
 #pragma unroll
-        for (int c = 0; c < 3; c++) { atomicMin(&s_box[c], g[c]); atomicMax(&s_box[3 + c], g[c]); }
+        for (int c = 0; c < 3; c++) { lo[c] = min(lo[c], g[c]); hi[c] = max(hi[c], g[c]); }
+    }
+    if (bits) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { atomicMin(&s_box[c], lo[c]); atomicMax(&s_box[3 + c], hi[c]); }
     }
     __syncthreads();
     if (threadIdx.x < 6) {
@@ -142,23 +164,32 @@ __global__ void __launch_bounds__(256) k_ag_probe(AgLevel p, AgKey kd, const flo
     }
 }
 
+#define AG_SURV_ITEMS 8
 __global__ void __launch_bounds__(256) k_ag_survivors(uint32_t T, const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
                                                       uint32_t* __restrict__ hdr, unsigned long long* __restrict__ surv) {
-    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long key = h < T ? keys[h] : AG_EMPTY;
-    const bool used = key != AG_EMPTY;
-    const bool live = used && vals[h] == 0;
-    const unsigned long long m = __ballot(used);
-    if (m && threadIdx.x % 64 == (unsigned)__builtin_ctzll(m)) atomicAdd(hdr + 8, (uint32_t)__builtin_popcountll(m));
-    const uint32_t pos = ag_append(live, hdr + 9);
-    if (live) surv[pos] = key;
+    __shared__ uint32_t s_wave[5];
+    const uint32_t base = blockIdx.x * (256 * AG_SURV_ITEMS) + threadIdx.x;
+    unsigned long long key[AG_SURV_ITEMS];
+    uint32_t live = 0, used = 0;
+#pragma unroll
+    for (int it = 0; it < AG_SURV_ITEMS; it++) {
+        const uint32_t h = base + it * 256;
+        key[it] = h < T ? keys[h] : AG_EMPTY;
+        if (key[it] != AG_EMPTY) { used++; if (vals[h] == 0) live |= 1u << it; }
+    }
+    (void)ag_block_append(used, hdr + 8, s_wave);                        // distinct voxels (:711)
+    uint32_t pos = ag_block_append((uint32_t)__builtin_popcount(live), hdr + 9, s_wave);
+#pragma unroll
+    for (int it = 0; it < AG_SURV_ITEMS; it++) if (live >> it & 1u) surv[pos++] = key[it];
 }
 
-__global__ void __launch_bounds__(256) k_ag_split(uint32_t U, const unsigned long long* __restrict__ surv, const uint32_t* __restrict__ perm, int hi, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_ag_split(uint32_t U, const unsigned long long* __restrict__ surv, const uint32_t* __restrict__ perm, int hi, uint32_t* __restrict__ out,
+                                                  uint32_t* __restrict__ ident) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= U) return;
     const unsigned long long key = surv[perm ? perm[i] : i];
     out[i] = hi ? (uint32_t)(key >> 32) : (uint32_t)key;
+    if (ident) ident[i] = i;                                             // a key of zero bits (one voxel) is not sorted at all: the permutation must exist anyway
 }
 
 __global__ void __launch_bounds__(256) k_ag_emit(AgLevel p, AgKey kd, uint32_t U, const unsigned long long* __restrict__ surv, const uint32_t* __restrict__ perm,
@@ -211,21 +242,22 @@ size_t lidargs_ag_scratch_bytes(int N0, int n_offsets) {
 
 int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, const float* anchor, const float* offset, const float* scaling,
                                  const float* anchor_feat, const float* grads, const uint8_t* offset_mask, const float* rnd,
-                                 float grad_threshold, float rand_threshold, float cur_size, int flags, char* scratch, size_t scratch_bytes,
+                                 float grad_threshold, float rand_threshold, double cur_size, int flags, char* scratch, size_t scratch_bytes,
                                  lidargs_alloc_fn alloc_work, void* work_user, lidargs_alloc_fn alloc_anchor, void* anchor_user,
                                  lidargs_alloc_fn alloc_feat, void* feat_user, int* counts_host, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (counts_host) counts_host[0] = counts_host[1] = counts_host[2] = 0;
     if (N < 0 || N0 < 0 || N0 > N || n_offsets < 1 || feat_dim < 1 || feat_dim > 256) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: bad sizes");
     if ((size_t)N * n_offsets >= ((size_t)1 << 31)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: N * n_offsets must be below 2^31");
-    if (!(cur_size > 0.0f) || !(cur_size < INFINITY)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: cur_size must be positive and finite");
+    if (!(cur_size > 0.0) || !(cur_size < (double)INFINITY) || !((float)cur_size > 0.0f)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: cur_size must be positive and finite");
     if (N0 == 0) return 0;
     if (!anchor || !offset || !scaling || !anchor_feat || !grads || !offset_mask || !scratch || !alloc_work || !alloc_anchor || !alloc_feat)
         return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: NULL pointer");
     if (scratch_bytes < lidargs_ag_scratch_bytes(N0, n_offsets)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: scratch too small");
     lg::AgLevel p;
     p.N = N; p.N0 = N0; p.k = n_offsets; p.F = feat_dim;
-    p.thr = grad_threshold; p.rthr = rand_threshold; p.size = cur_size; p.inv = 1.0f / cur_size;
+    p.thr = grad_threshold; p.rthr = rand_threshold; p.size = (float)cur_size;
+    p.inv = (float)(1.0 / cur_size);       // the reciprocal of the Python double, THEN rounded: what torch-ROCm's tensor / scalar kernel multiplies by (measured: tools/div_convention.py)
     p.exact = (flags & LIDARGS_AG_EXACT_DIVISION) ? 1 : 0;
     lg::Carver cv(scratch);
     uint32_t* hdr = cv.take<uint32_t>(AG_HDR);
@@ -233,7 +265,7 @@ int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, con
     const size_t slots = (size_t)N0 * n_offsets;
 
     hipLaunchKernelGGL(lg::k_ag_init, dim3(1), dim3(64), 0, stream, hdr);
-    hipLaunchKernelGGL(lg::k_ag_mark, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, p, anchor, offset, scaling, grads, offset_mask, rnd, hdr, list);
+    hipLaunchKernelGGL(lg::k_ag_mark, dim3((unsigned)((slots + 256 * AG_MARK_ITEMS - 1) / (256 * AG_MARK_ITEMS))), dim3(256), 0, stream, p, anchor, offset, scaling, grads, offset_mask, rnd, hdr, list);
     AG_HIP(hipGetLastError());
     uint32_t h[AG_HDR];
     AG_HIP(lg::api_read_words_zero_behind(hdr, 8, h, nullptr, 0, stream));
@@ -274,7 +306,7 @@ int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, con
     AG_HIP(hipMemsetAsync(vals, 0, T * sizeof(int), stream));
     hipLaunchKernelGGL(lg::k_ag_insert, dim3((C + 255) / 256), dim3(256), 0, stream, p, kd, C, anchor, offset, scaling, list, keys, cand_slot);
     hipLaunchKernelGGL(lg::k_ag_probe, dim3(((unsigned)N + 255) / 256), dim3(256), 0, stream, p, kd, anchor, keys, vals);
-    hipLaunchKernelGGL(lg::k_ag_survivors, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, stream, (uint32_t)T, keys, vals, hdr, surv);
+    hipLaunchKernelGGL(lg::k_ag_survivors, dim3((unsigned)((T + 256 * AG_SURV_ITEMS - 1) / (256 * AG_SURV_ITEMS))), dim3(256), 0, stream, (uint32_t)T, keys, vals, hdr, surv);
     AG_HIP(hipGetLastError());
     AG_HIP(lg::api_read_words_zero_behind(hdr + 8, 2, h, nullptr, 0, stream));
     const uint32_t V = h[0], U = h[1];
@@ -283,12 +315,12 @@ int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, con
 
     // the live keys in ascending order: LSD on the low word, then on the high word (the permutation is the value)
     const unsigned ub = (U + 255) / 256;
-    hipLaunchKernelGGL(lg::k_ag_split, dim3(ub), dim3(256), 0, stream, U, surv, (const uint32_t*)nullptr, 0, ka);
+    hipLaunchKernelGGL(lg::k_ag_split, dim3(ub), dim3(256), 0, stream, U, surv, (const uint32_t*)nullptr, 0, ka, va);
     int side = lg::launch_radix_sort_pairs(ka, kb, va, vb, U, total_bits < 32 ? total_bits : 32, sort_scratch, stream, 0, nullptr, 0, true);
     uint32_t* perm = side ? vb : va;
     if (total_bits > 32) {
         uint32_t* k2a = side ? kb : ka; uint32_t* k2b = side ? ka : kb; uint32_t* v2b = side ? va : vb;
-        hipLaunchKernelGGL(lg::k_ag_split, dim3(ub), dim3(256), 0, stream, U, surv, perm, 1, k2a);
+        hipLaunchKernelGGL(lg::k_ag_split, dim3(ub), dim3(256), 0, stream, U, surv, perm, 1, k2a, (uint32_t*)nullptr);
         const int side2 = lg::launch_radix_sort_pairs(k2a, k2b, perm, v2b, U, total_bits - 32, sort_scratch, stream);
         perm = side2 ? v2b : perm;
     }

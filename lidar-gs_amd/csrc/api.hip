@@ -25,12 +25,59 @@ using lg::SegPlan;
 
 thread_local char g_err[512] = "";
 // diagnostics of the last forward ON THIS THREAD (lidargs_last_counters); never read by the compute path
-thread_local long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-thread_local const uint8_t* g_last_flags = nullptr; thread_local size_t g_last_flags_R = 0, g_last_flags_stride = 0; thread_local int g_last_flags_planes = 0;
-thread_local uint32_t* g_last_totals_dev = nullptr;   // device address of the last forward's totals (geometry buffer)
-thread_local const uint8_t* g_last_touched = nullptr; thread_local size_t g_last_touched_P = 0;   // the last forward's touched marks (geometry buffer)
-thread_local long long g_touched_count = -1;
-thread_local lg::RenderBwdArgs g_last_bwd_view; thread_local bool g_last_bwd_view_ok = false; thread_local long long g_bwd_entries = -1;   // what the last plain forward's backward will walk
+thread_local long long g_counters[10] = {0, 0, 0, 0, 0, 0, 0, 0, -1, -1};
+// The device-side counters ([1], [3], [6], [8], [9]) are counted by small launches queued at the END OF THE FORWARD ITSELF, while the
+// caller's buffers are by definition alive, into a page this library owns, and only when asked for (lidargs_counters_enable): nothing
+// is remembered about the caller's memory, nothing is allocated per query (round-5 verdict item 9 / advisor finding).
+thread_local int g_counters_on = 0;
+struct CounterPage {
+    unsigned long long* dev = nullptr; unsigned long long* host = nullptr; hipEvent_t done = nullptr; int device = -1; bool pending = false;
+    bool ready() {
+        int d = -1;
+        if (hipGetDevice(&d) != hipSuccess) return false;
+        if (dev && d == device) return true;
+        if (dev) { (void)hipFree(dev); dev = nullptr; }
+        if (done) { (void)hipEventDestroy(done); done = nullptr; }
+        if (!host && hipHostMalloc((void**)&host, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { host = nullptr; return false; }
+        if (hipMalloc((void**)&dev, 8 * sizeof(unsigned long long)) != hipSuccess) { dev = nullptr; return false; }
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) { done = nullptr; return false; }
+        device = d; pending = false;
+        return true;
+    }
+};
+thread_local CounterPage t_cnt;
+
+__global__ void __launch_bounds__(64) k_cnt_diag(const unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
+    unsigned long long v = 0, r = 0;                                   // the preprocess' LG_INST_SLOTS pairs (visible, reference tiles_touched)
+    for (int i = threadIdx.x; i < LG_INST_SLOTS; i += 64) { v += slots[2 * i]; r += slots[2 * i + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o); r += __shfl_xor(r, o); }
+    if (threadIdx.x == 0) { out[0] = v; out[1] = r; }
+}
+__global__ void __launch_bounds__(256) k_cnt_bytes(const uint8_t* __restrict__ p, size_t n, size_t stride, unsigned long long* __restrict__ out) {
+    const uint8_t* row = p + (size_t)blockIdx.y * stride;
+    uint32_t c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += row[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+// queued behind a forward's last launch (see above); `view` = the selection a backward on these buffers will make, or NULL
+void queue_counters(const uint32_t* totals, const uint8_t* flags, size_t R, size_t flags_stride, int flags_planes, const uint8_t* touched, size_t P,
+                    const lg::RenderBwdArgs* view, hipStream_t s) {
+    g_counters[1] = g_counters[3] = g_counters[8] = g_counters[9] = -1;
+    g_counters[6] = flags ? -1 : 0;
+    t_cnt.pending = false;
+    if (!g_counters_on || !t_cnt.ready()) return;
+    unsigned long long* d = t_cnt.dev;
+    if (hipMemsetAsync(d, 0, 8 * sizeof *d, s) != hipSuccess) return;
+    hipLaunchKernelGGL(k_cnt_diag, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(totals + LG_TOTALS_DIAG_WORD), d);
+    if (flags && R) hipLaunchKernelGGL(k_cnt_bytes, dim3(512, flags_planes), dim3(256), 0, s, flags, R, flags_stride, d + 2);
+    if (touched && P) hipLaunchKernelGGL(k_cnt_bytes, dim3(512, 1), dim3(256), 0, s, touched, P, (size_t)0, d + 3);
+    if (view) lg::launch_count_backward_entries(*view, d + 4, s);
+    t_cnt.host[5] = (flags && R ? 1u : 0u) | (touched && P ? 2u : 0u) | (view ? 4u : 0u);     // which of the counts exist (host-side word of the same page)
+    if (hipMemcpyAsync(t_cnt.host, d, 5 * sizeof *d, hipMemcpyDeviceToHost, s) != hipSuccess) return;
+    if (hipEventRecord(t_cnt.done, s) != hipSuccess) return;
+    t_cnt.pending = true;
+}
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
@@ -261,15 +308,10 @@ int api_read_words_end(int n, uint32_t* out) {
     return (int)e;
 }
 void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* totals, const uint8_t* flags, size_t flags_stride,
-                      int flags_planes) {   // diagnostics only (lidargs_last_counters)
-    g_counters[0] = P; g_counters[1] = -1; g_counters[2] = R; g_counters[3] = -1; g_counters[4] = TH; g_counters[5] = tiles;
-    g_counters[6] = flags ? -1 : 0; g_counters[7] = S;
-    g_last_flags = flags; g_last_flags_R = (size_t)R; g_last_flags_stride = flags_stride; g_last_flags_planes = flags_planes;
-    g_last_totals_dev = (uint32_t*)totals;
-    g_last_touched = nullptr; g_last_touched_P = 0; g_touched_count = -1;
-    g_last_bwd_view_ok = false; g_bwd_entries = -1;
+                      int flags_planes, const uint8_t* touched, hipStream_t s) {   // diagnostics only (lidargs_last_counters)
+    g_counters[0] = P; g_counters[2] = R; g_counters[4] = TH; g_counters[5] = tiles; g_counters[7] = S;
+    queue_counters((const uint32_t*)totals, flags, (size_t)R, flags_stride, flags_planes, touched, (size_t)P, nullptr, s);
 }
-void api_note_touched(const uint8_t* touched, size_t P) { g_last_touched = touched; g_last_touched_P = P; g_touched_count = -1; }
 int api_encode_rendered(size_t R, int TH) { return encode_rendered(R, TH); }
 size_t api_rendered_capacity(int nr) { return rendered_capacity(nr); }
 int api_rendered_tile_rows(int nr) { return rendered_tile_rows(nr); }
@@ -540,7 +582,7 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     int head = 0;                                                      // segments at the head of every list that round 1 walked completely
     const bool fused = plan.fused && !is_shell;                        // the plain frame (a range shell's two phases keep the launches)
     // no flags (a one-segment plan: LIDARGS_MAX_SEGMENTS=1): pass 2 and the backward walk every listed entry, so every Gaussian may be added to
-    if (!fused && !ra.run_pass1 && R) lg::launch_touch_all(geom.touched, (size_t)P, stream);
+    if (!fused && !ra.run_pass1 && R) lg::launch_touch_all(geom.touched, radii, (size_t)P, stream);
     if (fused) {
         ra.flags = bin.flags; ra.alive = bin.alive;
         lg::launch_render_fused(ra, stream);
@@ -565,20 +607,14 @@ int forward_impl(lidargs_alloc_fn geometry_alloc, void* geometry_user, lidargs_a
     g_prof.mark("render_combine", stream);
     }
 
-    g_counters[0] = P; g_counters[1] = -1; g_counters[2] = (long long)R; g_counters[3] = -1; g_counters[4] = TH;
-    g_counters[5] = grid.num_tiles();
-    g_counters[6] = -1; g_counters[7] = S;
-    g_last_flags = ra.flags; g_last_flags_R = R; g_last_flags_stride = Rp; g_last_flags_planes = grid.waves_per_tile;
-    g_last_totals_dev = geom.totals;             // R_ref / V are summed lazily in lidargs_last_counters (the diagnostic slots)
-    g_last_touched = geom.touched; g_last_touched_P = (size_t)P; g_touched_count = -1;
-    {   // the selection a backward on these buffers will make (backward_impl builds the same view): for lidargs_last_counters only
-        lg::RenderBwdArgs& v = g_last_bwd_view;
-        v = lg::RenderBwdArgs();
+    g_counters[0] = P; g_counters[2] = (long long)R; g_counters[4] = TH; g_counters[5] = grid.num_tiles(); g_counters[7] = S;
+    if (g_counters_on) {   // the selection a backward on these buffers will make (backward_impl builds the same view): counted now, while the buffers are certainly alive
+        lg::RenderBwdArgs v = lg::RenderBwdArgs();
         v.walk.cnt = nullptr; v.grid = grid; v.ranges = img.ranges; v.seg = bin.seg; v.S = S; v.seg_len = plan.seg_len; v.R = Rp;
         v.alive = (fused || pass1_gated(plan, S)) ? bin.alive : nullptr;
         v.flags = (fused || S > 1 || is_shell) ? bin.flags : nullptr;
-        g_last_bwd_view_ok = R != 0 && !transmittance_pass; g_bwd_entries = -1;
-    }
+        queue_counters(geom.totals, ra.flags, R, Rp, grid.waves_per_tile, geom.touched, (size_t)P, (R != 0 && !transmittance_pass) ? &v : nullptr, stream);
+    } else queue_counters(nullptr, ra.flags, 0, 0, 0, nullptr, 0, nullptr, stream);
     return rendered;
 }
 
@@ -1003,43 +1039,21 @@ int lidargs_profile_summary(const char** names_out, float* total_ms_out, int* co
 int lidargs_debug_lane_stats(unsigned long long* out, int reset) { lg::lane_stats_read(out, reset); return 16; }
 #endif
 
+void lidargs_counters_enable(int on) { g_counters_on = on ? 1 : 0; }
+
 int lidargs_last_counters(long long* out, int n) {
-    if (g_counters[1] < 0 && g_last_totals_dev && g_counters[0] > 0) {
-        // the preprocess summed the visible Gaussians and the reference's tiles_touched into LG_INST_SLOTS slots (diagnostics path)
-        unsigned long long h[2 * LG_INST_SLOTS];
-        if (hipMemcpy(h, g_last_totals_dev + LG_TOTALS_DIAG_WORD, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-            long long v = 0, r = 0;
-            for (int i = 0; i < LG_INST_SLOTS; i++) { v += (long long)h[2 * i]; r += (long long)h[2 * i + 1]; }
-            g_counters[1] = v; g_counters[3] = r;
+    if (t_cnt.pending) {
+        t_cnt.pending = false;
+        if (hipEventSynchronize(t_cnt.done) == hipSuccess) {
+            const unsigned long long* h = t_cnt.host;
+            g_counters[1] = (long long)h[0]; g_counters[3] = (long long)h[1];
+            if (h[5] & 1u) g_counters[6] = (long long)h[2];
+            if (h[5] & 2u) g_counters[8] = (long long)h[3];
+            if (h[5] & 4u) g_counters[9] = (long long)h[4];
         }
-    }
-    if (g_counters[6] < 0 && g_last_flags && g_last_flags_R) {
-        const size_t nbytes = g_last_flags_stride * (size_t)g_last_flags_planes;
-        uint8_t* h = (uint8_t*)malloc(nbytes);
-        if (h && hipMemcpy(h, g_last_flags, nbytes, hipMemcpyDeviceToHost) == hipSuccess) {
-            long long c = 0;
-            for (int pl = 0; pl < g_last_flags_planes; pl++)
-                for (size_t i = 0; i < g_last_flags_R; i++) c += h[(size_t)pl * g_last_flags_stride + i] != 0;
-            g_counters[6] = c;
-        }
-        free(h);
-    }
-    if (g_touched_count < 0 && g_last_touched && g_last_touched_P) {
-        uint8_t* h = (uint8_t*)malloc(g_last_touched_P);
-        if (h && hipMemcpy(h, g_last_touched, g_last_touched_P, hipMemcpyDeviceToHost) == hipSuccess) {
-            long long c = 0;
-            for (size_t i = 0; i < g_last_touched_P; i++) c += h[i] != 0;
-            g_touched_count = c;
-        }
-        free(h);
     }
     int k = 0;
-    for (; k < n && k < 8; k++) out[k] = g_counters[k];
-    if (k < n) out[k++] = g_touched_count;                             // [8]
-    if (k < n) {                                                       // [9]
-        if (g_bwd_entries < 0 && g_last_bwd_view_ok) g_bwd_entries = lg::count_backward_entries(g_last_bwd_view);
-        out[k++] = g_bwd_entries;
-    }
+    for (; k < n && k < 10; k++) out[k] = g_counters[k];
     return k;
 }
 

@@ -361,7 +361,7 @@ static size_t pm_carve(char* base, int N, PmWork* w) {
     lg::Carver c(base);
     PmWork k;
     const size_t n = (size_t)N;
-    k.flags = c.take<uint32_t>(2 * n); k.offs = c.take<uint32_t>(2 * n + 1); k.total = c.take<uint32_t>(64);
+    k.flags = c.take<uint32_t>(2 * n + 1); k.offs = c.take<uint32_t>(2 * n + 1); k.total = c.take<uint32_t>(64);
     k.scan = c.take<uint32_t>(lg::scan_scratch_words(2 * n + 1)); k.nm = c.take<uint32_t>(4);
     k.pts1 = c.take<float>(3 * n + 4); k.pts2 = c.take<float>(3 * n + 4); k.dist1 = c.take<float>(n + 1); k.dist2 = c.take<float>(n + 1);
     k.idx1 = c.take<int>(n + 1); k.idx2 = c.take<int>(n + 1); k.part = c.take<double>(4 * 256);

@@ -331,8 +331,7 @@ int api_read_words_end(int n, uint32_t* out);                           // ... a
 void api_prof_begin(hipStream_t s, int kind);
 void api_prof_mark(const char* name, hipStream_t s);
 void api_note_forward(long long P, long long R, int TH, int tiles, int S, const void* spans, const uint8_t* flags, size_t flags_stride,
-                      int flags_planes);
-void api_note_touched(const uint8_t* touched, size_t P);              // (after api_note_forward) the frame's touched marks, for lidargs_last_counters
+                      int flags_planes, const uint8_t* touched, hipStream_t s);   // host-side counters; with lidargs_counters_enable(1) also queues the counting launches
 int api_encode_rendered(size_t R, int TH);
 size_t api_rendered_capacity(int num_rendered);
 int api_rendered_tile_rows(int num_rendered);
@@ -343,7 +342,7 @@ struct ZeroRows { static constexpr int MAX = 12; float* p[MAX]; int w[MAX]; int 
                   void add(float* q, int width) { if (q && n < MAX) { p[n] = q; w[n] = width; n++; } } };
 void launch_zero_touched(const uint8_t* touched, float4* acc, int line_f4, size_t P, uint8_t* tlist, uint16_t* tcount, const ZeroRows& zr, hipStream_t s);
 // touched[i] = 1 for all P (frames whose forward writes no contribution flags: every listed entry is walked, so every visible Gaussian counts)
-void launch_touch_all(uint8_t* touched, size_t P, hipStream_t s);
+void launch_touch_all(uint8_t* touched, const int* radii, size_t P, hipStream_t s);   // marks the Gaussians with radii > 0
 
 // kernels / launchers (defined in the .hip files)
 void launch_setup_tables(const float* beams, int W, int H, ImgView img, hipStream_t s);
@@ -491,7 +490,7 @@ struct RenderBwdArgs {
     WorkList walk;                 // the list k_render_combine filled; cnt == nullptr: the slot grid
 };
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s);
-long long count_backward_entries(const RenderBwdArgs& a);             // diagnostics: the list entries that launch gathers (synchronises; -1 on failure)
+void launch_count_backward_entries(const RenderBwdArgs& a, unsigned long long* out, hipStream_t s);   // diagnostics: adds the list entries k_render_backward gathers to *out
 
 struct GaussBwdArgs {
     int P; float scale_modifier; const float* view;   // device pointer

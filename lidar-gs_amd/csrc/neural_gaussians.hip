@@ -1079,11 +1079,16 @@ static bool ng_use_t16(int k) {
 }
 // LIDARGS_NG_T16_PASSES=1: the four MLPs in one launch (A/B); default two launches (see k_ng_backward_t16)
 static bool ng_t16_two_pass() { const char* e = getenv("LIDARGS_NG_T16_PASSES"); return !(e && e[0] == '1'); }
+// The variant is chosen by environment switches read per call (the suite selects variants in one process), and the backward takes no
+// capacity argument: what lidargs_ng_backward_partials last told this thread for k is remembered, and a backward whose variant would now
+// write a different number of partial rows refuses instead of overflowing the caller's buffer (round-5 advisor finding).
+static thread_local int t_ng_rows_reported[16] = {0};
 static int ng_partial_rows(int k) { return ng_use_t16(k) ? (ng_t16_two_pass() ? 2 : 1) * ng_cus() : 4 * ng_cus(); }
 int lidargs_ng_backward_partials(int n_offsets, int* waves, int* floats_per_wave) {
     const int k = n_offsets;
     if (!(k == 4 || k == 5 || k == 6 || k == 8 || k == 10) || !waves || !floats_per_wave) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "ng_backward_partials: bad argument");
     *waves = ng_partial_rows(k);
+    t_ng_rows_reported[k] = *waves;
     *floats_per_wave = (5 + 3 + (7 * k + 31) / 32) * 1024 + 128;
     return 0;
 }
@@ -1103,6 +1108,8 @@ int lidargs_ng_backward_mfma(int N, const lidargs_ng_model* model, const float* 
     lg::NgScratch s; lg::ng_carve(scratch, (size_t)N, (size_t)m.k, &s);
     const float3 cam = make_float3(cam_center[0], cam_center[1], cam_center[2]);
     const int waves = ng_partial_rows(m.k);
+    if (t_ng_rows_reported[m.k] && t_ng_rows_reported[m.k] != waves)
+        return lg::api_fail(LIDARGS_ERR_STATE, "ng_backward_mfma: the backward variant (LIDARGS_NG_BACKWARD_T16 / LIDARGS_NG_T16_PASSES) changed since lidargs_ng_backward_partials sized the partial rows; call it again");
 #define NG_T16_LAUNCH(K_, P_) hipLaunchKernelGGL((lg::k_ng_backward_t16<K_, P_>), dim3(ng_cus()), dim3(64 * NGT_WAVES), 0, stream, N, m, cam, anchor_feat, anchor, offset, \
                                         scaling, s.vis_flags, s.vis_idx, s.sel_flags, s.slot, dL_dxyz, dL_dcolor, dL_dopacity, dL_dscaling, dL_drot, dL_dneural_opacity, \
                                         dL_danchor_feat, dL_danchor, dL_doffset, dL_dscaling_in, partials, stagger)

@@ -680,7 +680,15 @@ void launch_zero_touched(const uint8_t* touched, float4* acc, int line_f4, size_
     if (line_f4 == 8) hipLaunchKernelGGL(k_zero_touched<8>, dim3(blocks), dim3(LG_REGION), 0, s, touched, acc, P, tlist, tcount, zr);
     else hipLaunchKernelGGL(k_zero_touched<4>, dim3(blocks), dim3(LG_REGION), 0, s, touched, acc, P, tlist, tcount, zr);
 }
-void launch_touch_all(uint8_t* touched, size_t P, hipStream_t s) { (void)hipMemsetAsync(touched, 1, P, s); }
+// the one-segment plan has no contribution flags: every VISIBLE Gaussian may be added to.  The culled ones stay unmarked -- their rows
+// must be the exact zeros the reference's torch::zeros leaves (the chain on zero sums would turn a huge or non-finite scale into 0 * inf)
+__global__ void __launch_bounds__(256) k_touch_visible(uint8_t* __restrict__ touched, const int* __restrict__ radii, size_t P) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < P) touched[i] = radii[i] > 0 ? 1 : 0;
+}
+void launch_touch_all(uint8_t* touched, const int* radii, size_t P, hipStream_t s) {
+    hipLaunchKernelGGL(k_touch_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, touched, radii, P);
+}
 
 void launch_gaussian_backward(const GaussBwdArgs& a, hipStream_t s) {
     const unsigned regions = (unsigned)((a.P + LG_REGION - 1) / LG_REGION);

@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     }
 }
 
-// Diagnostics (lidargs_last_counters, outside any timed region): the list entries k_render_backward gathers for a frame -- per (patch,
+// Diagnostics (lidargs_counters_enable + lidargs_last_counters, outside any timed region): the list entries k_render_backward gathers for a frame -- per (patch,
 // segment) the flagged entries in front of the segment's last blended one, exactly its own selection (above: n_max, the flags, the
 // patch's limit).  What bench.py prices the launch's algorithmic bytes on.
 __global__ void __launch_bounds__(64) k_count_backward_entries(const RenderBwdArgs a, unsigned long long* __restrict__ out) {
@@ -1265,15 +1265,8 @@ __global__ void __launch_bounds__(64) k_count_backward_entries(const RenderBwdAr
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if (lane == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
-long long count_backward_entries(const RenderBwdArgs& a) {
-    unsigned long long* d = nullptr;
-    if (hipMalloc((void**)&d, sizeof *d) != hipSuccess) return -1;
-    unsigned long long h = 0;
-    (void)hipMemset(d, 0, sizeof *d);
-    hipLaunchKernelGGL(k_count_backward_entries, dim3(segment_grid(a.grid.window_patches(), a.S)), dim3(64), 0, nullptr, a, d);
-    const bool ok = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipFree(d);
-    return ok ? (long long)h : -1;
+void launch_count_backward_entries(const RenderBwdArgs& a, unsigned long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_backward_entries, dim3(segment_grid(a.grid.window_patches(), a.S)), dim3(64), 0, s, a, out);
 }
 
 void launch_render_backward(const RenderBwdArgs& a, hipStream_t s) {

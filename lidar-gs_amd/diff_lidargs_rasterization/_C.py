@@ -35,6 +35,7 @@ for _name in ("lidargs_forward", "lidargs_forward_enqueue", "lidargs_backward", 
     getattr(_lib, _name).restype = C.c_int
 _lib.lidargs_profile_stage_name.restype = C.c_char_p
 _lib.lidargs_profile_enable.restype = None
+_lib.lidargs_counters_enable.restype = None
 if _lib.lidargs_abi_version() != 2:
     raise ImportError("diff_lidargs_rasterization: liblidargs_hip.so ABI version mismatch; rebuild it")
 
@@ -296,8 +297,15 @@ def profile_summary():
     return {names[i].decode(): (float(tot[i]) / max(1, cnt[i]), int(cnt[i])) for i in range(n)}
 
 
+def counters_enable(on):
+    """While on, every forward of this thread ends with the small counting launches behind V, R_ref, taken_instances, touched and
+    backward_entries of last_counters() (diagnostics: keep it off inside timed regions)."""
+    _lib.lidargs_counters_enable(C.c_int(1 if on else 0))
+
+
 def last_counters():
-    """dict(P, V, instances, R_ref, tile_rows, tiles, ..., touched) of the last forward on this thread."""
+    """dict(P, V, instances, R_ref, tile_rows, tiles, ..., touched) of the last forward on this thread; the device-side ones (V, R_ref,
+    taken_instances, touched, backward_entries) are -1 unless counters_enable(True) was in force during that forward."""
     buf = (C.c_longlong * 10)()
     _lib.lidargs_last_counters(buf, C.c_int(10))
     return dict(P=buf[0], V=buf[1], instances=buf[2], R_ref=buf[3], tile_rows=buf[4], tiles=buf[5], taken_instances=buf[6],

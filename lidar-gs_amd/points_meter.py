@@ -67,6 +67,12 @@ class PointsMeter:
         self.N = 0
 
     def update(self, preds, truths):
+        # the reference takes device tensors, host tensors or numpy arrays alike (prepare_inputs, :247-254) and ends on the device either
+        # way (:268-270): host inputs are moved there.  Beam tables are evaluated in float32 (a float64 table is rounded first; the
+        # reference keeps numpy's float64 until torch.FloatTensor, :269 -- a difference of at most half a float32 ulp of the angle,
+        # ~3e-8 relative in the points, far inside the metric's seven pinned digits).
+        dev = next((t.device for t in (preds, truths) if torch.is_tensor(t) and t.is_cuda), torch.device("cuda"))
+        preds, truths = (t.to(dev) if torch.is_tensor(t) else torch.as_tensor(np.asarray(t)).to(dev) for t in (preds, truths))
         out = points_metrics(preds[0], truths[0], self.scale, self.intrinsics, self.beam_inclinations, threshold=0.05)   # [B, H, W]: image 0, as the reference
         self.V.append(out[:2])                                         # (chamfer_dis, f_score), :280
         self.N += 1

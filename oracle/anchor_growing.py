@@ -9,8 +9,10 @@ PARITY STATUS: pinned against tests/golden/anchor_growing_golden.npz, produced b
 
 Two conventions of `tensor / python_float` exist in torch and both are restated (`exact_division`):
   True   IEEE division            -- torch's CPU kernel, hence what the fixture pins;
-  False  x * (1 / float32(size))  -- torch's device kernel (ATen BinaryDivTrueKernel.cu: "if the second operand is a CPU scalar, compute
-                                     a * reciprocal(b)"), hence what the reference computes where it really runs (every tensor is .cuda()).
+  False  x * float32(1.0 / size)  -- torch's device kernel (ATen BinaryDivTrueKernel.cu: "if the second operand is a CPU scalar, compute
+                                     a * reciprocal(b)"; the reciprocal of the Python double, then rounded: measured against torch-ROCm on
+                                     the MI355X, profiles/r06_div_convention.txt), hence what the reference computes where it really runs
+                                     (every tensor is .cuda()).
 """
 import numpy as np
 
@@ -20,7 +22,7 @@ F32 = np.float32
 def _quantize(x, cur_size, exact_division):
     """torch.round(x / cur_size).int()  (:706, :709): float32 quotient, round half to even, cast."""
     s = F32(cur_size)
-    q = (x / s) if exact_division else (x * (F32(1.0) / s))
+    q = (x / s) if exact_division else (x * F32(1.0 / float(cur_size)))
     return np.rint(q.astype(F32)).astype(np.int32)
 
 

@@ -65,6 +65,11 @@ def test_points_meter_class_and_edge_cases(hip_lib_built):
     v = meter.measure()
     assert abs(v[0] - 0.5 * float(GOLD["a_cd"])) <= 2e-5 * float(GOLD["a_cd"]) and abs(v[1] - 0.5 * (float(GOLD["a_fscore"]) + 1.0)) <= 2e-3
     assert "CD f-score" in meter.report()
+    # host tensors and numpy arrays, float64 beam table: accepted like the reference's prepare_inputs does (:247-254), same numbers
+    host = points_meter.PointsMeter(scale=scale, intrinsics=None, beam_inclinations=beams.astype(np.float64))
+    host.update(torch.from_numpy(pred)[None], truth[None])
+    host.update(truth[None], torch.from_numpy(truth).cuda()[None])
+    assert np.allclose(host.measure(), v, rtol=1e-6, atol=1e-7)
     empty = points_meter.points_metrics(torch.zeros(H, W).cuda(), torch.from_numpy(truth).cuda(), beam_inclinations=beams).cpu().numpy()
     assert np.isnan(empty[0]) and empty[1] == 0.0 and empty[4] == 0
     full = np.abs(truth) + 1.0

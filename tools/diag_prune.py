@@ -10,6 +10,7 @@ import lidargs_scenes as sc
 from util import hip_forward_backward
 from test_beam_tables_gpu import _stress_scene
 from diff_lidargs_rasterization import _C
+_C.counters_enable(True)      # diagnostics tool: every forward ends with the counting launches of last_counters()
 scene, W, H, grads = _stress_scene(%r)
 hip = hip_forward_backward(scene, W, H, None)
 c = _C.last_counters()

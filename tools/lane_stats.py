@@ -9,6 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "lidar-gs_amd"), os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import lidargs_scenes as sc
 from diff_lidargs_rasterization import _C
+_C.counters_enable(True)      # diagnostics tool: every forward ends with the counting launches of last_counters()
 from util import hip_forward_backward
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"

@@ -12,6 +12,7 @@ kind, P, beams = desc['kind'], desc['P'], desc['beams']
 hip = hip_forward_backward(scene, W, H, grads, **kw)
 ref = oracle_forward_backward(scene, W, H, grads, **kw)
 from diff_lidargs_rasterization import _C
+_C.counters_enable(True)      # diagnostics tool: every forward ends with the counting launches of last_counters()
 print(dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, **kw), _C.last_counters())
 for k in ("color", "depth", "occ"):
     d = np.abs(hip[k] - ref[k]); bad = np.argwhere(d > 1e-3 * (np.abs(ref[k]) + 1e-3 * np.abs(ref[k]).max()))
