@@ -472,7 +472,7 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
     from diff_lidargs_rasterization import _C as base_C
     from diff_lidargs_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = torch.device("cuda", 0)
-    scene = sc.make_scene(kind, P, H, seed)
+    scene = sc.make_scene(kind, P, H, seed, opacity_scale=args.opacity_scale)
     scene["scales"] = np.ascontiguousarray(scene["scales"][:, :2])
     st = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in scene.items()}
     rast = GaussianRasterizer(GaussianRasterizationSettings(
@@ -524,7 +524,8 @@ def bench_surfel(args, sc, kind, P, H, W, seed):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cfg5: {P} surfels ({kind} scene, seed {seed}) @ {H}x{W}, fwd+bwd, diff_lidargs_surfel_rasterization "
-                               f"(2DGS laser-surfel variant), lidar_far=80 lidar_near=0, bg=0",
+                               f"(2DGS laser-surfel variant), lidar_far=80 lidar_near=0, bg=0"
+                               + ("" if args.opacity_scale == 1.0 else f", opacities x {args.opacity_scale:g} (semi-transparent, early-training regime)"),
                    "visible_surfels": V, "instances_binned": info.get("R", 0), "patch_instance_pairs_taken": int(cnt["taken_instances"]), "touched_surfels": int(cnt.get("touched", -1)), "tile_rows": 4},
         "roofline": roofline_object(table, "cfg5", pmc_names),
         "stage_ms": {k: round(v[0], 4) for k, v in stages.items()},
@@ -1134,6 +1135,9 @@ def main():
     ap.add_argument("--beams", default="uniform", choices=["uniform", "waymo", "neartie"],
                     help="beam-inclination table of the synthetic scene (lidargs_scenes.beam_table): uniform = SURVEY 8d; waymo = "
                          "non-uniform stand-in for the measured table the Waymo configs read from the dataset json")
+    ap.add_argument("--opacity-scale", type=float, default=1.0,
+                    help="cfg1-5: the scene's opacities U(0.1, 1) times this factor (lidargs_scenes.make_scene).  1 = the BASELINE.json scene (lists saturate "
+                         "within a few entries); 0.3 / 0.1 / 0.03 = the semi-transparent frames training starts in: every list is walked to its end")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: capture forward + backward of the enqueue-only path (lidargs_forward_enqueue: no host wait) in a HIP graph "
@@ -1193,7 +1197,7 @@ def main():
     to_torch = lambda sd, device: {k_: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k_, v in sd.items()}
     make_settings = sc.raster_settings
 
-    scene = sc.make_scene(kind, P, H, seed, beams=args.beams)
+    scene = sc.make_scene(kind, P, H, seed, beams=args.beams, opacity_scale=args.opacity_scale)
     st = to_torch(scene, dev)
     gc, gd, go = (torch.from_numpy(g).to(dev) for g in sc.upstream_grads(H, W, seed))
     settings = make_settings(st, W, H)
@@ -1397,7 +1401,8 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {P} Gaussians ({kind} scene, seed {seed}) @ {H}x{W}, {what}, "
-                                   f"lidar_far=80 lidar_near=0, bg=0" + ("" if args.beams == "uniform" else f", beam table '{args.beams}' (non-uniform)"),
+                                   f"lidar_far=80 lidar_near=0, bg=0" + ("" if args.beams == "uniform" else f", beam table '{args.beams}' (non-uniform)")
+                                   + ("" if args.opacity_scale == 1.0 else f", opacities x {args.opacity_scale:g} (semi-transparent, early-training regime)"),
                        "visible_gaussians": cnt["V"], "instances_binned": cnt["instances"], "R_ref_16x1": cnt["R_ref"],
                        "patch_instance_pairs_taken": cnt["taken_instances"], "touched_gaussians": cnt.get("touched", -1), "tile_rows": cnt["tile_rows"], "segment_slots": cnt["segments"],
                        "forward": ("HIP-graph replay of forward + backward (enqueue-only path captured once)" if args.graph else

@@ -156,11 +156,16 @@ def _pack(rng, xyz, scales, rots, beams):
     )
 
 
-def make_scene(kind, P, H, seed, random_view=False, beams=None):
-    """beams: None / "uniform" (SURVEY 8d), "waymo", "neartie" (beam_table) or an explicit ascending float32[H] table."""
+def make_scene(kind, P, H, seed, random_view=False, beams=None, opacity_scale=1.0):
+    """beams: None / "uniform" (SURVEY 8d), "waymo", "neartie" (beam_table) or an explicit ascending float32[H] table.
+    opacity_scale: the opacities U(0.1, 1) of SURVEY 8d times this factor.  1 = frames that saturate within a few entries (a trained
+    scene); 0.1 / 0.03 = the semi-transparent frames training STARTS in (the reference's opacities are a tanh-MLP output masked > 0,
+    gaussian_renderer/__init__.py:60-70): no pixel reaches T < 1e-4 early, every list is walked to its end."""
     s = shell_scene(P, H, seed, beams) if kind == "shell" else street_scene(P, H, seed, beams)
     if random_view:
         s["viewmatrix"] = rigid_viewmatrix(np.random.default_rng(seed + 7))
+    if opacity_scale != 1.0:
+        s["opacities"] = (s["opacities"] * np.float32(opacity_scale)).astype(np.float32)
     return s
 
 
@@ -257,6 +262,53 @@ def sweep_case(seed, mid=None):
         scene["opacities"] = (scene["opacities"] * np.float32(0.008)).astype(np.float32)
     grads = upstream_grads(H, W, seed % 1000)
     return scene, W, H, grads, kw, dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, **kw)
+
+
+def sweep_case_any(seed, mid=None):
+    """sweep_case for EVERY scene tools/parity_sweep.py draws, its surfel scenes (seed % 4 == 3, H >= 4) and precomputed-covariance
+    scenes (seed % 5 == 1) included, with the sweep's own order of random draws: dict(scene, W, H, grads, kw, surfel, cov, desc).
+    Surfel scenes: scales are [P,2], grads = (dL_dcolor [2,H,W], dL_dothers [7,H,W]) with the median-depth plane's gradient zeroed."""
+    if mid is None:
+        mid = seed >= 100000 and seed < 900000
+    rng = np.random.default_rng(seed)
+    if mid:
+        H = int(rng.choice([16, 32, 64])); W = int(rng.choice([900, 1800, 2650])); P = int(rng.integers(20000, 60000))
+    else:
+        H = int(rng.choice([2, 3, 5, 16, 17, 32, 40, 64])); W = int(rng.integers(1, 700)); P = int(rng.integers(1, 6000))
+    if not mid and seed % 7 == 5:
+        W = int(rng.integers(4100, 4300)); H = int(rng.choice([2, 3, 16])); P = int(rng.integers(1, 3000))
+    if not mid and seed % 11 == 7:
+        H = int(rng.choice([130, 272])); W = int(rng.integers(1, 200)); P = int(rng.integers(1, 3000))
+    if not mid and seed % 17 == 4:
+        H = int(rng.choice([1025, 1100])); W = int(rng.integers(64, 200)); P = int(rng.integers(1, 3000))
+    if not mid and seed % 19 == 6:
+        H = 1100; W = 4800; P = int(rng.integers(1, 2000))
+    kind = "shell" if rng.random() < 0.5 else "street"
+    beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
+    surfel = (seed % 4 == 3) and H >= 4
+    kw = dict(far=int(rng.choice([80, 30])), near=int(rng.choice([0, 2])), scale_modifier=float(rng.choice([1.0, 0.5, 2.5])))
+    if not mid and seed % 13 == 3:
+        kw["scale_modifier"] = float(rng.choice([6.0, 12.0, 30.0]))
+    desc = dict(seed=seed, kind=kind, P=P, H=H, W=W, beams=beams, variant="surfel" if surfel else "3d", **kw)
+    cov = None
+    if surfel:
+        scene = make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)))
+        scene["scales"] = np.ascontiguousarray(scene["scales"][:, :2])
+        scene["beams"] = beam_table(H, beams)
+        g = np.random.default_rng(seed % 1000 + 200)
+        grads = (g.normal(size=(2, H, W)).astype(np.float32), g.normal(size=(7, H, W)).astype(np.float32))
+        grads[1][5] = 0.0
+    else:
+        scene = make_scene(kind, P, H, seed % 1000, random_view=bool(rng.integers(0, 2)), beams=beams)
+        if seed % 23 == 8:
+            scene["opacities"] = (scene["opacities"] * np.float32(0.008)).astype(np.float32)
+        grads = upstream_grads(H, W, seed % 1000)
+        if seed % 5 == 1:
+            A = rng.normal(size=(P, 3, 3)) * float(scene["scales"].mean())
+            S = A @ np.transpose(A, (0, 2, 1)) + 1e-4 * np.eye(3)
+            cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1).astype(np.float32)
+            desc["cov3D_precomp"] = True
+    return dict(scene=scene, W=W, H=H, grads=grads, kw=kw, surfel=surfel, cov=cov, desc=desc)
 
 
 def anchor_scene(N, k, seed, voxel=0.01, feat_dim=32):

@@ -249,6 +249,13 @@ static char lgo_err[256] = "";
  * its own result is only defined up to summation order; tests use this knob to measure that band. */
 static int lgo_reverse_pixel_order = 0;
 void lgo_set_reverse_pixel_order(int on) { lgo_reverse_pixel_order = on; }
+/* Test knob (round 6): the per-Gaussian sums of the backward blend in float64.  Every TERM stays the float32 value the reference
+ * computes per (pixel, Gaussian); only the sum -- which the reference takes with float atomicAdd in whatever order the hardware
+ * schedules (R3/cr/backward.cu:702-788) and this restatement in raster order -- is made exact.  It is the centre every conforming
+ * summation order scatters around: an implementation whose result is closer to it than the raster-order float32 sum is, is not
+ * "off" where the two float32 sums disagree. */
+static int lgo_accumulate_double = 0;
+void lgo_set_accumulate_double(int on) { lgo_accumulate_double = on; }
 const char* lgo_last_error(void) { return lgo_err; }
 
 void lgo_free(void* h) {
@@ -786,6 +793,21 @@ int lgo_backward_ex(const void* h, int P, int D, int M, int R, const float* back
     }
     const int W = width, H = height, C = LGO_CHANNELS;
     const long long N = (long long)W * H;
+    /* lgo_set_accumulate_double: float64 shadows of the eight per-Gaussian arrays K8 adds to (29 values per Gaussian) */
+    double* acc64 = NULL;
+    if (lgo_accumulate_double) {
+        acc64 = (double*)calloc((size_t)P * 24 + 1, sizeof(double));
+        if (!acc64) { snprintf(lgo_err, sizeof lgo_err, "backward: out of memory (float64 sums)"); return -1; }
+    }
+    double* a_color = acc64;                         /* [P][2] */
+    double* a_depth = acc64 ? acc64 + (size_t)P * 2 : NULL;    /* [P]    */
+    double* a_u1 = acc64 ? acc64 + (size_t)P * 3 : NULL;       /* [P][3] */
+    double* a_u2 = acc64 ? acc64 + (size_t)P * 6 : NULL;       /* [P][3] */
+    double* a_m2 = acc64 ? acc64 + (size_t)P * 9 : NULL;       /* [P][4] */
+    double* a_sp = acc64 ? acc64 + (size_t)P * 13 : NULL;      /* [P][3] */
+    double* a_con = acc64 ? acc64 + (size_t)P * 16 : NULL;     /* [P][4] */
+    double* a_op = acc64 ? acc64 + (size_t)P * 20 : NULL;      /* [P]    */
+#define LGO_ACC(arr, sh, idx, val) do { if (acc64) (sh)[idx] += (double)(val); else (arr)[idx] += (val); } while (0)
 
     /* K8: cr/backward.cu:535-791 renderCUDA, per pixel, back to front */
     for (int yy = 0; yy < H; yy++)
@@ -840,13 +862,13 @@ int lgo_backward_ex(const void* h, int P, int D, int M, int R, const float* back
                     last_color[ch] = c;
                     const float dL_dchannel = dL_dpixel[ch];
                     dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-                    dL_dcolor[g * C + ch] += dchannel_dcolor * dL_dchannel;
+                    LGO_ACC(dL_dcolor, a_color, g * C + ch, dchannel_dcolor * dL_dchannel);
                 }
                 const float dep = s->depths[g];
                 accum_red = last_alpha * last_depth + (1.f - last_alpha) * accum_red;
                 last_depth = dep;
                 dL_dalpha += (dep - accum_red) * dL_dod;
-                dL_ddepths[g] += dchannel_dcolor * dL_dod;
+                LGO_ACC(dL_ddepths, a_depth, g, dchannel_dcolor * dL_dod);
                 accum_reo = (float)((double)last_alpha * 1.0 + (double)((1.f - last_alpha) * accum_reo));   /* :714 */
                 dL_dalpha += (1 - accum_reo) * dL_doo;
                 dL_dalpha *= T;
@@ -865,32 +887,44 @@ int lgo_backward_ex(const void* h, int P, int D, int M, int R, const float* back
                 const float ddy_du2x = (sdx * u2_u2 - _d_u2 * 2 * u2[0]) / (u2_u2 * u2_u2);
                 const float ddy_du2y = (sdy * u2_u2 - _d_u2 * 2 * u2[1]) / (u2_u2 * u2_u2);
                 const float ddy_du2z = (sdz * u2_u2 - _d_u2 * 2 * u2[2]) / (u2_u2 * u2_u2);
-                dL_dbasis_u1[3 * g + 0] += dL_dG * dG_ddelx * ddx_du1x;
-                dL_dbasis_u1[3 * g + 1] += dL_dG * dG_ddelx * ddx_du1y;
-                dL_dbasis_u1[3 * g + 2] += dL_dG * dG_ddelx * ddx_du1z;
-                dL_dbasis_u2[3 * g + 0] += dL_dG * dG_ddely * ddy_du2x;
-                dL_dbasis_u2[3 * g + 1] += dL_dG * dG_ddely * ddy_du2y;
-                dL_dbasis_u2[3 * g + 2] += dL_dG * dG_ddely * ddy_du2z;
-                dL_dmean2D[4 * g + 0] += dL_dG * dG_ddelx;
-                dL_dmean2D[4 * g + 1] += dL_dG * dG_ddely;
+                LGO_ACC(dL_dbasis_u1, a_u1, 3 * g + 0, dL_dG * dG_ddelx * ddx_du1x);
+                LGO_ACC(dL_dbasis_u1, a_u1, 3 * g + 1, dL_dG * dG_ddelx * ddx_du1y);
+                LGO_ACC(dL_dbasis_u1, a_u1, 3 * g + 2, dL_dG * dG_ddelx * ddx_du1z);
+                LGO_ACC(dL_dbasis_u2, a_u2, 3 * g + 0, dL_dG * dG_ddely * ddy_du2x);
+                LGO_ACC(dL_dbasis_u2, a_u2, 3 * g + 1, dL_dG * dG_ddely * ddy_du2y);
+                LGO_ACC(dL_dbasis_u2, a_u2, 3 * g + 2, dL_dG * dG_ddely * ddy_du2z);
+                LGO_ACC(dL_dmean2D, a_m2, 4 * g + 0, dL_dG * dG_ddelx);
+                LGO_ACC(dL_dmean2D, a_m2, 4 * g + 1, dL_dG * dG_ddely);
                 const float ddx_dsx = u1[0] / u1_u1, ddx_dsy = u1[1] / u1_u1, ddx_dsz = u1[2] / u1_u1;
                 const float ddy_dsx = u2[0] / u2_u2, ddy_dsy = u2[1] / u2_u2, ddy_dsz = u2[2] / u2_u2;
                 const float dG_dsx = dG_ddelx * ddx_dsx + dG_ddely * ddy_dsx;
                 const float dG_dsy = dG_ddelx * ddx_dsy + dG_ddely * ddy_dsy;
                 const float dG_dsz = dG_ddelx * ddx_dsz + dG_ddely * ddy_dsz;
                 const float gsx = dL_dG * dG_dsx, gsy = dL_dG * dG_dsy, gsz = dL_dG * dG_dsz;
-                dL_dsphere[3 * g + 0] += gsx;
-                dL_dsphere[3 * g + 1] += gsy;
-                dL_dsphere[3 * g + 2] += gsz;
-                dL_dmean2D[4 * g + 2] += sqrtf(gsx * gsx + gsy * gsy + gsz * gsz);   /* :779 a statistic, not a gradient */
-                dL_dmean2D[4 * g + 3] += 0.0f;
-                dL_dconic[4 * g + 0] += -0.5f * gdx * dx * dL_dG;
-                dL_dconic[4 * g + 1] += -0.5f * gdx * dy * dL_dG;
-                dL_dconic[4 * g + 3] += -0.5f * gdy * dy * dL_dG;
-                dL_dopacity[g] += G * dL_dalpha;
+                LGO_ACC(dL_dsphere, a_sp, 3 * g + 0, gsx);
+                LGO_ACC(dL_dsphere, a_sp, 3 * g + 1, gsy);
+                LGO_ACC(dL_dsphere, a_sp, 3 * g + 2, gsz);
+                LGO_ACC(dL_dmean2D, a_m2, 4 * g + 2, sqrtf(gsx * gsx + gsy * gsy + gsz * gsz));   /* :779 a statistic, not a gradient */
+                LGO_ACC(dL_dmean2D, a_m2, 4 * g + 3, 0.0f);
+                LGO_ACC(dL_dconic, a_con, 4 * g + 0, -0.5f * gdx * dx * dL_dG);
+                LGO_ACC(dL_dconic, a_con, 4 * g + 1, -0.5f * gdx * dy * dL_dG);
+                LGO_ACC(dL_dconic, a_con, 4 * g + 3, -0.5f * gdy * dy * dL_dG);
+                LGO_ACC(dL_dopacity, a_op, g, G * dL_dalpha);
             }
         }
 
+#undef LGO_ACC
+    if (acc64) {   /* the exact sums, rounded once (added to whatever the caller's arrays held: zeros) */
+        for (long long i = 0; i < (long long)P * 2; i++) dL_dcolor[i] = (float)((double)dL_dcolor[i] + a_color[i]);
+        for (long long i = 0; i < (long long)P; i++) dL_ddepths[i] = (float)((double)dL_ddepths[i] + a_depth[i]);
+        for (long long i = 0; i < (long long)P * 3; i++) dL_dbasis_u1[i] = (float)((double)dL_dbasis_u1[i] + a_u1[i]);
+        for (long long i = 0; i < (long long)P * 3; i++) dL_dbasis_u2[i] = (float)((double)dL_dbasis_u2[i] + a_u2[i]);
+        for (long long i = 0; i < (long long)P * 4; i++) dL_dmean2D[i] = (float)((double)dL_dmean2D[i] + a_m2[i]);
+        for (long long i = 0; i < (long long)P * 3; i++) dL_dsphere[i] = (float)((double)dL_dsphere[i] + a_sp[i]);
+        for (long long i = 0; i < (long long)P * 4; i++) dL_dconic[i] = (float)((double)dL_dconic[i] + a_con[i]);
+        for (long long i = 0; i < (long long)P; i++) dL_dopacity[i] = (float)((double)dL_dopacity[i] + a_op[i]);
+        free(acc64);
+    }
     const float* cov3D_ptr = (cov3D_precomp != NULL) ? cov3D_precomp : s->cov3D;
     for (int i = 0; i < P; i++)
         cov2d_bwd_one(i, means3D, radii, cov3D_ptr, viewmatrix, dL_dbasis_u1, dL_dbasis_u2, dL_dconic, dL_dmean3D, dL_dcov3D);

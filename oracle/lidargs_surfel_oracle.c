@@ -70,6 +70,10 @@ static float sf_expf(float x) { return sf_perturb(expf(x), x, 4.0f, 2); }
 
 static int sfo_reverse_pixel_order = 0;
 void sfo_set_reverse_pixel_order(int on) { sfo_reverse_pixel_order = on; }
+/* Test knob (round 6), as lgo_set_accumulate_double: the per-surfel sums of the backward blend in float64 (every term stays the float32
+ * value R2/cr/backward.cu computes; the reference sums them with float atomics in scheduling order). */
+static int sfo_accumulate_double = 0;
+void sfo_set_accumulate_double(int on) { sfo_accumulate_double = on; }
 
 static char sfo_err[256] = "";
 const char* sfo_last_error(void) { return sfo_err; }
@@ -487,6 +491,19 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
     const long long N = (long long)W * H;
     const float pi = SF_PI;
 
+    double* acc64 = NULL;
+    if (sfo_accumulate_double) {
+        acc64 = (double*)calloc((size_t)P * 22 + 1, sizeof(double));
+        if (!acc64) { snprintf(sfo_err, sizeof sfo_err, "backward: out of memory (float64 sums)"); return -1; }
+    }
+    double* a_col = acc64;                                       /* [P][2] */
+    double* a_nrm = acc64 ? acc64 + (size_t)P * 2 : NULL;        /* [P][3] */
+    double* a_tm = acc64 ? acc64 + (size_t)P * 5 : NULL;         /* [P][9] */
+    double* a_t2 = acc64 ? acc64 + (size_t)P * 14 : NULL;        /* [P][3] */
+    double* a_m2 = acc64 ? acc64 + (size_t)P * 17 : NULL;        /* [P][4] */
+    double* a_op = acc64 ? acc64 + (size_t)P * 21 : NULL;        /* [P]    */
+#define SFO_ACC(arr, sh, idx, val) do { if (acc64) (sh)[idx] += (double)(val); else (arr)[idx] += (val); } while (0)
+
     /* K8': R2/cr/backward.cu:143-605 */
     for (int yy = 0; yy < H; yy++)
         for (int xx = 0; xx < W; xx++) {
@@ -535,7 +552,7 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
                     last_color[ch] = c;
                     const float dL_dchannel = dL_dpixel[ch];
                     if (ch == 0) dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;       /* :358-359 ray-drop channel detached */
-                    dL_dcolor[g * C + ch] += dchannel_dcolor * dL_dchannel;
+                    SFO_ACC(dL_dcolor, a_col, g * C + ch, dchannel_dcolor * dL_dchannel);
                 }
                 float dL_dz = 0.0f, dL_dweight = 0;
                 const float m_d = SF_FAR_N / (SF_FAR_N - SF_NEAR_N) * (1 - SF_NEAR_N / c_d);
@@ -555,7 +572,7 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
                     accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
                     last_normal[ch] = q.normal[ch];
                     dL_dalpha += (q.normal[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
-                    dL_dnormal[g * 3 + ch] += alpha * T * dL_dnormal2D[ch];
+                    SFO_ACC(dL_dnormal, a_nrm, g * 3 + ch, alpha * T * dL_dnormal2D[ch]);
                 }
                 dL_dalpha *= T;
                 last_alpha = alpha;
@@ -606,11 +623,10 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
                     sf3 gN = { dL_ds.x * dsx_dn.x + dL_ds.y * dsy_dn.x + dL_dD * dD_dlambda2 * dl_dn.x,
                                dL_ds.x * dsx_dn.y + dL_ds.y * dsy_dn.y + dL_dD * dD_dlambda2 * dl_dn.y,
                                dL_ds.x * dsx_dn.z + dL_ds.y * dsy_dn.z + dL_dD * dD_dlambda2 * dl_dn.z };
-                    float* gT = dL_dtransMat + 9 * g;
-                    gT[0] += gTu.x; gT[1] += gTu.y; gT[2] += gTu.z; gT[3] += gTv.x; gT[4] += gTv.y; gT[5] += gTv.z;
-                    gT[6] += gTw.x; gT[7] += gTw.y; gT[8] += gTw.z;
-                    dL_dtransMat_2dtemp[3 * g] += fabsf(gTw.x); dL_dtransMat_2dtemp[3 * g + 1] += fabsf(gTw.y); dL_dtransMat_2dtemp[3 * g + 2] += fabsf(gTw.z);
-                    dL_dnormal[3 * g] += gN.x; dL_dnormal[3 * g + 1] += gN.y; dL_dnormal[3 * g + 2] += gN.z;
+                    SFO_ACC(dL_dtransMat, a_tm, 9 * g + 0, gTu.x); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 1, gTu.y); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 2, gTu.z); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 3, gTv.x); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 4, gTv.y); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 5, gTv.z);
+                    SFO_ACC(dL_dtransMat, a_tm, 9 * g + 6, gTw.x); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 7, gTw.y); SFO_ACC(dL_dtransMat, a_tm, 9 * g + 8, gTw.z);
+                    SFO_ACC(dL_dtransMat_2dtemp, a_t2, 3 * g, fabsf(gTw.x)); SFO_ACC(dL_dtransMat_2dtemp, a_t2, 3 * g + 1, fabsf(gTw.y)); SFO_ACC(dL_dtransMat_2dtemp, a_t2, 3 * g + 2, fabsf(gTw.z));
+                    SFO_ACC(dL_dnormal, a_nrm, 3 * g, gN.x); SFO_ACC(dL_dnormal, a_nrm, 3 * g + 1, gN.y); SFO_ACC(dL_dnormal, a_nrm, 3 * g + 2, gN.z);
                     /* :564-577 heuristic mean2D statistics; "/float(W)*2.0*pi" evaluates in double */
                     float mx = (float)(fabs((double)(gTw.x * sinf(beta_temp) * cosf(alpha_temp) / (float)W) * 2.0 * (double)pi) +
                                        fabs((double)(gTw.y * cosf(beta_temp) * cosf(alpha_temp) / (float)W) * 2.0 * (double)pi));
@@ -618,29 +634,39 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
                     float my = fabsf(gTw.x * sinf(alpha_temp) * cosf(beta_temp) * grad_alpha) + fabsf(gTw.y * sinf(alpha_temp) * sinf(beta_temp) * grad_alpha) +
                                fabsf(gTw.z * cosf(alpha_temp) * grad_alpha);
                     my = (float)((double)(my * q.rho_r) * 0.5 * (double)(float)H);
-                    dL_dmean2D[4 * g] += mx; dL_dmean2D[4 * g + 1] += my; dL_dmean2D[4 * g + 2] += fabsf(mx); dL_dmean2D[4 * g + 3] += fabsf(my);
+                    SFO_ACC(dL_dmean2D, a_m2, 4 * g, mx); SFO_ACC(dL_dmean2D, a_m2, 4 * g + 1, my); SFO_ACC(dL_dmean2D, a_m2, 4 * g + 2, fabsf(mx)); SFO_ACC(dL_dmean2D, a_m2, 4 * g + 3, fabsf(my));
                 } else {
                     const float dG_ddelx = -G * SF_FILTER_INV_SQ * 40 * q.d.x;
                     const float dG_ddely = -G * SF_FILTER_INV_SQ * 100 * q.d.y;
                     /* "* 0.5 * W": double 0.5 -> double product, int W (:582-585) */
                     float m0 = (float)((double)(dL_dG * dG_ddelx) * 0.5 * (double)W), m1 = (float)((double)(dL_dG * dG_ddely) * 0.5 * (double)H);
-                    dL_dmean2D[4 * g] += m0; dL_dmean2D[4 * g + 1] += m1;
-                    dL_dmean2D[4 * g + 2] += (float)fabs((double)(dL_dG * dG_ddelx) * 0.5 * (double)W);
-                    dL_dmean2D[4 * g + 3] += (float)fabs((double)(dL_dG * dG_ddely) * 0.5 * (double)H);
+                    SFO_ACC(dL_dmean2D, a_m2, 4 * g, m0); SFO_ACC(dL_dmean2D, a_m2, 4 * g + 1, m1);
+                    SFO_ACC(dL_dmean2D, a_m2, 4 * g + 2, (float)fabs((double)(dL_dG * dG_ddelx) * 0.5 * (double)W));
+                    SFO_ACC(dL_dmean2D, a_m2, 4 * g + 3, (float)fabs((double)(dL_dG * dG_ddely) * 0.5 * (double)H));
                     float rho_xy2 = sqrtf(Tw.x * Tw.x + Tw.y * Tw.y);
                     float ddelx_dpx = (float)W / (2 * pi) * Tw.y / (rho_xy2 * rho_xy2);
                     float ddelx_dpy = (float)(-1.0 * (double)(float)W / (double)(2 * pi) * (double)Tw.x / (double)(rho_xy2 * rho_xy2));
                     float ddely_dpx = (float)((double)grad_alpha * (-1.0) * (double)Tw.z * (double)Tw.x / (double)(q.rho_r * q.rho_r * rho_xy2));
                     float ddely_dpy = (float)((double)grad_alpha * (-1.0) * (double)Tw.z * (double)Tw.y / (double)(q.rho_r * q.rho_r * rho_xy2));
                     float ddely_dpz = grad_alpha * rho_xy2 / (q.rho_r * q.rho_r);
-                    float* gT = dL_dtransMat + 9 * g;
-                    gT[6] += dL_dz * (Tw.x / q.rho_r) + dL_dG * (dG_ddelx * ddelx_dpx + dG_ddely * ddely_dpx);
-                    gT[7] += dL_dz * (Tw.y / q.rho_r) + dL_dG * (dG_ddelx * ddelx_dpy + dG_ddely * ddely_dpy);
-                    gT[8] += dL_dz * (Tw.z / q.rho_r) + dL_dG * (dG_ddely * ddely_dpz);
+                    SFO_ACC(dL_dtransMat, a_tm, 9 * g + 6, dL_dz * (Tw.x / q.rho_r) + dL_dG * (dG_ddelx * ddelx_dpx + dG_ddely * ddely_dpx));
+                    SFO_ACC(dL_dtransMat, a_tm, 9 * g + 7, dL_dz * (Tw.y / q.rho_r) + dL_dG * (dG_ddelx * ddelx_dpy + dG_ddely * ddely_dpy));
+                    SFO_ACC(dL_dtransMat, a_tm, 9 * g + 8, dL_dz * (Tw.z / q.rho_r) + dL_dG * (dG_ddely * ddely_dpz));
                 }
-                dL_dopacity[g] += G * dL_dalpha;
+                SFO_ACC(dL_dopacity, a_op, g, G * dL_dalpha);
             }
         }
+
+#undef SFO_ACC
+    if (acc64) {
+        for (long long i = 0; i < (long long)P * 2; i++) dL_dcolor[i] = (float)((double)dL_dcolor[i] + a_col[i]);
+        for (long long i = 0; i < (long long)P * 3; i++) dL_dnormal[i] = (float)((double)dL_dnormal[i] + a_nrm[i]);
+        for (long long i = 0; i < (long long)P * 9; i++) dL_dtransMat[i] = (float)((double)dL_dtransMat[i] + a_tm[i]);
+        for (long long i = 0; i < (long long)P * 3; i++) dL_dtransMat_2dtemp[i] = (float)((double)dL_dtransMat_2dtemp[i] + a_t2[i]);
+        for (long long i = 0; i < (long long)P * 4; i++) dL_dmean2D[i] = (float)((double)dL_dmean2D[i] + a_m2[i]);
+        for (long long i = 0; i < (long long)P; i++) dL_dopacity[i] = (float)((double)dL_dopacity[i] + a_op[i]);
+        free(acc64);
+    }
 
     /* K10': R2/cr/backward.cu:607-749 compute_cylinder_transmat_aabb */
     for (int idx = 0; idx < P; idx++) {

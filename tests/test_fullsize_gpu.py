@@ -121,17 +121,23 @@ def _wedge_subset(scene, W, radii, c0, c1):
     return (pc >= c0 - reach) & (pc <= c1 + reach)
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg3_waymo", "cfg2_neartie"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg3_waymo", "cfg2_neartie", "cfg3_thin"])
 def test_fullsize_wedge_matches_oracle(cfg, hip_lib_built):
     """The headline frame's own code path, value by value (see the module docstring).  cfg4 (8 M Gaussians @ 128 x 4096) runs at
     the adaptive 16- or 32-row tile height; cfg2 / cfg3 on the fine segment plan (64-entry segments, 45 slots, gated first round).
     `cfg3_waymo` / `cfg2_neartie` (round 3): the same frames on NON-UNIFORM beam tables (lidargs_scenes.beam_table) -- what the Waymo
-    configs really read from the dataset json (scene/dataset_readers.py:358-359); radii must then agree with 0 mismatches."""
+    configs really read from the dataset json (scene/dataset_readers.py:358-359); radii must then agree with 0 mismatches.
+    `cfg3_thin` (round 6): the 2 M-Gaussian frame with every opacity x 0.1 -- the semi-transparent state training starts in
+    (gaussian_renderer/__init__.py:60-70): no pixel saturates early, every segment of every list is walked and handed over, the
+    `alive` gates stay open and the slot plan fills; the regime the saturating street scene never visits at this size."""
     from diff_lidargs_rasterization import _C
     from util import GRAD_KEYS_SR, hip_forward_backward, oracle_forward_backward, parity
     cfg, _, table = cfg.partition("_")
+    thin = table == "thin"
+    if thin:
+        table = ""
     kind, P, H, W, seed = sc.BASELINE_CONFIGS[cfg]
-    scene = sc.make_scene(kind, P, H, seed, beams=table or None)
+    scene = sc.make_scene(kind, P, H, seed, beams=table or None, opacity_scale=0.1 if thin else 1.0)
     grads = sc.upstream_grads(H, W, seed)
     hip = hip_forward_backward(scene, W, H, grads)                    # the FULL frame
     cnt = _C.last_counters()
@@ -166,5 +172,20 @@ def test_fullsize_wedge_matches_oracle(cfg, hip_lib_built):
         inside = (ref["radii"] > 0) & (hip["radii"][rows] > 0) & (x_lo >= c0) & (x_hi <= c1)
         assert inside.sum() > 2000, inside.sum()
         print(f"[wedge] {cfg} columns [{c0},{c1}): {int(inside.sum())} Gaussians with their whole rect inside")
+        if thin:    # opacities 0.01-0.1: a large share of the (pixel, Gaussian) pairs sits near the alpha >= 1/255 threshold (R3/cr/forward.cu:607),
+                    # and every gradient row is a long float32 sum: where the plain budget is exceeded the excess must be the oracle's
+                    # summation error or lie in the reference's own band (util.parity_or_closer)
+            from util import oracle_backward_exact_sums, oracle_envelope, parity_or_closer
+            ref64 = oracle_backward_exact_sums(ref, grads)
+            env = {}
+
+            def band(k):
+                if not env:
+                    _b, lo, hi = oracle_envelope(sub, W, H, grads, {}, GRAD_KEYS_SR)
+                    env.update(lo=lo, hi=hi)
+                return env["lo"][k][inside], env["hi"][k][inside]
+            for k in GRAD_KEYS_SR:
+                parity_or_closer(f"{cfg}_thin.{k}[wedge]", hip[k][rows[inside]], ref[k][inside], ref64[k][inside], band=lambda k=k: band(k))
+            continue
         for k in GRAD_KEYS_SR:
             parity(f"{cfg}.{k}[wedge]", hip[k][rows[inside]], ref[k][inside])

@@ -43,3 +43,57 @@ def test_sweep_residue_lies_in_the_reference_band(seed, named, hip_lib_built):
     for k, st in stats.items():
         assert st["hip_over_where_oracle_moves_half"] == st["hip_over"], f"{k}: HIP is off where the reference's band is not: {st}"   # (b)
         assert st["worst_outside_anywhere"] <= 0.5, f"{k}: HIP outside the reference's envelope by {st['worst_outside_anywhere']:.3f} widths"   # (c)
+
+
+# Round 6 (round-5 verdict item 3): the six scenes the round-5 sweeps listed as OUTSIDE the seven-run envelope (profiles/r05_parity_sweep_b.json,
+# _c.json) -- all 1100 x 4800 images with at most 2000 Gaussians, surfel and precomputed-covariance scenes among them: every gradient row is a
+# float32 sum of up to a million per-pixel terms.  DESIGN.md said "the oracle's sequential float32 sum is the less accurate one" without showing
+# it.  Measured (profiles/r06_thin_residue.txt, r06_hip_run_to_run.txt): with the oracle's per-Gaussian sums taken in float64 (the exact sum of
+# the SAME float32 terms: lgo_set_accumulate_double) the statement holds for 31 of the 36 gradient arrays of the six scenes -- each passes the
+# plain budget or HIP has no more entries over 1e-4 against the exact sums than the raster-order float32 oracle has (976321, 976511, 976264
+# entirely; e.g. 990343.dL_dmeans2D: oracle 636 entries over, HIP 0).  It does NOT hold for the five arrays of RESIDUE below (6-19 entries of
+# 1168-5456 each): there HIP's own rounding is the larger one.  It is not the atomics' order (four HIP runs differ from each other by more than
+# 1e-4 on at most one entry per array); all but 2-4 of those entries sit where the reference's seven conforming evaluations differ by more
+# than 0.5e-4 from each other (giant footprints -- scale modifier 30 / surfels spanning hundreds of beams -- put thousands of pairs next to
+# the alpha >= 1/255 threshold), but HIP lies up to 7 local widths outside that seven-sample envelope.  The test pins this state: every
+# other array must pass, the listed ones may carry at most the recorded number of entries.
+LISTED = [976017, 976264, 976321, 976359, 976511, 990343]
+RESIDUE = {976017: {"dL_dopacity": 12}, 976359: {"dL_dmeans3D": 10, "dL_drotations": 18},
+           990343: {"dL_dmeans3D": 22, "dL_dscales": 24, "dL_drotations": 28}}     # array -> most entries over 1e-4 against the exact sums (measured + 50 %)
+
+
+@pytest.mark.parametrize("seed", LISTED)
+def test_listed_sweep_scenes_against_the_exact_sums(seed, hip_lib_built):
+    from util import (GRAD_KEYS_SURFEL, hip_surfel_forward_backward, oracle_backward_exact_sums, oracle_forward_backward,
+                      oracle_surfel_forward_backward, parity, parity_or_closer)
+    c = sc.sweep_case_any(seed, mid=False)
+    scene, W, H, grads, kw = c["scene"], c["W"], c["H"], c["grads"], c["kw"]
+    print(c["desc"])
+    if c["surfel"]:
+        hip = hip_surfel_forward_backward(scene, W, H, grads, **kw)
+        ref = oracle_surfel_forward_backward(scene, W, H, grads, **kw)
+        keys = GRAD_KEYS_SURFEL
+        parity("color", hip["color"], ref["color"])
+    else:
+        hip = hip_forward_backward(scene, W, H, grads, cov3D_precomp=c["cov"], **kw)
+        ref = oracle_forward_backward(scene, W, H, grads, cov3D_precomp=c["cov"], **kw)
+        keys = GRAD_KEYS_SR if c["cov"] is None else ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D")
+        for k in ("color", "depth", "occ"):
+            parity(k, hip[k], ref[k])
+    assert int((hip["radii"] != ref["radii"]).sum()) <= 1
+    ref64 = oracle_backward_exact_sums(ref, grads, surfel=c["surfel"])
+    judged, residue = 0, {}
+    for k in keys:
+        try:
+            st = parity_or_closer(f"{seed}.{k}", hip[k], ref[k], ref64[k])
+            judged += "oracle_over" in st
+        except AssertionError as e:
+            r64 = np.asarray(ref64[k], np.float64).ravel()
+            den = np.abs(r64) + 1e-3 * np.abs(r64).max() + 1e-30
+            residue[k] = int((np.abs(np.asarray(hip[k], np.float64).ravel() - r64) / den > 1e-4).sum())
+            assert np.abs(np.asarray(hip[k], np.float64).ravel() - r64).max() <= 0.05 * np.abs(r64).max(), e
+    print(f"[listed] seed {seed}: {judged} of {len(keys)} gradient arrays judged against the exact sums; residue {residue}")
+    allowed = RESIDUE.get(seed, {})
+    assert set(residue) <= set(allowed), f"arrays outside every criterion that were not before: {set(residue) - set(allowed)} ({residue})"
+    for k, n in residue.items():
+        assert n <= allowed[k], f"{k}: {n} entries over 1e-4 against the exact sums (recorded: at most {allowed[k]})"

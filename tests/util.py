@@ -125,6 +125,62 @@ def oracle_forward_backward(scene, W, H, grads=None, cov3D_precomp=None, far=80,
     return out
 
 
+def oracle_backward_exact_sums(ref, grads, surfel=False):
+    """The oracle's backward on the forward state of `ref` (what oracle_[surfel_]forward_backward returned) once more, with the
+    per-Gaussian sums of the backward blend taken in float64 (lgo_set_accumulate_double / sfo_...: every term stays the float32 value
+    the reference computes; its float atomics add them in scheduling order, R3/cr/backward.cu:702-788, this restatement in raster order --
+    the float64 sum is the centre both scatter around).  -> dict of the gradient arrays."""
+    import ctypes as C
+    from oracle import lgo, lgo_surfel
+    L = lgo.lib()
+    setter = L.sfo_set_accumulate_double if surfel else L.lgo_set_accumulate_double
+    setter(C.c_int(1))
+    try:
+        return (lgo_surfel if surfel else lgo).backward(ref["fwd"], *grads)
+    finally:
+        setter(C.c_int(0))
+
+
+def parity_or_closer(name, hip, ref32, ref64, band=None, rtol=RTOL, floor=FLOOR, max_widths=1.0, **kw):
+    """parity(hip, ref32) -- or, where that budget is exceeded, one of two statements about WHY (round-5 verdict item 3):
+      closer   the excess is the oracle's own summation error: against the exact (float64) sums of the same float32 terms
+               (oracle_backward_exact_sums) HIP has no more entries over rtol than the raster-order float32 oracle itself (+ the flip
+               budget: threshold flips are not summation error);
+      band     the excess lies in the reference's own band: `band()` -> (lo, hi), the entry-wise envelope of the seven conforming
+               evaluations of the reference source (oracle_envelope); every entry where HIP is off by more than rtol is one the oracle
+               itself moves by more than rtol / 2, and HIP lies within `max_widths` local widths of the envelope (envelope_residue).
+    Either way no entry may be off by more than FLIP_ABS_MAX x max|ref|.  `band` is only called when the first two fail (seven oracle runs)."""
+    try:
+        return parity(name, hip, ref32, rtol=rtol, floor=floor, **kw)
+    except AssertionError as first:
+        if PARITY_LOG and PARITY_LOG[-1]["name"] == name:
+            PARITY_LOG.pop()                                            # judged below instead
+        h = np.asarray(hip, np.float64).ravel(); r32 = np.asarray(ref32, np.float64).ravel(); r64 = np.asarray(ref64, np.float64).ravel()
+        scale = np.abs(r64).max()
+        den = np.abs(r64) + floor * scale + 1e-30
+        e_hip, e_ora = np.abs(h - r64) / den, np.abs(r32 - r64) / den
+        n_hip, n_ora = int((e_hip > rtol).sum()), int((e_ora > rtol).sum())
+        allowed_flip = max(MIN_COUNT, int(FLIP_FRAC * r64.size))
+        print(f"[parity] {name:18s} vs exact sums: HIP over {rtol:g}: {n_hip}, float32 raster-order oracle over: {n_ora} (n={r64.size}); "
+              f"HIP p99.9 {np.quantile(e_hip, 0.999):.2e} max {e_hip.max():.2e}, oracle p99.9 {np.quantile(e_ora, 0.999):.2e} max {e_ora.max():.2e}")
+        entry = dict(name=name + " (vs exact sums)", max=float(e_hip.max()), p999=float(np.quantile(e_hip, 0.999)), median=float(np.median(e_hip)),
+                     outliers=n_hip, soft=n_hip, flips=0, n=int(r64.size), scale=float(scale), abs_max=float(np.abs(h - r64).max() / (scale + 1e-30)),
+                     allowed=n_ora + allowed_flip, allowed_flips=allowed_flip, outlier_frac_used=n_hip / r64.size, soft_frac_used=0.0, flip_frac_used=0.0,
+                     rtol=rtol, soft_max=SOFT_MAX, oracle_over=n_ora, judged="closer")
+        assert np.abs(h - r64).max() <= FLIP_ABS_MAX * scale, f"{name}: an entry is off by more than {FLIP_ABS_MAX} x max|ref| from the exact sums"
+        if n_hip > n_ora + allowed_flip:
+            assert band is not None, f"{name}: over the parity budget ({first}) and NOT closer to the exact sums than the float32 oracle: {n_hip} entries over {rtol} against {n_ora}"
+            lo, hi = band()
+            st = envelope_residue({"x": np.asarray(hip).ravel()}, {"x": np.asarray(ref32).ravel()}, {"x": np.asarray(lo).ravel()}, {"x": np.asarray(hi).ravel()}, "x", rtol, floor)
+            print(f"[parity] {name:18s} vs the reference's band: HIP over: {st['hip_over']}, of those where the oracle moves: {st['hip_over_where_oracle_moves_half']}, "
+                  f"band itself over: {st['oracle_band_over']}, worst outside: {st['worst_outside_in_widths']:.2f} widths")
+            entry.update(name=name + " (vs the band)", judged="band", oracle_band_over=st["oracle_band_over"], worst_outside_in_widths=st["worst_outside_in_widths"])
+            assert st["hip_over_where_oracle_moves_half"] == st["hip_over"] and st["worst_outside_in_widths"] <= max_widths, \
+                f"{name}: over the parity budget ({first}), not closer to the exact sums ({n_hip} vs {n_ora}) and not in the reference's band: {st}"
+        PARITY_LOG.append(entry)
+        return entry
+
+
 GRAD_KEYS_SR = ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations")
 
 
