@@ -73,16 +73,41 @@ def _load_valu_rates():
 VALU_RATES_FROM = _load_valu_rates()
 
 
+_ISA_MIX = None
+
+
+def _isa_mix():
+    """The committed instruction-mix profile to price VALU issue with: the one stamped with THIS build's id (tools/isa_mix.py, build_hip.build_id())
+    when there is one, the newest otherwise -- and which of the two it was (round-5 verdict item 13: round 5 priced its rewritten walks on round 3's mix)."""
+    global _ISA_MIX
+    if _ISA_MIX is None:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*isa_mix*.json")))
+        best, same = None, False
+        try:
+            import build_hip
+            bid = build_hip.build_id()
+        except Exception:
+            bid = None
+        for f in files:
+            try:
+                j = json.load(open(f))
+            except Exception:
+                continue
+            if best is None or not same:
+                if bid is not None and j.get("build_id") == bid:
+                    best, same = (j, os.path.basename(f)), True
+                elif not same:
+                    best = (j, os.path.basename(f))
+        _ISA_MIX = (best[0], best[1], same, bid) if best else (None, None, False, bid)
+    return _ISA_MIX
+
+
 def valu_class_shares(kernel):
     """(shares {full, half, quarter}, where from) of a kernel's VALU instructions: its hot loop's mix from the committed
     profiles/*isa_mix*.json (`whole` = the whole kernel, for the one-thread-per-Gaussian streams that have no hot loop)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*isa_mix*.json")))
-    if not files:
-        return None, None
-    try:
-        j = json.load(open(files[-1]))
-    except Exception:
+    j, name, _same, _bid = _isa_mix()
+    if j is None:
         return None, None
     for k, v in j["kernels"].items():
         if k == kernel or k.startswith(kernel + "<") or kernel.startswith(k):
@@ -90,8 +115,8 @@ def valu_class_shares(kernel):
             if not m:
                 continue
             tot = float(m["full"] + m["half"] + m["quarter"]) or 1.0
-            return {c: m[c] / tot for c in ("full", "half", "quarter")}, os.path.basename(files[-1])
-    return None, os.path.basename(files[-1])
+            return {c: m[c] / tot for c in ("full", "half", "quarter")}, name
+    return None, name
 
 
 def valu_roof(kernel_names, insts, ms):
@@ -107,7 +132,8 @@ def valu_roof(kernel_names, insts, ms):
     g = insts / (ms * 1e-3) / 1e9
     return {"bound": "valu-issue (class-weighted)", "achieved": g, "peak": mean_rate, "unit": "G wave-instructions/s", "frac": g / mean_rate,
             "valu_insts_per_launch": insts, "class_shares": {c: round(v, 3) for c, v in shares.items()},
-            "class_rates": dict(VALU_CLASS_RATES), "rates_from": VALU_RATES_FROM, "shares_from": src}
+            "class_rates": dict(VALU_CLASS_RATES), "rates_from": VALU_RATES_FROM, "shares_from": src,
+            "shares_build": (_isa_mix()[0] or {}).get("build_id"), "shares_same_build": bool(_isa_mix()[2])}
 
 
 def reference_dataflow_bytes(P, V, R_ref, N, T):

@@ -732,10 +732,12 @@ int launch_radix_sort_pairs16(uint16_t* key_a, uint16_t* key_b, uint32_t* val_a,
 // A bucket with more than BSORT_CAP pairs (a frame whose Gaussians crowd into a thousandth of its range span) is sorted by the same
 // workgroup through global memory (wg_radix_sort on the bucket's sub-range): correct, slower.  The culled Gaussians (key 0xFFFFFFFF) are
 // the last bucket: all keys equal, nothing to sort.
-constexpr int BUCKET_BITS = 10, BUCKET_BINS = 1 << BUCKET_BITS;
+constexpr int BUCKET_BITS = 10, BUCKET_BITS_BIG = 11;     // 1024 intervals up to 4 M Gaussians, 2048 above (round 6): the LDS path holds 7168 pairs per bucket
 constexpr int BSORT_WAVES = 8, BSORT_ITEMS = 14, BSORT_CAP = 64 * BSORT_WAVES * BSORT_ITEMS;   // 7168 pairs per bucket on the LDS path (66 KB of LDS: two workgroups per CU)
 constexpr uint32_t BSORT_CULL_SLICE = 4096;                              // culled Gaussians written per workgroup of the launch's tail
-constexpr size_t BUCKET_SORT_MAX = (size_t)4 << 20;                    // beyond: the plain LSD passes (buckets of 4 k pairs on average would leave the LDS path no room)
+constexpr size_t BUCKET_SORT_MAX = (size_t)4 << 20;                    // beyond: the plain LSD passes.  Round 6 measured the 2048-interval form (BUCKET_BITS_BIG, kept behind
+                                                                       // LIDARGS_RANGE_SORT_BUCKET_BITS=11 and tested) at 8 M Gaussians: 409 us against the LSD passes' 336 -- with 2048 digits a 4096-key
+                                                                       // block's digit runs are 2 keys long (scatter 185 us: every pair a 4-byte write of its own), the bucket launch 166 us
 
 // (its own function, not inlined: the rare path's registers must not count against the LDS path's occupancy)
 __device__ __attribute__((noinline)) void bucket_sort_slow(uint32_t* ka, uint32_t* kb, uint32_t* va, uint32_t* vb, uint32_t n, int bits, uint32_t kmn,
@@ -743,6 +745,7 @@ __device__ __attribute__((noinline)) void bucket_sort_slow(uint32_t* ka, uint32_
     KeyMap km; km.kmin = kmn; km.cull = 0u; km.on = true; km.lin_span = nullptr;
     wg_radix_sort<uint32_t, BSORT_WAVES>(ka, kb, va, vb, n, 0, bits, 8, 0, RadixTail(), km, cnt, wsum);
 }
+template <int BUCKET_BINS>
 __global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) k_bucket_sort(uint32_t* keys, uint32_t* ids, uint32_t* key_tmp, uint32_t* id_tmp,
                                                                        const uint32_t* __restrict__ tot, uint32_t* ids_out, const RadixTail tail, const uint32_t P) {
     constexpr int W = BSORT_WAVES, ITEMS = BSORT_ITEMS, BINS = 256;
@@ -900,26 +903,34 @@ __global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_
     }
 }
 
-// LIDARGS_RANGE_SORT_BUCKETS=0: the LSD passes again (A/B, tests)
+// LIDARGS_RANGE_SORT_BUCKETS=0: the LSD passes again (A/B, tests).  LIDARGS_RANGE_SORT_BUCKET_BITS=11: the 2048-interval form at any size
+// (tests: the oracle cannot run frames above 4 M Gaussians; read per call, the suite switches it inside one process).
+static int forced_bucket_bits() { const char* e = getenv("LIDARGS_RANGE_SORT_BUCKET_BITS"); const int v = e ? atoi(e) : 0; return (v == BUCKET_BITS || v == BUCKET_BITS_BIG) ? v : 0; }
 bool range_sort_buckets_ok(size_t P) {
     static const bool on = [] { const char* e = getenv("LIDARGS_RANGE_SORT_BUCKETS"); return !e || atoi(e) != 0; }();
     static const size_t small_max = [] { const char* e = getenv("LIDARGS_SMALL_SORT_MAX"); const long v = e ? atol(e) : (long)SMALL_SORT_DEFAULT;
                                          return (size_t)(v < 0 ? 0 : (v > (long)SMALL_SORT_MAX ? (long)SMALL_SORT_MAX : v)); }();
     static const int small_off = [] { const char* e = getenv("LIDARGS_NO_SMALL_SORT"); return e ? atoi(e) : 0; }();
-    return on && P <= BUCKET_SORT_MAX && (small_off || P > small_max);
+    return on && (P <= BUCKET_SORT_MAX || forced_bucket_bits() == BUCKET_BITS_BIG) && (small_off || P > small_max);
 }
 // (key_a, positions) -> ids in range order in id_a, tail.dst = the records of tail.src in range order.  key_b / id_b hold the bucketed
 // pairs; `scratch` as for launch_radix_sort_pairs with scratch_bits = SORT_MAX_RADIX_BITS.  key_span: GeomView totals + LG_TOTALS_KEYSPAN_WORD.
+template <int BB>
+static void range_sort_buckets_t(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a, uint32_t* id_b, size_t P, uint32_t* scratch, const KeyBias* kb, RadixTail tail, hipStream_t s) {
+    // (4096-key blocks: with 1024 digits a block's digit runs are 4 keys long, 2 in a half-size block -- every pair a write of its own:
+    //  scatter 36.3 -> 28.7 us, histogram 12.7 -> 10.2 us at 2 M keys)
+    radix_pass_items<BB, SORT_ITEMS, uint32_t>(key_a, nullptr, key_b, id_b, P, nullptr, 0, scratch, s, SORT_MAX_RADIX_BITS, RadixTail(), kb);
+    const uint32_t* tot = scratch + ((size_t)1 << SORT_MAX_RADIX_BITS) * sort_blocks(P);       // where the pass left the digit totals (radix_pass_items)
+    const unsigned cull_blocks = (unsigned)((P + BSORT_CULL_SLICE - 1) / BSORT_CULL_SLICE);     // (as many as a frame of culled Gaussians only would need: the others leave at once)
+    hipLaunchKernelGGL(k_bucket_sort<(1 << BB)>, dim3((1 << BB) - 1 + cull_blocks), dim3(64 * BSORT_WAVES), 0, s, key_b, id_b, key_a, id_a, tot, id_a, tail, (uint32_t)P);
+}
 void launch_range_sort_buckets(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a, uint32_t* id_b, size_t P, uint32_t* scratch, const uint32_t* key_span,
                                RadixTail tail, hipStream_t s) {
     if (P == 0) return;
     KeyBias kb; kb.kmin = 0u; kb.cull = 0xFFFFFFFFu; kb.lin_span = key_span;
-    // (4096-key blocks: with 1024 digits a block's digit runs are 4 keys long, 2 in a half-size block -- every pair a write of its own:
-    //  scatter 36.3 -> 28.7 us, histogram 12.7 -> 10.2 us at 2 M keys)
-    radix_pass_items<BUCKET_BITS, SORT_ITEMS, uint32_t>(key_a, nullptr, key_b, id_b, P, nullptr, 0, scratch, s, SORT_MAX_RADIX_BITS, RadixTail(), &kb);
-    const uint32_t* tot = scratch + ((size_t)1 << SORT_MAX_RADIX_BITS) * sort_blocks(P);       // where the pass left the digit totals (radix_pass_items)
-    const unsigned cull_blocks = (unsigned)((P + BSORT_CULL_SLICE - 1) / BSORT_CULL_SLICE);     // (as many as a frame of culled Gaussians only would need: the others leave at once)
-    hipLaunchKernelGGL(k_bucket_sort, dim3(BUCKET_BINS - 1 + cull_blocks), dim3(64 * BSORT_WAVES), 0, s, key_b, id_b, key_a, id_a, tot, id_a, tail, (uint32_t)P);
+    const int forced = forced_bucket_bits();
+    if (forced ? forced == BUCKET_BITS_BIG : P > BUCKET_SORT_MAX) range_sort_buckets_t<BUCKET_BITS_BIG>(key_a, key_b, id_a, id_b, P, scratch, &kb, tail, s);
+    else range_sort_buckets_t<BUCKET_BITS>(key_a, key_b, id_a, id_b, P, scratch, &kb, tail, s);
 }
 
 // ------------------------------------------------------------------------------------------------

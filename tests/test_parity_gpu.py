@@ -55,14 +55,18 @@ def test_forward_backward_matches_oracle(case, hip_lib_built):
 RANGE_SORT_CASES = ["duplicate_ranges", "crowded_bucket", "one_bucket", "two_ranges_only", "mostly_culled"]
 
 
+@pytest.mark.parametrize("bucket_bits", [10, 11], ids=["1024_intervals", "2048_intervals"])
 @pytest.mark.parametrize("case", RANGE_SORT_CASES)
-def test_bucketed_range_sort_on_inputs_built_against_it(case, hip_lib_built):
+def test_bucketed_range_sort_on_inputs_built_against_it(case, bucket_bits, hip_lib_built, monkeypatch):
     """The range sort of frames above 4096 Gaussians is one bucket pass on the LINEAR range + one launch that finishes every bucket in LDS
     (binning.hip, round 5).  The per-tile order it must produce is (range bits, index) -- R3/cr/rasterizer_impl.cu:103-106, :317-322 -- and
     every pixel of the image depends on it.  Inputs built against it: thousands of Gaussians at bit-identical ranges (the stable order
     among equal keys is the index order), a bucket far over the LDS path's 7168 pairs (20 000 Gaussians inside 2 cm of range beside two
     outliers that stretch the span: sorted through global memory by one workgroup), every Gaussian in ONE bucket at one identical range,
-    a span with only two distinct keys, and a frame whose Gaussians are mostly culled (the last bucket: the launch's tail of slices)."""
+    a span with only two distinct keys, and a frame whose Gaussians are mostly culled (the last bucket: the launch's tail of slices).
+    Round 6: frames above 4 M Gaussians take the same path with 2048 intervals (cfg4: 8 M); the oracle cannot run at that size, so the form
+    is forced here (LIDARGS_RANGE_SORT_BUCKET_BITS=11) on the same adversarial inputs, and tests/test_fullsize_gpu.py checks cfg4's wedge."""
+    monkeypatch.setenv("LIDARGS_RANGE_SORT_BUCKET_BITS", str(bucket_bits))
     H, W, seed = 16, 512, 71
     rng = np.random.default_rng(seed)
     scene = sc.make_scene("shell", 30_000 if case != "crowded_bucket" else 24_000, H, seed, random_view=False)

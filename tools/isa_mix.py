@@ -102,7 +102,7 @@ def demangle(n):
 
 
 def main():
-    res = {"note": __doc__.split("\n\n")[0], "class_rates_G_wave_inst_per_s": RATE, "rates_from": "profiles/r03_valu_rate2.json (4 waves per SIMD)", "kernels": {}}
+    res = {"note": __doc__.split("\n\n")[0], "build_id": build_hip.build_id(), "class_rates_G_wave_inst_per_s": RATE, "rates_from": "profiles/r03_valu_rate2.json (4 waves per SIMD)", "kernels": {}}
     with tempfile.TemporaryDirectory() as tmp:
         for src, extra in build_hip.SOURCES.items():
             out = os.path.join(tmp, src + ".s")
