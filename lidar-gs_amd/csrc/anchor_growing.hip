@@ -6,8 +6,8 @@
 // 1e4 x 1.2 M = 1.2e10 per level.  The feature maximum per voxel is torch_scatter.scatter_max (:742).
 //
 // Here the same sets come from hashing, in HBM-bound passes over the inputs:
-//   k_ag_mark       N0*k offsets: the mask (:683-688), the candidates' positions (:698) and voxels (:709) -> list of candidate slots
-//                   (block-aggregated append), their count and voxel bounding box                     [host read: count, box]
+//   k_ag_mark       N0*k offsets: the mask (:683-688) -> list of candidate slots (block-aggregated append) and their count
+//   k_ag_box        candidates: positions (:698) and voxels (:709) -> their voxel bounding box           [host read: count, box]
 //   k_ag_insert     candidates -> 64-bit voxel key packed to the box (x most significant: the key's order is torch.unique's row order),
 //                   atomicCAS insert into an open-addressing set of >= 2 C slots; each candidate remembers its slot
 //   k_ag_probe      the N existing anchors quantised the same way (:706) probe the set: a hit marks the voxel dead (:714-729)
@@ -23,6 +23,7 @@
 #include "../../include/lidargs_rasterizer.h"
 #include "../../include/lidargs_anchor_growing.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace lg {
 
@@ -86,36 +87,75 @@ __global__ void k_ag_init(uint32_t* hdr) {
 #define AG_MARK_ITEMS 16     // offsets per thread of the mask pass: 4096 per block, 1758 blocks at 7.2 M offsets
 __global__ void __launch_bounds__(256) k_ag_mark(AgLevel p, const float* __restrict__ anchor, const float* __restrict__ offset, const float* __restrict__ scaling,
                                                  const float* __restrict__ grads, const uint8_t* __restrict__ omask, const float* __restrict__ rnd,
-                                                 uint32_t* __restrict__ hdr, uint32_t* __restrict__ list) {
-    __shared__ int s_box[6];
+                                                 uint32_t* __restrict__ hdr, uint32_t* __restrict__ list, int vec) {
     __shared__ uint32_t s_wave[5];
-    if (threadIdx.x < 6) s_box[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : INT_MIN;
     const size_t slots = (size_t)p.N0 * p.k;
-    const size_t base = (size_t)blockIdx.x * (256 * AG_MARK_ITEMS) + threadIdx.x;
+    // thread t takes 16 CONSECUTIVE offsets: four 16-byte loads of the gradients, four of the random draws, one of the mask bytes
+    // (48 scalar loads before: the pass ran at 1.2 TB/s); `vec` = the three arrays are 16-byte aligned (torch's allocations are)
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * AG_MARK_ITEMS;
     uint32_t bits = 0;
+    if (vec && base + AG_MARK_ITEMS <= slots) {
+        const float4* g4 = reinterpret_cast<const float4*>(grads + base);
+        const uint4 m4 = *reinterpret_cast<const uint4*>(omask + base);
+        float4 g[4], r[4];
 #pragma unroll
-    for (int it = 0; it < AG_MARK_ITEMS; it++) {
-        const size_t s = base + (size_t)it * 256;
-        bool cand = false;
-        if (s < slots) {
-            cand = grads[s] >= p.thr && omask[s] != 0;                   // :683-684 (a NaN gradient is no candidate: the compare is false)
-            if (cand && rnd) cand = rnd[s] > p.rthr;                    // :687-689
+        for (int q = 0; q < 4; q++) g[q] = g4[q];
+        if (rnd) {
+            const float4* r4 = reinterpret_cast<const float4*>(rnd + base);
+#pragma unroll
+            for (int q = 0; q < 4; q++) r[q] = r4[q];
         }
-        bits |= (cand ? 1u : 0u) << it;
+        const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float gv[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+            const float rv[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                bool cand = gv[e] >= p.thr && ((mw[q] >> (8 * e)) & 0xFFu) != 0;      // :683-684 (a NaN gradient is no candidate: the compare is false)
+                if (rnd) cand = cand && rv[e] > p.rthr;                                 // :687-689
+                bits |= (cand ? 1u : 0u) << (4 * q + e);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int it = 0; it < AG_MARK_ITEMS; it++) {
+            const size_t s = base + (size_t)it;
+            bool cand = false;
+            if (s < slots) {
+                cand = grads[s] >= p.thr && omask[s] != 0;
+                if (cand && rnd) cand = rnd[s] > p.rthr;
+            }
+            bits |= (cand ? 1u : 0u) << it;
+        }
     }
     uint32_t pos = ag_block_append((uint32_t)__builtin_popcount(bits), hdr, s_wave);
+    for (uint32_t b = bits; b; b &= b - 1) list[pos++] = (uint32_t)(base + (size_t)__builtin_ctz(b));
+}
+
+// the candidates' voxel bounding box: one candidate per thread, every gather of the launch in flight at once (inside k_ag_mark the few
+// lanes with candidates walked theirs one dependent round trip after the other: 52-74 us for a pass that streams in 15)
+__global__ void __launch_bounds__(256) k_ag_box(AgLevel p, const float* __restrict__ anchor, const float* __restrict__ offset, const float* __restrict__ scaling,
+                                                uint32_t* __restrict__ hdr, const uint32_t* __restrict__ list) {
+    __shared__ int s_box[6];
+    if (threadIdx.x < 6) s_box[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : INT_MIN;
+    __syncthreads();
+    const uint32_t C = hdr[0];
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
-    for (uint32_t b = bits; b; b &= b - 1) {
-        const size_t s = base + (size_t)__builtin_ctz(b) * 256;
-        list[pos++] = (uint32_t)s;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
         int g[3];
-        ag_candidate_voxel(p, (uint32_t)s, anchor, offset, scaling, g);
+        ag_candidate_voxel(p, list[c], anchor, offset, scaling, g);
 #pragma unroll
-        for (int c = 0; c < 3; c++) { lo[c] = min(lo[c], g[c]); hi[c] = max(hi[c], g[c]); }
+        for (int q = 0; q < 3; q++) { lo[q] = min(lo[q], g[q]); hi[q] = max(hi[q], g[q]); }
     }
-    if (bits) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) { atomicMin(&s_box[c], lo[c]); atomicMax(&s_box[3 + c], hi[c]); }
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[q] = min(lo[q], __shfl_xor(lo[q], o)); hi[q] = max(hi[q], __shfl_xor(hi[q], o)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) { atomicMin(&s_box[q], lo[q]); atomicMax(&s_box[3 + q], hi[q]); }
     }
     __syncthreads();
     if (threadIdx.x < 6) {
@@ -264,8 +304,10 @@ int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, con
     uint32_t* list = cv.take<uint32_t>((size_t)N0 * n_offsets);
     const size_t slots = (size_t)N0 * n_offsets;
 
+    const int vec = (((uintptr_t)grads | (uintptr_t)offset_mask | (uintptr_t)(rnd ? rnd : grads)) & 15u) == 0 ? 1 : 0;
     hipLaunchKernelGGL(lg::k_ag_init, dim3(1), dim3(64), 0, stream, hdr);
-    hipLaunchKernelGGL(lg::k_ag_mark, dim3((unsigned)((slots + 256 * AG_MARK_ITEMS - 1) / (256 * AG_MARK_ITEMS))), dim3(256), 0, stream, p, anchor, offset, scaling, grads, offset_mask, rnd, hdr, list);
+    hipLaunchKernelGGL(lg::k_ag_mark, dim3((unsigned)((slots + 256 * AG_MARK_ITEMS - 1) / (256 * AG_MARK_ITEMS))), dim3(256), 0, stream, p, anchor, offset, scaling, grads, offset_mask, rnd, hdr, list, vec);
+    hipLaunchKernelGGL(lg::k_ag_box, dim3((unsigned)std::min<size_t>(1024, (slots + 255) / 256)), dim3(256), 0, stream, p, anchor, offset, scaling, hdr, list);
     AG_HIP(hipGetLastError());
     uint32_t h[AG_HDR];
     AG_HIP(lg::api_read_words_zero_behind(hdr, 8, h, nullptr, 0, stream));

@@ -189,6 +189,13 @@ def test_degenerate_inputs(hip_lib_built):
     a, f, counts = ag.grow_level(far, off - 1e4 / act[:, None, :3], act, args[3], torch.ones(5000 * 4, device="cuda"), sel, None, 0.5, 0.5, 4096.0)
     assert counts == (20000, 1, 1) and torch.equal(a, torch.zeros(1, 3, device="cuda"))
     assert torch.equal(f[0], args[3].max(0).values)
+    # inputs at addresses that are not 16-byte aligned (views into larger tensors) take the kernel's scalar loads: same anchors
+    g0, m0 = t(c["grads"]), t(c["offset_mask"])
+    rnd = torch.rand(5000 * 4, device="cuda")
+    ref_a, ref_f, ref_c = ag.grow_level(*args, g0, m0, rnd, 0.0005, 0.5, 0.16)
+    shift = lambda x: torch.cat([x[:1], x])[1:]
+    a, f, counts = ag.grow_level(*args, shift(g0), shift(m0), shift(rnd), 0.0005, 0.5, 0.16)
+    assert shift(g0).data_ptr() % 16 != 0 and counts == ref_c and ref_c[2] > 0 and torch.equal(a, ref_a) and torch.equal(f, ref_f)
     # CPU tensors are refused (no CPU path)
     with pytest.raises(RuntimeError):
         ag.grow_level(args[0].cpu(), args[1].cpu(), act.cpu(), args[3].cpu(), t(c["grads"]).cpu(), t(c["offset_mask"]).cpu(), None, 0.1, 0.5, 0.16)
