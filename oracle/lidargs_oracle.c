@@ -256,6 +256,10 @@ void lgo_set_reverse_pixel_order(int on) { lgo_reverse_pixel_order = on; }
  * "off" where the two float32 sums disagree. */
 static int lgo_accumulate_double = 0;
 void lgo_set_accumulate_double(int on) { lgo_accumulate_double = on; }
+/* mode 2 (diagnostic): additionally the backward's transmittance chain T = T / (1 - alpha) (R3/cr/backward.cu:676) is carried in float64
+ * and rounded per entry: the reference walks back from T_final with one float32 division per entry, so its T drifts from the forward's
+ * by ~sqrt(entries) half-ulps -- 1300-entry lists (scale modifier 30): ~2e-6, which a cancelling gradient row amplifies.  An
+ * implementation that restarts the chain at stored per-segment values does not share that drift. */
 const char* lgo_last_error(void) { return lgo_err; }
 
 void lgo_free(void* h) {
@@ -820,6 +824,7 @@ int lgo_backward_ex(const void* h, int P, int D, int M, int R, const float* back
             /* shell extension: T starts at this shell's own end value, T_final is the global one and the
              * "colour behind" recurrences are seeded with what the farther shells composited */
             float T = s->final_T[pix];
+            double Td = (double)T;
             const float T_final = T_final_global ? T_final_global[pix] : T;
             uint32_t contributor = r1 - r0;
             const int last_contributor = (int)s->n_contrib[pix];
@@ -853,7 +858,7 @@ int lgo_backward_ex(const void* h, int P, int D, int M, int R, const float* back
                 const float alpha = 0.99f < aa ? 0.99f : aa;
                 if (alpha < 1.0f / 255.0f) continue;
 
-                T = T / (1.f - alpha);
+                if (lgo_accumulate_double >= 2) { Td = Td / (double)(1.f - alpha); T = (float)Td; } else T = T / (1.f - alpha);
                 const float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.0f;
                 for (int ch = 0; ch < C; ch++) {

@@ -516,6 +516,7 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
             const sf3 p = sf_pixel_dir(x, y, W, H, beams);
             const float T_final = s->accum[pix];
             float T = T_final;
+            double Td = (double)T;          /* sfo_set_accumulate_double(2): the chain below in float64 (see lgo_set_accumulate_double) */
             uint32_t contributor = r1 - r0;
             const int last_contributor = (int)s->n_contrib[pix];
             float accum_rec[SF_CHANNELS] = { 0 }, dL_dpixel[SF_CHANNELS];
@@ -543,7 +544,7 @@ int sfo_backward(const void* h, int P, int R, const float* background, int width
                 const float aa = q.opa * G;
                 const float alpha = 0.99f < aa ? 0.99f : aa;
                 if (alpha < 1.0f / 255.0f) continue;
-                T = T / (1.f - alpha);
+                if (sfo_accumulate_double >= 2) { Td = Td / (double)(1.f - alpha); T = (float)Td; } else T = T / (1.f - alpha);
                 const float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.0f;
                 for (int ch = 0; ch < C; ch++) {

@@ -52,21 +52,25 @@ class CpuAndRecord(TorchFunctionMode):
 def reference_methods():
     tree = ast.parse(open(os.path.join(REF, "scene/gaussian_model.py")).read())
     cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "GaussianModel")
-    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("anchor_growing", "cat_tensors_to_optimizer")]
-    assert len(fns) == 2
+    names = ("anchor_growing", "cat_tensors_to_optimizer", "adjust_anchor", "prune_anchor", "_prune_anchor_optimizer")
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names)
     util = ast.parse(open(os.path.join(REF, "utils/general_utils.py")).read())
     inv = next(n for n in util.body if isinstance(n, ast.FunctionDef) and n.name == "inverse_sigmoid")
     ns = {"torch": torch, "nn": nn, "reduce": reduce, "scatter_max": scatter_max}
     exec(compile(ast.fix_missing_locations(ast.Module(body=[inv] + fns, type_ignores=[])), REF, "exec"), ns)
-    return ns["anchor_growing"], ns["cat_tensors_to_optimizer"]
+    return ns
 
 
 def host_class():
-    grow, cat = reference_methods()
+    ns = reference_methods()
 
     class Host:
-        anchor_growing = grow
-        cat_tensors_to_optimizer = cat
+        anchor_growing = ns["anchor_growing"]
+        cat_tensors_to_optimizer = ns["cat_tensors_to_optimizer"]
+        adjust_anchor = ns["adjust_anchor"]                                                # :776-830 (case "adj")
+        prune_anchor = ns["prune_anchor"]
+        _prune_anchor_optimizer = ns["_prune_anchor_optimizer"]
         get_anchor = property(lambda self: self._anchor)                                   # scene/gaussian_model.py:254-256
         get_scaling = property(lambda self: 1.0 * torch.exp(self._scaling))                # :212-214 (scaling_activation = torch.exp, :39)
     return Host
@@ -115,6 +119,49 @@ def scene(tag, seed):
                 offset_mask=offset_mask, seed=seed)
 
 
+def run_adjust(tag, seed, out):
+    """GaussianModel.adjust_anchor as a whole (:776-830): gradient norms from the accumulators, anchor_growing, the statistics' reset and
+    padding, the prune masks, prune_anchor with the optimizer surgery -- executed on case `a`'s model with accumulators built to make
+    every branch run (offsets over and under the visit threshold, NaN gradients from 0 / 0, anchors to prune)."""
+    c = scene("a", seed)
+    Host = host_class()
+    h = Host()
+    N, k = c["N"], c["k"]
+    h.n_offsets, h.feat_dim, h.voxel_size = k, 32, c["voxel"]
+    h.update_depth, h.update_init_factor, h.update_hierachy_factor = 3, 16, 4
+    h._anchor = nn.Parameter(c["anchor"].clone()); h._offset = nn.Parameter(c["offset"].clone()); h._anchor_feat = nn.Parameter(c["feat"].clone())
+    h._opacity = nn.Parameter(torch.full((N, 1), 0.25)); h._scaling = nn.Parameter(c["scaling"].clone())
+    h._rotation = nn.Parameter(torch.tensor([[1.0, 0, 0, 0]]).repeat(N, 1))
+    h.optimizer = torch.optim.Adam([{"params": [getattr(h, "_" + n)], "lr": 1e-3, "name": n} for n in PARAMS], lr=0.0, eps=1e-15)
+    for n in PARAMS:
+        getattr(h, "_" + n).grad = torch.zeros_like(getattr(h, "_" + n))
+    h.optimizer.step()
+    g = torch.Generator().manual_seed(seed + 5)
+    denom = torch.randint(0, 40, (N * k, 1), generator=g).float()                           # visits; > check_interval * success_threshold = 10 passes :781
+    accum = c["grads"].view(-1, 1) * denom                                                  # so that accum / denom = the case's gradient norms (0 / 0 -> NaN -> 0, :779)
+    h.offset_gradient_accum, h.offset_denom = accum.clone(), denom.clone()
+    h.anchor_demon = torch.randint(0, 40, (N, 1), generator=g).float()
+    h.opacity_accum = torch.rand(N, 1, generator=g) * 0.4 * h.anchor_demon * 0.02           # some below min_opacity * anchor_demon (:799)
+    ins = dict(offset_gradient_accum=accum, offset_denom=denom, anchor_demon=h.anchor_demon.clone(), opacity_accum=h.opacity_accum.clone())
+    torch.manual_seed(c["seed"] + 2000)
+    mode = CpuAndRecord()
+    with torch.no_grad(), mode:
+        h.adjust_anchor(check_interval=100, success_threshold=0.1, grad_threshold=c["thr"], min_opacity=0.005)     # train.py:247 with arguments/__init__.py:150-155
+    npy = lambda t: t.detach().numpy().copy()
+    out.update({f"{tag}_N": N, f"{tag}_k": k, f"{tag}_voxel_size": np.float64(c["voxel"]), f"{tag}_threshold": np.float64(c["thr"]),
+                f"{tag}_in_anchor": npy(c["anchor"]), f"{tag}_in_offset": npy(c["offset"]), f"{tag}_in_scaling": npy(c["scaling"]), f"{tag}_in_anchor_feat": npy(c["feat"]),
+                f"{tag}_n_rand": len(mode.rands)})
+    for n, t in ins.items():
+        out[f"{tag}_in_{n}"] = npy(t)
+    for i, rr in enumerate(mode.rands):
+        out[f"{tag}_rand{i}"] = npy(rr)
+    for n in PARAMS:
+        out[f"{tag}_out_{n}"] = npy(getattr(h, "_" + n))
+    for n in ("offset_gradient_accum", "offset_denom", "anchor_demon", "opacity_accum", "max_radii2D"):
+        out[f"{tag}_out_{n}"] = npy(getattr(h, n))
+    print(tag, "anchors", N, "->", h._anchor.shape[0], "rand draws", len(mode.rands))
+
+
 def run(tag, seed, out):
     c = scene(tag, seed)
     Host = host_class()
@@ -158,5 +205,6 @@ if __name__ == "__main__":
     run("a", 11, out)
     run("b", 12, out)
     run("c", 13, out)
+    run_adjust("adj", 14, out)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

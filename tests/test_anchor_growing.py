@@ -82,6 +82,15 @@ class _Model:
         import torch
         return {n: torch.cat((getattr(self, "_" + n), d[n]), dim=0) for n in PARAMS}
 
+    def prune_anchor(self, mask):
+        """What the reference's prune_anchor / _prune_anchor_optimizer leave in the parameters (:625-675), optimizer state aside: the kept rows,
+        and -- a quirk of :644-648 -- columns 3.. of the (log-space) scaling clamped at 0.05."""
+        keep = ~mask
+        for n in PARAMS:
+            setattr(self, "_" + n, getattr(self, "_" + n)[keep])
+        tail = self._scaling[:, 3:]
+        tail[tail > 0.05] = 0.05
+
 
 def _fixed_rands(monkeypatch, rands):
     import torch
@@ -107,6 +116,32 @@ def test_hip_matches_reference_golden(tag, hip_lib_built, monkeypatch):
             assert np.array_equal(got, c["out_" + n]), n
     for n in STATS:
         assert np.array_equal(getattr(m, n).cpu().numpy(), c["out_" + n]), n
+
+
+@pytest.mark.gpu
+def test_adjust_anchor_matches_reference_golden(hip_lib_built, monkeypatch):
+    """GaussianModel.adjust_anchor as a whole (:776-830) -- gradient norms from the accumulators (0 / 0 -> NaN -> 0), the growing, the
+    statistics' reset and padding, the prune masks, the pruned rows -- against the executed reference method (case `adj` of the fixture)."""
+    import torch
+    import anchor_growing as ag
+    c = load("adj")
+    c["N"], c["k"] = int(c["N"]), int(c["k"])
+    m = _Model(c)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for n in ("offset_gradient_accum", "offset_denom", "anchor_demon", "opacity_accum"):
+        setattr(m, n, t(c["in_" + n]))
+    _fixed_rands(monkeypatch, [c["rand%d" % i] for i in range(3)])
+    ag.adjust_anchor(m, check_interval=100, success_threshold=0.1, grad_threshold=float(c["threshold"]), min_opacity=0.005, flags=ag.EXACT_DIVISION)
+    for n in PARAMS:
+        got = getattr(m, "_" + n).cpu().numpy()
+        assert got.shape == c["out_" + n].shape, (n, got.shape, c["out_" + n].shape)
+        if n in ("scaling", "opacity"):
+            np.testing.assert_allclose(got, c["out_" + n], rtol=1e-6)
+        else:
+            assert np.array_equal(got, c["out_" + n]), n
+    for n in ("offset_gradient_accum", "offset_denom", "anchor_demon", "opacity_accum", "max_radii2D"):
+        got = getattr(m, n).cpu().numpy()
+        assert got.shape == c["out_" + n].shape and np.array_equal(got, c["out_" + n]), n
 
 
 def _big_case(N, k, seed, voxel=0.01):

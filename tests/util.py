@@ -125,7 +125,7 @@ def oracle_forward_backward(scene, W, H, grads=None, cov3D_precomp=None, far=80,
     return out
 
 
-def oracle_backward_exact_sums(ref, grads, surfel=False):
+def oracle_backward_exact_sums(ref, grads, surfel=False, mode=1):
     """The oracle's backward on the forward state of `ref` (what oracle_[surfel_]forward_backward returned) once more, with the
     per-Gaussian sums of the backward blend taken in float64 (lgo_set_accumulate_double / sfo_...: every term stays the float32 value
     the reference computes; its float atomics add them in scheduling order, R3/cr/backward.cu:702-788, this restatement in raster order --
@@ -134,7 +134,7 @@ def oracle_backward_exact_sums(ref, grads, surfel=False):
     from oracle import lgo, lgo_surfel
     L = lgo.lib()
     setter = L.sfo_set_accumulate_double if surfel else L.lgo_set_accumulate_double
-    setter(C.c_int(1))
+    setter(C.c_int(mode))      # 2 (diagnostic): the backward's T = T / (1 - alpha) chain in float64 as well
     try:
         return (lgo_surfel if surfel else lgo).backward(ref["fwd"], *grads)
     finally:

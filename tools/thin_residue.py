@@ -13,7 +13,7 @@ from util import (GRAD_KEYS_SR, GRAD_KEYS_SURFEL, envelope_residue, hip_forward_
                   oracle_envelope, oracle_forward_backward, oracle_surfel_envelope, oracle_surfel_forward_backward)
 
 
-def report(tag, hip, base, lo, hi, r64, keys, rows=None, inside=None):
+def report(tag, hip, base, lo, hi, r64, keys, rows=None, inside=None, r64t=None):
     for k in keys:
         h = hip[k] if rows is None else hip[k][rows]
         hh = {k: h if inside is None else h[inside]}
@@ -22,7 +22,8 @@ def report(tag, hip, base, lo, hi, r64, keys, rows=None, inside=None):
         r = np.asarray(sel(r64[k]), np.float64); b = np.asarray(sel(base[k]), np.float64); x = np.asarray(hh[k], np.float64)
         den = np.abs(r) + 1e-3 * np.abs(r).max() + 1e-30
         print(f"[{tag}] {k:14s} n={st['n']:7d} hip>1e-4 vs oracle: {st['hip_over']:5d} (in the band: {st['hip_over_where_oracle_moves_half']:5d}, band itself >1e-4: {st['oracle_band_over']:5d}, "
-              f"worst outside {st['worst_outside_anywhere']:.2f} widths) | vs exact sums: hip {int((np.abs(x - r) / den > 1e-4).sum()):5d}, oracle {int((np.abs(b - r) / den > 1e-4).sum()):5d}", flush=True)
+              f"worst outside {st['worst_outside_anywhere']:.2f} widths) | vs exact sums: hip {int((np.abs(x - r) / den > 1e-4).sum()):5d}, oracle {int((np.abs(b - r) / den > 1e-4).sum()):5d}"
+              + ("" if r64t is None else f" | vs exact sums + float64 T chain: hip {int((np.abs(x - np.asarray(sel(r64t[k]), np.float64)) / den > 1e-4).sum()):5d}, oracle {int((np.abs(b - np.asarray(sel(r64t[k]), np.float64)) / den > 1e-4).sum()):5d}"), flush=True)
 
 
 args = sys.argv[1:] or ["thin"]
@@ -48,14 +49,22 @@ for a in args:
     else:
         c = sc.sweep_case_any(int(a), mid=False)
         scene, W, H, grads, kw = c["scene"], c["W"], c["H"], c["grads"], c["kw"]
+        fast = os.environ.get("NO_ENVELOPE") == "1"                     # the plain oracle only (no seven-run band)
         if c["surfel"]:
             hip = hip_surfel_forward_backward(scene, W, H, grads, **kw)
-            base, lo, hi = oracle_surfel_envelope(scene, W, H, grads, kw, GRAD_KEYS_SURFEL)
             keys = GRAD_KEYS_SURFEL
+            if fast:
+                base = oracle_surfel_forward_backward(scene, W, H, grads, **kw); lo = hi = {k: np.asarray(base[k], np.float64) for k in keys}
+            else:
+                base, lo, hi = oracle_surfel_envelope(scene, W, H, grads, kw, GRAD_KEYS_SURFEL)
         else:
             hip = hip_forward_backward(scene, W, H, grads, cov3D_precomp=c["cov"], **kw)
             keys = GRAD_KEYS_SR if c["cov"] is None else ("dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dcov3D")
-            base, lo, hi = oracle_envelope(scene, W, H, grads, dict(kw, cov3D_precomp=c["cov"]), keys)
+            if fast:
+                base = oracle_forward_backward(scene, W, H, grads, cov3D_precomp=c["cov"], **kw); lo = hi = {k: np.asarray(base[k], np.float64) for k in keys}
+            else:
+                base, lo, hi = oracle_envelope(scene, W, H, grads, dict(kw, cov3D_precomp=c["cov"]), keys)
         r64 = oracle_backward_exact_sums(base, grads, surfel=c["surfel"])
+        r64t = oracle_backward_exact_sums(base, grads, surfel=c["surfel"], mode=2)
         print(c["desc"])
-        report(a, hip, base, lo, hi, r64, keys)
+        report(a, hip, base, lo, hi, r64, keys, r64t=r64t)
