@@ -243,13 +243,16 @@ void phase_clocks_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out,
 #else
 #define LG_PHASE_CLK(slot) do { } while (0)
 #endif
-template <int BITS, int ITEMS, typename KT = uint32_t>
+// AUX (round 6, the bucketed range sort's pass): a second 32-bit value per key travels with the pair -- aux_in[i] in input order,
+// aux_out at the pair's destination (the Gaussians' span records: the bucket launch then finds them beside the ids instead of gathering
+// 2 M random words of an 8-MB table, 128 MB of line traffic for 8 MB of data).
+template <int BITS, int ITEMS, typename KT = uint32_t, bool AUX = false>
 __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        KT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        size_t n, const uint32_t* __restrict__ n_dev, int shift, const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ tot, unsigned nblocks,
                                                        const uint32_t* __restrict__ part, unsigned chunk, unsigned chunks, const RadixTail tail,
-                                                       const KeyMap km) {
+                                                       const KeyMap km, const uint32_t* __restrict__ aux_in = nullptr, uint32_t* __restrict__ aux_out = nullptr) {
     constexpr int BINS = 1 << BITS;
     constexpr int CHUNK = 256 * ITEMS;                    // keys per block
     constexpr int PER = BINS > 256 ? BINS / 256 : 1;      // bins per thread in the block-wide scans (thread t owns bins [t*PER, t*PER+PER))
@@ -262,16 +265,18 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_key[CHUNK];
     __shared__ uint32_t s_val[CHUNK];
+    __shared__ uint32_t s_aux[AUX ? CHUNK : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const size_t blk_base = (size_t)blockIdx.x * CHUNK;
     const size_t base = blk_base + (size_t)w * (64 * ITEMS);
-    uint32_t k[ITEMS], v[ITEMS], pos[ITEMS];
+    uint32_t k[ITEMS], v[ITEMS], pos[ITEMS], ax[AUX ? ITEMS : 1];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const size_t i = base + (size_t)r * 64 + lane;
         const bool valid = i < n;
         k[r] = valid ? (uint32_t)keys_in[i] : 0u;
         v[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;    // vals_in == nullptr: the values are the positions (first pass of an id sort)
+        if constexpr (AUX) ax[r] = valid ? aux_in[i] : 0u;
     }
     // global digit bases: exclusive scan of the digit totals (every block repeats this tiny scan)
     {
@@ -369,6 +374,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
             const uint32_t d = key_digit<BINS>(km, lin, k[r], shift);
             const uint32_t p = run[w][d] + pos[r];
             s_key[p] = k[r]; s_val[p] = v[r];
+            if constexpr (AUX) s_aux[p] = ax[r];
         }
     }
     __syncthreads();
@@ -382,6 +388,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const KT* __restrict__ ke
             const uint32_t d = key_digit<BINS>(km, lin, kk, shift);
             const size_t g = (size_t)gbase[d] + (i - dbase[d]);
             keys_out[g] = (KT)kk; vals_out[g] = s_val[i];
+            if constexpr (AUX) aux_out[g] = s_aux[i];
         }
     } else {
         // last pass with a tail: the sorted keys are not written; the record of every value is gathered (all of a thread's gathers
@@ -444,6 +451,30 @@ static void radix_pass_items(const KT* kin, const uint32_t* vin, KT* kout, uint3
     if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
     hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS, KT>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, hist, tot, nb,
                        two_level ? part : (const uint32_t*)nullptr, chunk, chunks, tail, key_map(bias));
+}
+// the same pass with a second value per key (k_radix_scatter<..., AUX = true>); no tail
+template <int BITS, int ITEMS>
+static void radix_pass_items_aux(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const uint32_t* aux_in, uint32_t* aux_out, size_t n, int shift,
+                                 uint32_t* scratch, hipStream_t s, int scratch_bits, const KeyBias* bias) {
+    const size_t cap_bins = (size_t)1 << scratch_bits;
+    constexpr size_t CHUNK = 256 * ITEMS;
+    const unsigned nb = (unsigned)((n + CHUNK - 1) / CHUNK);
+    constexpr int BINS = 1 << BITS;
+    uint32_t* hist = scratch;
+    uint32_t* tot = scratch + cap_bins * sort_blocks(n);
+    uint32_t* part = tot + cap_bins;
+    const unsigned chunks_all = (nb + SORT_PREFIX_CHUNK - 1) / SORT_PREFIX_CHUNK;
+    const bool two_level = chunks_all > 2;
+    const unsigned chunk = two_level ? SORT_PREFIX_CHUNK : nb, chunks = two_level ? chunks_all : 1u;
+    hipLaunchKernelGGL((k_radix_hist<BITS, ITEMS, uint32_t>), dim3(nb), dim3(256), 0, s, kin, n, (const uint32_t*)nullptr, shift, hist, nb, key_map(bias));
+    const dim3 pgrid(BINS * chunks);
+    uint32_t* const pout = two_level ? part : tot;
+    if (chunk <= 8 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<2>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    else if (chunk <= 16 * 64) hipLaunchKernelGGL(k_radix_digit_prefix<4>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    else hipLaunchKernelGGL(k_radix_digit_prefix<8>, pgrid, dim3(256), 0, s, hist, nb, BINS, chunk, chunks, pout);
+    if (two_level) hipLaunchKernelGGL(k_radix_chunk_prefix, dim3((BINS + 3) / 4), dim3(256), 0, s, part, BINS, chunks, tot);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, ITEMS, uint32_t, true>), dim3(nb), dim3(256), 0, s, kin, vin, kout, vout, n, (const uint32_t*)nullptr, shift, hist, tot, nb,
+                       two_level ? part : (const uint32_t*)nullptr, chunk, chunks, RadixTail(), key_map(bias), aux_in, aux_out);
 }
 // ------------------------------------------------------------------------------------------------
 // Small inputs (<= SMALL_SORT_MAX pairs: small scenes, tests): the WHOLE multi-pass sort in ONE launch of one 1024-thread workgroup.
@@ -903,6 +934,150 @@ __global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_
     }
 }
 
+// Round 6: the same launch when the bucket pass carried the span records along (k_radix_scatter<AUX>): `aux` holds them beside the ids.
+// A bucket's pairs are sorted as ONE 32-bit word each, (key - bucket minimum) << 13 | position inside the bucket: half the LDS traffic and
+// registers of the (key, id) pairs, 37 KB of LDS instead of 66 (four workgroups per CU), stable by construction; the ids and span records
+// are then read through the sorted positions from the bucket's own 2 x 28-KB window (lines that are fetched once and used whole)
+// instead of gathering 2 M random words of the 8-MB span table by id (128 MB of line traffic, the old launch's length).
+// Buckets whose keys span more than 19 bits, or that do not fit (n > 7168), take the old path: sorted through global memory, spans by id.
+constexpr int BPK_IDX_BITS = 13;
+static_assert((1 << BPK_IDX_BITS) >= BSORT_CAP, "positions inside a bucket must fit the word's low bits");
+template <int BUCKET_BINS>
+__global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) k_bucket_sort_packed(uint32_t* keys, uint32_t* ids, const uint32_t* __restrict__ aux, uint32_t* key_tmp, uint32_t* id_tmp,
+                                                                         const uint32_t* __restrict__ tot, uint32_t* ids_out, uint32_t* span_out, const uint32_t* __restrict__ span_table,
+                                                                         const uint32_t P) {
+    constexpr int W = BSORT_WAVES, ITEMS = BSORT_ITEMS, BINS = 256;
+    if (blockIdx.x >= (unsigned)(BUCKET_BINS - 1)) {                   // the culled Gaussians: as k_bucket_sort
+        const uint32_t nc = tot[BUCKET_BINS - 1], first = P - nc;
+        const uint32_t lo = (blockIdx.x - (unsigned)(BUCKET_BINS - 1)) * BSORT_CULL_SLICE, hi = min(nc, lo + BSORT_CULL_SLICE);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 64 * W) { ids_out[first + i] = ids[first + i]; span_out[first + i] = 0xFFFFFFFFu; }
+        return;
+    }
+    __shared__ uint32_t s_w[BSORT_CAP];
+    __shared__ uint32_t cnt[BINS][W + 1];
+    __shared__ uint32_t wsum[W];
+    __shared__ uint32_t s_red[3][W];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned d = blockIdx.x;
+    const uint32_t n = tot[d];
+    if (n == 0) return;
+    uint32_t part = 0u;
+    for (unsigned j = (unsigned)tid; j < d; j += 64 * W) part += tot[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const bool fits = n <= (uint32_t)BSORT_CAP;
+    const uint32_t per = ((n + W - 1) / W + 63u) & ~63u;
+    const uint32_t lo = min(n, (uint32_t)w * per), hi = min(n, lo + per);
+    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+    if (lane == 0) s_red[0][w] = part;
+    __syncthreads();
+    uint32_t start = 0;
+#pragma unroll
+    for (int q = 0; q < W; q++) start += s_red[0][q];
+    uint32_t k[ITEMS];
+    if (fits) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t i = lo + (uint32_t)r * 64u + lane;
+            k[r] = keys[start + (i < n ? i : n - 1u)];
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            if (lo + (uint32_t)r * 64u + lane < hi) { kmn = min(kmn, k[r]); kmx = max(kmx, k[r]); }
+            else k[r] = 0u;
+        }
+    } else {
+        for (uint32_t i = tid; i < n; i += 64 * W) { const uint32_t kk = keys[start + i]; kmn = min(kmn, kk); kmx = max(kmx, kk); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, o)); kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, o)); }
+    if (lane == 0) { s_red[1][w] = kmn; s_red[2][w] = kmx; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < W; q++) { kmn = min(kmn, s_red[1][q]); kmx = max(kmx, s_red[2][q]); }
+    const uint32_t span = kmx - kmn;
+    const int bits = span ? 32 - __builtin_clz(span) : 0;
+    if (bits > 0 && (!fits || bits + BPK_IDX_BITS > 32)) {
+        // the old path: the pairs sorted through global memory by this workgroup, the span records gathered by id
+        bucket_sort_slow(keys + start, key_tmp + start, ids + start, id_tmp + start, n, bits, kmn, cnt, wsum);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t i = tid; i < n; i += 64 * W) { const uint32_t g = ids[start + i]; ids_out[start + i] = g; span_out[start + i] = span_table[g]; }
+        return;
+    }
+    if (bits > 0) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        // the words: (key - kmn) << 13 | position; every pass below is a stable counting pass on 8 (or fewer) bits of the key part
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t i = lo + (uint32_t)r * 64u + lane;
+            k[r] = i < hi ? (((k[r] - kmn) << BPK_IDX_BITS) | i) : 0u;
+        }
+        const int passes = (bits + 7) / 8;
+        int shift = BPK_IDX_BITS;
+        for (int pass = 0; pass < passes; pass++) {
+            const int left = bits + BPK_IDX_BITS - shift, pl = passes - pass;
+            const int pb = (left + pl - 1) / pl;
+            const uint32_t mask = (1u << pb) - 1u;
+            for (int i = tid; i < BINS * (W + 1); i += 64 * W) (&cnt[0][0])[i] = 0u;
+            __syncthreads();
+            uint32_t pos[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                if ((uint32_t)r * 64u >= per) break;
+                const bool valid = lo + (uint32_t)r * 64u + lane < hi;
+                const uint32_t dg = valid ? (k[r] >> shift) & mask : 0u;
+                const unsigned long long peers = small_sort_peers(dg, valid);
+                const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                pos[r] = valid ? cnt[dg][w] + rank : 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (valid && rank == 0) cnt[dg][w] += (uint32_t)__popcll(peers);
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            {
+                constexpr int PER = BINS * W / (64 * W);
+                uint32_t c[PER], tsum = 0;
+#pragma unroll
+                for (int q = 0; q < PER; q++) { const int cell = tid * PER + q; c[q] = cnt[cell / W][cell % W]; tsum += c[q]; }
+                const uint32_t inc = wave_incl_scan(tsum, lane);
+                if (lane == 63) wsum[w] = inc;
+                __syncthreads();
+                uint32_t off = inc - tsum;
+                for (int q = 0; q < w; q++) off += wsum[q];
+#pragma unroll
+                for (int q = 0; q < PER; q++) { const int cell = tid * PER + q; cnt[cell / W][cell % W] = off; off += c[q]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                if ((uint32_t)r * 64u >= per) break;
+                if (lo + (uint32_t)r * 64u + lane < hi) s_w[cnt[(k[r] >> shift) & mask][w] + pos[r]] = k[r];
+            }
+            __syncthreads();
+            shift += pb;
+            if (pass + 1 < passes) {
+#pragma unroll
+                for (int r = 0; r < ITEMS; r++) {
+                    if ((uint32_t)r * 64u >= per) break;
+                    const uint32_t i = lo + (uint32_t)r * 64u + lane;
+                    if (i < hi) k[r] = s_w[i];
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // the ids and span records through the sorted positions (bits == 0: every key equal, the input order stands)
+    for (uint32_t i0 = tid; i0 < n; i0 += 4 * 64 * W) {
+        uint32_t li[4], g[4], x[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t i = min(i0 + (uint32_t)q * 64u * W, n - 1u); li[q] = bits > 0 ? (s_w[i] & ((1u << BPK_IDX_BITS) - 1u)) : i; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { g[q] = ids[start + li[q]]; x[q] = aux[start + li[q]]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t i = i0 + (uint32_t)q * 64u * W; if (i < n) { ids_out[start + i] = g[q]; span_out[start + i] = x[q]; } }
+    }
+}
+
 // LIDARGS_RANGE_SORT_BUCKETS=0: the LSD passes again (A/B, tests).  LIDARGS_RANGE_SORT_BUCKET_BITS=11: the 2048-interval form at any size
 // (tests: the oracle cannot run frames above 4 M Gaussians; read per call, the suite switches it inside one process).
 static int forced_bucket_bits() { const char* e = getenv("LIDARGS_RANGE_SORT_BUCKET_BITS"); const int v = e ? atoi(e) : 0; return (v == BUCKET_BITS || v == BUCKET_BITS_BIG) ? v : 0; }
@@ -917,11 +1092,21 @@ bool range_sort_buckets_ok(size_t P) {
 // pairs; `scratch` as for launch_radix_sort_pairs with scratch_bits = SORT_MAX_RADIX_BITS.  key_span: GeomView totals + LG_TOTALS_KEYSPAN_WORD.
 template <int BB>
 static void range_sort_buckets_t(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a, uint32_t* id_b, size_t P, uint32_t* scratch, const KeyBias* kb, RadixTail tail, hipStream_t s) {
+    const uint32_t* tot = scratch + ((size_t)1 << SORT_MAX_RADIX_BITS) * sort_blocks(P);       // where the pass leaves the digit totals (radix_pass_items)
+    const unsigned cull_blocks = (unsigned)((P + BSORT_CULL_SLICE - 1) / BSORT_CULL_SLICE);     // (as many as a frame of culled Gaussians only would need: the others leave at once)
+    static const bool packed_on = [] { const char* e = getenv("LIDARGS_RANGE_SORT_PACKED"); return !e || atoi(e) != 0; }();   // 0: round 5's form (A/B)
+    if (tail.mode == 1 && packed_on) {
+        // 4-byte span records: they ride along with the pairs (the second half of the span_sorted allocation -- u32x2[P], of which the
+        // compact form uses the first P words -- holds them between the two launches)
+        uint32_t* aux_b = static_cast<uint32_t*>(tail.dst) + P;
+        radix_pass_items_aux<BB, SORT_ITEMS>(key_a, nullptr, key_b, id_b, static_cast<const uint32_t*>(tail.src), aux_b, P, 0, scratch, s, SORT_MAX_RADIX_BITS, kb);
+        hipLaunchKernelGGL(k_bucket_sort_packed<(1 << BB)>, dim3((1 << BB) - 1 + cull_blocks), dim3(64 * BSORT_WAVES), 0, s, key_b, id_b, aux_b, key_a, id_a, tot, id_a,
+                           static_cast<uint32_t*>(tail.dst), static_cast<const uint32_t*>(tail.src), (uint32_t)P);
+        return;
+    }
     // (4096-key blocks: with 1024 digits a block's digit runs are 4 keys long, 2 in a half-size block -- every pair a write of its own:
     //  scatter 36.3 -> 28.7 us, histogram 12.7 -> 10.2 us at 2 M keys)
     radix_pass_items<BB, SORT_ITEMS, uint32_t>(key_a, nullptr, key_b, id_b, P, nullptr, 0, scratch, s, SORT_MAX_RADIX_BITS, RadixTail(), kb);
-    const uint32_t* tot = scratch + ((size_t)1 << SORT_MAX_RADIX_BITS) * sort_blocks(P);       // where the pass left the digit totals (radix_pass_items)
-    const unsigned cull_blocks = (unsigned)((P + BSORT_CULL_SLICE - 1) / BSORT_CULL_SLICE);     // (as many as a frame of culled Gaussians only would need: the others leave at once)
     hipLaunchKernelGGL(k_bucket_sort<(1 << BB)>, dim3((1 << BB) - 1 + cull_blocks), dim3(64 * BSORT_WAVES), 0, s, key_b, id_b, key_a, id_a, tot, id_a, tail, (uint32_t)P);
 }
 void launch_range_sort_buckets(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a, uint32_t* id_b, size_t P, uint32_t* scratch, const uint32_t* key_span,
