@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(64 * BSORT_WAVES) __attribute__((amdgpu_waves_
 }
 
 // LIDARGS_RANGE_SORT_BUCKETS=0: the LSD passes again (A/B, tests).  LIDARGS_RANGE_SORT_BUCKET_BITS=11: the 2048-interval form at any size
-// (tests: the oracle cannot run frames above 4 M Gaussians; read per call, the suite switches it inside one process).
+// (tests: the CPU checker cannot run frames above 4 M Gaussians; read per call, the suite switches it inside one process).
 static int forced_bucket_bits() { const char* e = getenv("LIDARGS_RANGE_SORT_BUCKET_BITS"); const int v = e ? atoi(e) : 0; return (v == BUCKET_BITS || v == BUCKET_BITS_BIG) ? v : 0; }
 bool range_sort_buckets_ok(size_t P) {
     static const bool on = [] { const char* e = getenv("LIDARGS_RANGE_SORT_BUCKETS"); return !e || atoi(e) != 0; }();
