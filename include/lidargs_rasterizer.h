@@ -343,6 +343,24 @@ int lidargs_wedge_select_enqueue(int P, const float* means3D, const float* color
                                  float* out_opacities, float* out_scales, float* out_rotations, unsigned* n_valid_dev,
                                  unsigned* status_host, char* scratch, size_t scratch_bytes, int chunk_rows, int world,
                                  float* chunk_counts, void* stream);
+/* Round 6 (experiment, not what lidargs_dist uses by default: measured no faster): the selection of an ORDINARY frame in ONE launch (test, scan
+ * in index order by decoupled look-back over the blocks, gather -- k_select_fused) instead of flags + a three-launch scan + gather: the caller passes `capacity`-row arrays (capacity = P is always enough),
+ * the call makes the one host read the two-step form makes as well and returns the rows gathered M; the first M rows are the selection,
+ * ascending by index, bit-identical to the two-step form's. */
+int lidargs_shell_select_sync(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                              const float* rotations, const float* viewmatrix, float shell_lo, float shell_hi, int capacity, int* idx_out,
+                              float* out_means3D, float* out_colors, float* out_opacities, float* out_scales, float* out_rotations,
+                              unsigned* n_valid_dev, char* scratch, size_t scratch_bytes, int chunk_rows, int world, float* chunk_counts,
+                              void* stream);
+int lidargs_wedge_select_sync(int P, const float* means3D, const float* colors, const float* opacities, const float* scales,
+                              const float* rotations, float scale_modifier, const float* viewmatrix, int width, int col_lo, int col_hi,
+                              int capacity, int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
+                              float* out_rotations, unsigned* n_valid_dev, char* scratch, size_t scratch_bytes, int chunk_rows, int world,
+                              float* chunk_counts, void* stream);
+/* Round 6, gradient mode "shard" of lidargs_dist: the [n, 18] gradient rows a rank received for its own index chunk
+ * [base, base + chunk_rows) unpacked into dense f32[17][chunk_rows] (six contiguous blocks: means3D 3, means2D 4, colours 2, opacity 1, scales 3,
+ * rotations 4 columns of chunk_rows rows each; zero-filled here); add != 0 adds rows of equal index (column wedges). */
+int lidargs_shell_unpack_grad_rows_chunk(int n, const float* rows, int base, int chunk_rows, float* dense, int add, void* stream);
 int lidargs_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, void* stream);
 int lidargs_shell_compose(int G, int rank, int N, const float* planes, const float* background, float* out_color,
                           float* out_depth, float* out_occ, float* T_final, float* behind, void* stream);

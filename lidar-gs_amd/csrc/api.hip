@@ -1168,6 +1168,83 @@ int lidargs_wedge_select_enqueue(int P, const float* means3D, const float* color
                                 out_scales, out_rotations, n_valid_dev, status_host, flags, offs, total, chunk_rows, world, chunk_counts, stream);
 }
 
+namespace {
+// the one-launch selection (preprocess.hip k_select_fused) into `capacity` rows; fill_tail: idx_out's tail = 0x7F7F7F7F (enqueue-only frames:
+// the array stays ascending and every consumer skips indices >= P); wait: read the two counts back and return the rows gathered
+int select_fused(bool wedge, lg::SelArgs a, int capacity, unsigned* n_valid_dev, unsigned* status_host, char* scratch, size_t scratch_bytes,
+                 bool fill_tail, bool wait, hipStream_t stream) {
+    if (a.chunk_counts && (a.chunk_rows <= 0 || a.world <= 0 || a.world > 256)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "select: chunk counts need chunk_rows > 0 and 1 <= world <= 256%s");
+    if (scratch_bytes < lidargs_shell_select_scratch_bytes(a.P)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "select: scratch too small%s");
+    lg::Carver c(scratch);
+    const size_t words = lg::select_fused_words((size_t)a.P);
+    uint32_t* z = c.take<uint32_t>(words + 2);
+    a.ticket = z; a.status = reinterpret_cast<unsigned long long*>(z + 2);       // (128-byte aligned base: the 64-bit words are 8-byte aligned)
+    a.cap = (uint32_t)capacity; a.n_valid_out = n_valid_dev;
+    LG_HIP(hipMemsetAsync(z, 0, sizeof(uint32_t) * (words + 2), stream));
+    if (fill_tail) LG_HIP(hipMemsetAsync(a.idx_out, 0x7F, sizeof(int) * (size_t)capacity, stream));
+    if (a.chunk_counts) LG_HIP(hipMemsetAsync(a.chunk_counts, 0, sizeof(float) * (size_t)a.world, stream));
+    lg::launch_select_fused(a, wedge, stream);
+    if (status_host) LG_HIP(hipMemcpyAsync(status_host, n_valid_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    const int rc = check_launch(stream, 0, "select (one launch)");
+    if (rc || !wait) return rc;
+    uint32_t h[2] = {0, 0};
+    LG_HIP((hipError_t)lg::api_read_words_zero_behind(n_valid_dev, 2, h, nullptr, 0, stream));
+    return (int)h[0];
+}
+lg::SelArgs sel_args(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations, const float* viewmatrix,
+                     int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales, float* out_rotations, int chunk_rows, int world,
+                     float* chunk_counts) {
+    lg::SelArgs a = lg::SelArgs();
+    a.P = P; a.means = means3D; a.colors = colors; a.opac = opacities; a.scales = scales; a.rot = rotations; a.vm = viewmatrix;
+    a.idx_out = idx_out; a.o_means = out_means3D; a.o_colors = out_colors; a.o_opac = out_opacities; a.o_scales = out_scales; a.o_rot = out_rotations;
+    a.chunk_rows = chunk_rows; a.world = world; a.chunk_counts = chunk_counts;
+    return a;
+}
+void sel_wedge(lg::SelArgs& a, float scale_modifier, int width, int col_lo, int col_hi) {
+    const float pi_f = 3.14159265358979323846f, step = 2 * pi_f / (float)width;       // as launch_wedge_flags
+    a.mod = scale_modifier; a.inv_col_step = 1.f / step; a.inv_tan_step = 1.f / tanf(step); a.col_lo = (float)col_lo; a.col_hi = (float)col_hi;
+}
+}  // namespace
+
+// Round 6 experiment (round-5 verdict item 4a), NOT the default: the selection of an ordinary frame in ONE launch (k_select_fused: test, scan in
+// index order by decoupled look-back over the blocks, gather) into `capacity` rows (the caller passes P-row arrays), then the one host read the
+// two-step form makes as well; returns the rows gathered M.  Bit-identical to the two-step form (tests/test_dist_gpu.py) and no faster:
+// 215-247 us against 88 + 38 + 78 us at 8 M Gaussians (EXPERIMENTS.md).
+int lidargs_shell_select_sync(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
+                              const float* viewmatrix, float shell_lo, float shell_hi, int capacity, int* idx_out, float* out_means3D, float* out_colors,
+                              float* out_opacities, float* out_scales, float* out_rotations, unsigned* n_valid_dev, char* scratch, size_t scratch_bytes,
+                              int chunk_rows, int world, float* chunk_counts, void* stream_) {
+    if (P < 0 || capacity < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select_sync: bad sizes%s");
+    if (P == 0 || capacity == 0) {
+        if (chunk_counts && world > 0) LG_HIP(hipMemsetAsync(chunk_counts, 0, sizeof(float) * (size_t)world, (hipStream_t)stream_));
+        return 0;
+    }
+    if (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !idx_out || !out_means3D || !out_colors || !out_opacities ||
+        !out_scales || !out_rotations || !n_valid_dev || !scratch)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_select_sync: NULL pointer%s");
+    lg::SelArgs a = sel_args(P, means3D, colors, opacities, scales, rotations, viewmatrix, idx_out, out_means3D, out_colors, out_opacities, out_scales, out_rotations,
+                             chunk_rows, world, chunk_counts);
+    a.lo = shell_lo; a.hi = shell_hi;
+    return select_fused(false, a, capacity, n_valid_dev, nullptr, scratch, scratch_bytes, false, true, (hipStream_t)stream_);
+}
+int lidargs_wedge_select_sync(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
+                              float scale_modifier, const float* viewmatrix, int width, int col_lo, int col_hi, int capacity, int* idx_out, float* out_means3D,
+                              float* out_colors, float* out_opacities, float* out_scales, float* out_rotations, unsigned* n_valid_dev, char* scratch,
+                              size_t scratch_bytes, int chunk_rows, int world, float* chunk_counts, void* stream_) {
+    if (P < 0 || capacity < 0 || width <= 0 || col_lo < 0 || col_hi <= col_lo) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select_sync: bad sizes%s");
+    if (P == 0 || capacity == 0) {
+        if (chunk_counts && world > 0) LG_HIP(hipMemsetAsync(chunk_counts, 0, sizeof(float) * (size_t)world, (hipStream_t)stream_));
+        return 0;
+    }
+    if (!means3D || !colors || !opacities || !scales || !rotations || !viewmatrix || !idx_out || !out_means3D || !out_colors || !out_opacities ||
+        !out_scales || !out_rotations || !n_valid_dev || !scratch)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "wedge_select_sync: NULL pointer%s");
+    lg::SelArgs a = sel_args(P, means3D, colors, opacities, scales, rotations, viewmatrix, idx_out, out_means3D, out_colors, out_opacities, out_scales, out_rotations,
+                             chunk_rows, world, chunk_counts);
+    sel_wedge(a, scale_modifier, width, col_lo, col_hi);
+    return select_fused(true, a, capacity, n_valid_dev, nullptr, scratch, scratch_bytes, false, true, (hipStream_t)stream_);
+}
+
 // both steps in one call, into P-row arrays
 int lidargs_shell_select(int P, const float* means3D, const float* colors, const float* opacities, const float* scales, const float* rotations,
                          const float* viewmatrix, float shell_lo, float shell_hi, int* idx_out, float* out_means3D, float* out_colors,
@@ -1195,6 +1272,20 @@ int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense
     LG_HIP(hipMemsetAsync(dense, 0, sizeof(float) * 17 * (size_t)P, (hipStream_t)stream));
     if (n) lg::launch_shell_unpack_rows(n, rows, P, dense, blocked, (hipStream_t)stream);
     return check_launch((hipStream_t)stream, 0, "shell unpack rows");
+}
+// Round 6, gradient mode "shard": the rows a rank received for its OWN index chunk [base, base + chunk_rows), unpacked into a
+// [17][chunk_rows] block (six contiguous gradient blocks of chunk_rows rows each) -- no dense [P, 17] block is zero-filled or scattered into
+// (544 MB + 20 M scattered words per frame at 8 M Gaussians).  add != 0: rows of equal index are added (column wedges).
+int lidargs_shell_unpack_grad_rows_chunk(int n, const float* rows, int base, int chunk_rows, float* dense, int add, void* stream) {
+    if (n < 0 || base < 0 || chunk_rows < 0) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_unpack_grad_rows_chunk: bad sizes%s");
+    if (chunk_rows == 0) return 0;
+    if (!dense || (n > 0 && !rows)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_unpack_grad_rows_chunk: NULL pointer%s");
+    LG_HIP(hipMemsetAsync(dense, 0, sizeof(float) * 17 * (size_t)chunk_rows, (hipStream_t)stream));
+    if (n) {
+        if (add) lg::launch_shell_unpack_rows_add(n, rows, chunk_rows, dense, (hipStream_t)stream, base);
+        else lg::launch_shell_unpack_rows(n, rows, chunk_rows, dense, 1, (hipStream_t)stream, base);
+    }
+    return check_launch((hipStream_t)stream, 0, "shell unpack rows (chunk)");
 }
 int lidargs_shell_chunk_counts(int M, const int* idx, int chunk_rows, int world, float* counts, void* stream) {
     if (M < 0 || chunk_rows <= 0 || world <= 0 || !counts || (M > 0 && !idx)) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_chunk_counts: bad arguments%s");

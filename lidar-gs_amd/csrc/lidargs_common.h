@@ -354,7 +354,7 @@ void launch_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, i
 
 void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const float* g_col, const float* g_op, const float* g_sc,
                             const float* g_rot, const int* idx, float* rows, hipStream_t s);
-void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s);
+void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s, int base = 0);
 void launch_shell_chunk_counts(int M, const int* idx, int chunk, int world, float* counts, hipStream_t s);
 void launch_shell_scatter_i32(int M, const int* idx, const int* src, int P, int* dst, hipStream_t s);
 void launch_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, hipStream_t s);
@@ -363,10 +363,24 @@ void launch_shell_compose(int G, int rank, int N, const float* planes, const flo
 void launch_wedge_pack_columns(int H, int W, int c0, int c1, int wmax, const float* color, const float* depth, const float* occ, float* out, hipStream_t s);
 void launch_wedge_unpack_columns(int G, int H, int W, int wmax, size_t stride, const int* edges, const float* blocks, float* color, float* depth,
                                  float* occ, hipStream_t s);
+// the one-launch selection of a rank's Gaussians (preprocess.hip k_select_fused, round 6)
+#define SEL_ITEMS 4
+#define SEL_BLOCK (256 * SEL_ITEMS)
+struct SelArgs {
+    int P; const float* means; const float* colors; const float* opac; const float* scales; const float* rot; const float* vm;
+    float lo, hi;                                                      // shell: range in [lo, hi)
+    float mod, inv_col_step, inv_tan_step, col_lo, col_hi;             // wedge: the reach bound of k_wedge_flags
+    uint32_t cap; int* idx_out; float* o_means; float* o_colors; float* o_opac; float* o_scales; float* o_rot;
+    uint32_t* n_valid_out; int chunk_rows, world; float* chunk_counts;
+    unsigned long long* status; uint32_t* ticket;                      // [blocks] (flag << 32 | value), [2]: ticket, finished blocks -- zeroed by the caller
+    unsigned blocks;
+};
+inline size_t select_fused_words(size_t P) { return 2 * ((P + SEL_BLOCK - 1) / SEL_BLOCK) + 8; }      // u32 words of zeroed scratch: status (u64 per block) + ticket + finished
+void launch_select_fused(SelArgs a, bool wedge, hipStream_t s);
 void launch_shell_flags(int P, const float* means3D, const float* view, float lo, float hi, uint32_t* flags, hipStream_t s);
 void launch_wedge_flags(int P, const float* means3D, const float* scales, const float* rotations, float scale_modifier, const float* view,
                         int W, int col_lo, int col_hi, uint32_t* flags, hipStream_t s);
-void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s);
+void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s, int base = 0);
 void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, const float* means3D, const float* colors, const float* opacities,
                          const float* scales, const float* rotations, int* idx_out, float* o_means, float* o_colors, float* o_opac,
                          float* o_scales, float* o_rot, hipStream_t s, uint32_t cap = 0xFFFFFFFFu, const uint32_t* total = nullptr,

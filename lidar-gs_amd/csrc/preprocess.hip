@@ -790,6 +790,168 @@ void launch_shell_gather(int P, const uint32_t* flags, const uint32_t* offs, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 6: the selection in ONE launch (round-5 verdict item 4a).  flags -> scan (three launches over P) -> gather read every replicated
+// Gaussian's position twice and wrote / read 8 bytes of flags and offsets per Gaussian in between: 238 us of an 8 M-Gaussian wedge rank's
+// 0.90-ms frame.  Here a block tests 1024 consecutive Gaussians, scans its flags in index order (the selection stays ascending: equal
+// ranges break ties by index), learns the rows in front of it by decoupled look-back over the blocks before it (each block publishes its
+// count, then its inclusive prefix, in one 64-bit word; blocks take their number from a ticket so that a block only ever waits for blocks
+// that are already running), and writes the selected rows itself.  The block that finishes last writes the row counts and the gradient
+// all-to-all's split sizes (lower bounds on the ascending index array it can now read).
+template <bool WEDGE>
+__global__ void __launch_bounds__(256) k_select_fused(const SelArgs a) {
+    __shared__ uint32_t s_bid, s_cnt[SEL_ITEMS][4], s_base, s_total;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_bid = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const unsigned b = s_bid;
+    const size_t base = (size_t)b * SEL_BLOCK;
+    const float* __restrict__ vm = a.vm;
+    bool f[SEL_ITEMS];
+    float3 pw[SEL_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SEL_ITEMS; j++) {
+        const size_t idx = base + (size_t)j * 256 + tid;
+        f[j] = false; pw[j] = f3(0.f, 0.f, 0.f);
+        if (idx < (size_t)a.P) {
+            pw[j] = f3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+            const float3 p = f3(vm[0] * pw[j].x + vm[4] * pw[j].y + vm[8] * pw[j].z + vm[12],
+                                vm[1] * pw[j].x + vm[5] * pw[j].y + vm[9] * pw[j].z + vm[13],
+                                vm[2] * pw[j].x + vm[6] * pw[j].y + vm[10] * pw[j].z + vm[14]);
+            if (!WEDGE) {
+                const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);      // k_shell_flags' expression (and k_preprocess's)
+                f[j] = dist >= a.lo && dist < a.hi;
+            } else {                                                                // k_wedge_flags' bound
+                const float d2 = p.x * p.x + p.y * p.y + p.z * p.z;
+                const float smax = a.mod * fmaxf(fabsf(a.scales[3 * idx]), fmaxf(fabsf(a.scales[3 * idx + 1]), fabsf(a.scales[3 * idx + 2])));
+                const float4 q = reinterpret_cast<const float4*>(a.rot)[idx];
+                const float nq = fmaxf(1.f, q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+                const float A = (smax * smax * nq * nq * 1.0001f + 0.01f) / fmaxf(d2, 1e-12f);
+                const float rx = 3.f * sqrtf(2.f * A + 3.2e-5f) * a.inv_tan_step * 1.001f + 1.f;
+                const float pi_f = 3.14159265358979323846f;
+                const float p_c = (pi_f - atan2f(p.y, p.x)) * a.inv_col_step;
+                const float reach = rx + 18.f;
+                f[j] = p_c + reach >= a.col_lo && p_c - reach < a.col_hi && d2 > 0.f;
+            }
+        }
+    }
+    // flags in index order inside the block: item-major (item j covers indices base + 256 j ..), then wave, then lane
+    uint32_t within[SEL_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SEL_ITEMS; j++) {
+        const unsigned long long m = __ballot(f[j]);
+        within[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[j][w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    // exclusive offsets of the 4 x SEL_ITEMS (item, wave) cells, in index order, by the first wave (one cell per lane: SEL_ITEMS * 4 <= 64)
+    static_assert(SEL_ITEMS * 4 <= 64, "one cell per lane");
+    if (w == 0) {
+        const uint32_t c = lane < SEL_ITEMS * 4 ? (&s_cnt[0][0])[lane] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane < SEL_ITEMS * 4) (&s_cnt[0][0])[lane] = incl - c;
+        if (lane == 63) s_total = incl;
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    uint32_t off[SEL_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SEL_ITEMS; j++) off[j] = s_cnt[j][w];
+    if (w == 0) {
+        // decoupled look-back by one WAVE: lane l reads the word of block p - l; the nearest block that already knows its inclusive prefix ends
+        // the walk, the aggregates of the blocks in front of it are added.  (One thread walking word by word waited a full memory round trip
+        // per predecessor: 8 k blocks looked back one after the other -- 5 ms for a 0.2-ms job.)
+        uint32_t excl = 0;
+        if (b > 0) {
+            if (lane == 0) __hip_atomic_store(a.status + b, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long p = (long long)b - 1;                            // the nearest block not yet accounted for
+            for (;;) {
+                const long long mine = p - lane;
+                unsigned long long v = 2ull << 32;                    // in front of block 0: an inclusive prefix of 0
+                if (mine >= 0) v = __hip_atomic_load(a.status + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long empty = __ballot((v >> 32) == 0ull);
+                const unsigned long long pref = __ballot((v >> 32) == 2ull);
+                // usable lanes: those nearer than the first empty one; among them the nearest prefix ends the walk
+                const int first_empty = empty ? __builtin_ctzll(empty) : 64;
+                const int first_pref = pref ? __builtin_ctzll(pref) : 64;
+                const int upto = first_pref < first_empty ? first_pref + 1 : first_empty;      // lanes [0, upto) are added
+                uint32_t add = lane < upto ? (uint32_t)v : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) add += __shfl_xor(add, o);
+                excl += add;
+                if (first_pref < first_empty) break;
+                p -= upto;
+                if (upto == 0) __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(a.status + b, (2ull << 32) | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = excl;
+        }
+    }
+    __syncthreads();
+    const uint32_t blk = s_base;
+#pragma unroll
+    for (int j = 0; j < SEL_ITEMS; j++) {
+        if (!f[j]) continue;
+        const size_t idx = base + (size_t)j * 256 + tid;
+        const size_t c = (size_t)blk + off[j] + within[j];
+        if (c >= (size_t)a.cap) continue;
+        a.idx_out[c] = (int)idx;
+        a.o_means[3 * c] = pw[j].x; a.o_means[3 * c + 1] = pw[j].y; a.o_means[3 * c + 2] = pw[j].z;
+        for (int k = 0; k < 3; k++) a.o_scales[3 * c + k] = a.scales[3 * idx + k];
+        reinterpret_cast<float2*>(a.o_colors)[c] = reinterpret_cast<const float2*>(a.colors)[idx];
+        a.o_opac[c] = a.opac[idx];
+        reinterpret_cast<float4*>(a.o_rot)[c] = reinterpret_cast<const float4*>(a.rot)[idx];
+    }
+    // Row counts and the gradient all-to-all's split sizes, without reading another block's rows (no fence anywhere in this launch: a
+    // word of the look-back carries its own data, relaxed 64-bit atomics suffice -- with release / acquire every block wrote the L2 back
+    // and the 8 k blocks of an 8 M-Gaussian frame went through one after the other, 2.2 ms).  counts[d] = before((d + 1) chunk) - before(d chunk)
+    // with before(i) = selected rows with index < i, clamped at the capacity: the block that holds index i adds +before(i) to counts[d - 1]
+    // and -before(i) to counts[d] (float atomics on integers < 2^24: exact, any order; zeroed by the caller); the block that holds the last
+    // index adds the total.
+    const bool last_block = base + SEL_BLOCK >= (size_t)a.P;
+    if (a.chunk_counts) {
+        for (int d = 1; d < a.world; d++) {
+            const long long i_d = (long long)d * a.chunk_rows;
+            if (i_d < (long long)base || i_d >= (long long)base + SEL_BLOCK || i_d >= (long long)a.P) continue;     // (block-uniform)
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < SEL_ITEMS; j++) c += (f[j] && (long long)(base + (size_t)j * 256 + tid) < i_d) ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            __syncthreads();
+            if (lane == 0) s_cnt[0][w] = c;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t v = blk + s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+                v = v < a.cap ? v : a.cap;
+                atomicAdd(a.chunk_counts + d - 1, (float)v); atomicAdd(a.chunk_counts + d, -(float)v);
+            }
+        }
+    }
+    if (last_block && tid == 0) {
+        const uint32_t t = blk + total, n = t < a.cap ? t : a.cap;
+        if (a.n_valid_out) { a.n_valid_out[0] = n; a.n_valid_out[1] = t; }
+        if (a.chunk_counts) {
+            // boundaries at or behind P see every selected row in front of them
+            for (int d = 1; d <= a.world; d++) {
+                const long long i_d = (long long)d * a.chunk_rows;
+                if (d < a.world && i_d < (long long)a.P) continue;
+                atomicAdd(a.chunk_counts + d - 1, (float)n);
+                if (d < a.world) atomicAdd(a.chunk_counts + d, -(float)n);
+            }
+        }
+    }
+}
+void launch_select_fused(SelArgs a, bool wedge, hipStream_t s) {
+    a.blocks = (unsigned)(((size_t)a.P + SEL_BLOCK - 1) / SEL_BLOCK);
+    if (wedge) hipLaunchKernelGGL(k_select_fused<true>, dim3(a.blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_select_fused<false>, dim3(a.blocks), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gradient rows of a range shell (lidargs_dist step 6): the six returned gradients of the shell's M Gaussians + their global
 // index as one [M, 18] row block (what the all-to-all ships), and back: rows scattered by index into a dense [P, 17] block.
 // One launch each instead of a concatenate, casts, an index_copy and their temporaries.
@@ -812,11 +974,12 @@ __global__ void __launch_bounds__(256) k_shell_pack_rows(int M, const float* __r
     r[17] = __int_as_float(idx[i]);                                    // the index travels as a bit pattern
 }
 // blocked != 0: dense is six contiguous blocks [P,3][P,4][P,2][P,1][P,3][P,4] (what autograd takes without a strided copy each)
-__global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* __restrict__ rows, int P, float* __restrict__ dense, int blocked) {
+// base (round 6, the "shard" gradient mode): `dense` holds the rows [base, base + P) of the index space only -- a rank's own chunk
+__global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* __restrict__ rows, int P, float* __restrict__ dense, int blocked, int base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rows + 18 * (size_t)i;
-    const int g = __float_as_int(r[17]);
+    const int g = __float_as_int(r[17]) - base;
     if (g < 0 || g >= P) return;
     if (!blocked) {
         float* d = dense + 17 * (size_t)g;
@@ -834,11 +997,11 @@ __global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* _
 }
 // Column wedges: a Gaussian whose rect straddles a wedge boundary has gradient rows on two (or more) ranks; the owner ADDS them.
 // dense = six contiguous blocks (blocked layout), zeroed by the caller.
-__global__ void __launch_bounds__(256) k_shell_unpack_rows_add(int n, const float* __restrict__ rows, int P, float* __restrict__ dense) {
+__global__ void __launch_bounds__(256) k_shell_unpack_rows_add(int n, const float* __restrict__ rows, int P, float* __restrict__ dense, int base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rows + 18 * (size_t)i;
-    const int g = __float_as_int(r[17]);
+    const int g = __float_as_int(r[17]) - base;
     if (g < 0 || g >= P) return;
     const size_t Ps = (size_t)P, gs = (size_t)g;
     const int off[6] = {0, 3, 7, 9, 10, 13}, wid[6] = {3, 4, 2, 1, 3, 4};
@@ -851,8 +1014,8 @@ __global__ void __launch_bounds__(256) k_shell_unpack_rows_add(int n, const floa
                 if (v != 0.f) atomicAdd(dense + off[b] * Ps + wid[b] * gs + k, v);
             }
 }
-void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s) {
-    hipLaunchKernelGGL(k_shell_unpack_rows_add, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense);
+void launch_shell_unpack_rows_add(int n, const float* rows, int P, float* dense, hipStream_t s, int base) {
+    hipLaunchKernelGGL(k_shell_unpack_rows_add, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense, base);
 }
 // counts[d] = #(idx in [d * chunk, (d + 1) * chunk)), idx ascending: the split sizes of the gradient all-to-all
 __global__ void __launch_bounds__(64) k_shell_chunk_counts(int M, const int* __restrict__ idx, int chunk, int world, float* __restrict__ counts) {
@@ -871,8 +1034,8 @@ void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const f
                             const float* g_rot, const int* idx, float* rows, hipStream_t s) {
     hipLaunchKernelGGL(k_shell_pack_rows, dim3((M + 255) / 256), dim3(256), 0, s, M, g_m3, g_m2, g_col, g_op, g_sc, g_rot, idx, rows);
 }
-void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s) {
-    hipLaunchKernelGGL(k_shell_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense, blocked);
+void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s, int base) {
+    hipLaunchKernelGGL(k_shell_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, rows, P, dense, blocked, base);
 }
 void launch_shell_chunk_counts(int M, const int* idx, int chunk, int world, float* counts, hipStream_t s) {
     hipLaunchKernelGGL(k_shell_chunk_counts, dim3((world + 63) / 64), dim3(64), 0, s, M, idx, chunk, world, counts);

@@ -182,6 +182,9 @@ def rebalance_shares(shares, times, damping=0.5, fixed=0.0):
 _NULL_CTX = contextlib.nullcontext()
 
 
+_SELECT_FUSED = os.environ.get("LIDARGS_SELECT_FUSED", "0") == "1"      # 1: the one-launch selection (round-6 experiment: bit-identical, no faster -- EXPERIMENTS.md)
+
+
 class HipShellBackend:
     """Per-rank compute on a HIP device through the C ABI (include/lidargs_rasterizer.h)."""
 
@@ -192,7 +195,8 @@ class HipShellBackend:
         for name in ("lidargs_wedge_select_count", "lidargs_forward_wedge", "lidargs_backward_wedge", "lidargs_wedge_pack_columns", "lidargs_wedge_unpack_columns",
                      "lidargs_wedge_unpack_grad_rows_add", "lidargs_shell_select", "lidargs_shell_select_count", "lidargs_shell_select_gather", "lidargs_shell_transmittance", "lidargs_shell_compose", "lidargs_shell_pack_grad_rows",
                      "lidargs_shell_unpack_grad_rows", "lidargs_shell_chunk_counts", "lidargs_shell_scatter_radii", "lidargs_shell_select_enqueue",
-                     "lidargs_wedge_select_enqueue", "lidargs_forward_shell_enqueue", "lidargs_forward_wedge_enqueue"):
+                     "lidargs_wedge_select_enqueue", "lidargs_forward_shell_enqueue", "lidargs_forward_wedge_enqueue", "lidargs_shell_select_sync",
+                     "lidargs_wedge_select_sync", "lidargs_shell_unpack_grad_rows_chunk"):
             getattr(self.lib, name).restype = C.c_int
         self.lib.lidargs_shell_select_scratch_bytes.restype = C.c_size_t
         self._scratch = {}          # persistent scratch of the selection (flags + offsets) per (device, P); never saved for a backward
@@ -255,6 +259,32 @@ class HipShellBackend:
             _C._raise(rc, "select (enqueue-only)")
         return idx, sel
 
+    def _select_sync(self, inp, call, chunks, what):
+        """An ordinary frame's selection in one launch (round 6): P-row arrays per call (the caching allocator hands them out without a
+        device malloc; only the first M rows are written and kept as views), one host read for M."""
+        _C = self._C
+        m3 = inp["means3D"]
+        dev, P = m3.device, int(m3.shape[0])
+        key = (dev, P)
+        scr = self._scratch.get(key)
+        if scr is None:
+            nb = int(self.lib.lidargs_shell_select_scratch_bytes(C.c_int(P)))
+            scr = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
+            self._scratch = {key: scr}
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        idx = torch.empty(P, dtype=torch.int32, device=dev)
+        rows = dict(means3D=f(P, 3), colors=f(P, 2), opacities=f(P, 1), scales=f(P, 3), rotations=f(P, 4))
+        n_valid = torch.empty(2, dtype=torch.int32, device=dev)
+        p = _C._ptr
+        with self._on(dev):
+            M = call(p, C.c_int(P), C.c_int(P), p(idx), p(rows["means3D"]), p(rows["colors"]), p(rows["opacities"]), p(rows["scales"]), p(rows["rotations"]),
+                     p(n_valid), p(scr[0]), C.c_size_t(scr[1]), *self._chunk_args(chunks), self._st(dev))
+        if M < 0:
+            _C._raise(M, what)
+        sel = dict(inp)
+        sel.update({k: v[:M] for k, v in rows.items()})
+        return idx[:M], sel
+
     def select(self, inp, lo, hi, plan=None, chunks=None):
         """Step 0: dense copies of the Gaussians with range in [lo, hi) + their indices (ascending).
 
@@ -269,6 +299,10 @@ class HipShellBackend:
                 C.c_float(lo), C.c_float(hi), ccap, *rest), chunks)
         _C._require_device(m3, "means3D")
         dev, P = m3.device, int(m3.shape[0])
+        if _SELECT_FUSED and P:
+            return self._select_sync(inp, lambda p, cP, *rest: lib.lidargs_shell_select_sync(
+                cP, p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), p(inp["rotations"]), p(inp["viewmatrix"]),
+                C.c_float(lo), C.c_float(hi), *rest), chunks, "lidargs_shell_select_sync")
         key = (dev, P)
         scr = self._scratch.get(key)
         if scr is None:
@@ -421,6 +455,10 @@ class HipShellBackend:
                 p(inp["viewmatrix"]), C.c_int(inp["W"]), C.c_int(c0), C.c_int(c1), ccap, *rest), chunks)
         _C._require_device(m3, "means3D")
         dev, P = m3.device, int(m3.shape[0])
+        if _SELECT_FUSED and P:
+            return self._select_sync(inp, lambda p, cP, *rest: lib.lidargs_wedge_select_sync(
+                cP, p(m3), p(inp["colors"]), p(inp["opacities"]), p(inp["scales"]), p(inp["rotations"]), C.c_float(inp["scale_modifier"]),
+                p(inp["viewmatrix"]), C.c_int(inp["W"]), C.c_int(c0), C.c_int(c1), *rest), chunks, "lidargs_wedge_select_sync")
         key = (dev, P)
         scr = self._scratch.get(key)
         if scr is None:
@@ -539,6 +577,14 @@ class HipShellBackend:
         return dense
 
     # ---- step 6 helpers: one launch each instead of concatenates, casts and index copies -------------------------------
+    def unpack_rows_chunk(self, rows, base, chunk_rows, add=False):
+        """Gradient mode "shard": [n, 18] rows -> this rank's own [17 * chunk_rows] block (six contiguous gradient blocks)."""
+        dev = rows.device
+        dense = torch.empty(GRAD_COLS * int(chunk_rows), dtype=torch.float32, device=dev)
+        self._call("lidargs_shell_unpack_grad_rows_chunk", dev, C.c_int(int(rows.shape[0])), self._C._ptr(rows), C.c_int(int(base)), C.c_int(int(chunk_rows)),
+                   self._C._ptr(dense) if chunk_rows else None, C.c_int(1 if add else 0))
+        return dense
+
     def _call(self, name, dev, *args):
         with self._on(dev):
             rc = getattr(self.lib, name)(*args, self._st(dev))
@@ -685,7 +731,7 @@ def _shell_forward(module, means3D, colors, opacities, scales, rotations):
             module.edges = edges               # static cut: convert once, no device read per frame
     lo, hi = edges[comm.rank], edges[comm.rank + 1]
 
-    exchange = comm.world > 1 and module.grad_sync == "reduce_scatter"
+    exchange = comm.world > 1 and module.grad_sync in ("reduce_scatter", "shard")
     fused = getattr(be, "fused_chunk_counts", False)                              # (the HIP backend; the framework-op backend of the CPU tests is not)
     enqueue_only = module.enqueue_only and fused
     plan = module.plan.next() if enqueue_only else None                           # None: an ordinary frame (two host reads)
@@ -744,6 +790,8 @@ def _shell_backward(module, saved, g_color, g_depth, g_occ):
     packed = be.pack_rows(g, idx)                                                 # [M, 18]: gradients + the row's global index
     blocked = sync != "reduce_scatter_dense"
     module.plan.check()                            # every sync mode: a frame over its capacities raises in its own backward (its kernels are queued)
+    if module.grad_sync == "shard":
+        return _shard_grads(module, saved, packed, P, add=False)
     if sync == "reduce_scatter":
         # 6: the shell's rows go straight to their index-chunk owners; the row index travels as an 18th column (bit pattern)
         send, recv = saved["counts"].splits(comm.rank)
@@ -768,6 +816,32 @@ def _shell_backward(module, saved, g_color, g_depth, g_occ):
             out[k] = dense[o * P:(o + w) * P].view(P, w)
         else:
             out[k] = dense[:, o:o + w]
+        o += w
+    return out
+
+
+def shard_rows(P, world, rank):
+    """(first row, number of rows) of rank's index chunk: the rows whose gradients it receives under grad_sync "reduce_scatter" / "shard"."""
+    rows = _chunk_rows(P, world)
+    lo = min(P, rank * rows)
+    return lo, min(P, lo + rows) - lo
+
+
+def _shard_grads(module, saved, packed, P, add):
+    """grad_sync = "shard" (round 6): the rank's own chunk of every gradient, [rows_r, w] each -- what a rank that optimises only its shard
+    of the (replicated) Gaussians needs.  The rows travel as under "reduce_scatter" (one variable-split all-to-all); they are unpacked into
+    a [17, rows_r] block instead of a zero-filled dense [P, 17] one."""
+    comm, be = module.comm, module.backend
+    base, n = shard_rows(P, comm.world, comm.rank)
+    if comm.world > 1:
+        send, recv = saved["counts"].splits(comm.rank)
+        got = comm.all_to_all_rows(packed[:sum(send)], send, recv)
+    else:
+        got = packed
+    dense = be.unpack_rows_chunk(got, base, n, add=add)
+    o, out = 0, {}
+    for k, w in GRAD_WIDTHS:
+        out[k] = dense[o * n:(o + w) * n].view(n, w)
         o += w
     return out
 
@@ -811,6 +885,37 @@ class _ShellRasterize(torch.autograd.Function):
         return g["means3D"], g["means2D"], g["colors"], g["opacities"], g["scales"], g["rotations"], None
 
 
+class _ShardRasterize(torch.autograd.Function):
+    """grad_sync = "shard": the frame is rendered from the REPLICATED tensors (no gradient flows to them); the gradients come back for the
+    rank's own shard leaves [rows_r, w] -- rows [r * rows, r * rows + rows_r) of the replicated ones, which the caller keeps equal to them."""
+
+    @staticmethod
+    def forward(ctx, means3D, colors, opacities, scales, rotations, s_means3D, s_means2D, s_colors, s_opacities, s_scales, s_rotations, module, wedges):
+        outs, saved = (wedge_forward if wedges else shell_forward)(module, means3D, colors, opacities, scales, rotations)
+        ctx.module, ctx.saved, ctx.wedges = module, saved, wedges
+        ctx.mark_non_differentiable(outs[3])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_occ, _g_radii):
+        g = (wedge_backward if ctx.wedges else shell_backward)(ctx.module, ctx.saved, g_color, g_depth, g_occ)
+        return (None, None, None, None, None, g["means3D"], g["means2D"], g["colors"], g["opacities"], g["scales"], g["rotations"], None, None)
+
+
+def _shard_apply(module, wedges, means3D, opacities, colors, scales, rotations, shard):
+    P = int(means3D.shape[0])
+    base, n = shard_rows(P, module.comm.world, module.comm.rank)
+    keys = ("means3D", "means2D", "colors", "opacities", "scales", "rotations")
+    if shard is None or any(k not in shard for k in keys):
+        raise ValueError('grad_sync="shard": pass shard=dict(means3D, means2D, colors, opacities, scales, rotations) -- this rank\'s own rows as leaves')
+    for k, w in GRAD_WIDTHS:
+        if tuple(shard[k].shape) != (n, w):
+            raise ValueError(f'grad_sync="shard": shard["{k}"] must be [{n}, {w}] (rows {base}..{base + n} of the replicated tensor), got {tuple(shard[k].shape)}')
+    d = lambda t: t.detach()
+    return _ShardRasterize.apply(d(means3D), d(colors), d(opacities), d(scales), d(rotations), shard["means3D"], shard["means2D"], shard["colors"],
+                                 shard["opacities"], shard["scales"], shard["rotations"], module, wedges)
+
+
 class ShellRasterizer(nn.Module):
     """Range-shell sharded counterpart of GaussianRasterizer.forward (colors_precomp + scales/rotations path,
     the one gaussian_renderer.render() uses).  Inputs are REPLICATED on every rank; outputs are identical
@@ -818,7 +923,7 @@ class ShellRasterizer(nn.Module):
 
     def __init__(self, raster_settings, comm=None, backend=None, grad_sync="reduce_scatter", edges=None):
         super().__init__()
-        assert grad_sync in ("reduce_scatter", "reduce_scatter_dense", "all_reduce", "none")
+        assert grad_sync in ("reduce_scatter", "reduce_scatter_dense", "all_reduce", "none", "shard")
         self.raster_settings = raster_settings
         self.comm = comm if comm is not None else SingleComm()
         self.backend = backend if backend is not None else HipShellBackend()
@@ -827,7 +932,11 @@ class ShellRasterizer(nn.Module):
         self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"     # see _RankPlan; off by default
         self.plan = _RankPlan()
 
-    def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations):
+    def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations, shard=None):
+        """grad_sync "shard" (round 6): `shard` = this rank's own rows of the six tensors as leaves (shard_rows(P, world, rank)); the
+        replicated arguments only feed the rendering and receive no gradient."""
+        if self.grad_sync == "shard":
+            return _shard_apply(self, False, means3D, opacities, colors_precomp, scales, rotations, shard)
         return _ShellRasterize.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self)
 
 
@@ -899,7 +1008,7 @@ def _wedge_forward(module, means3D, colors, opacities, scales, rotations):
     c0, c1 = int(edges[comm.rank]), int(edges[comm.rank + 1])
     wmax = max(int(edges[g + 1]) - int(edges[g]) for g in range(comm.world))
 
-    exchange = comm.world > 1 and module.grad_sync == "reduce_scatter"
+    exchange = comm.world > 1 and module.grad_sync in ("reduce_scatter", "shard")
     fused = getattr(be, "fused_chunk_counts", False)
     enqueue_only = module.enqueue_only and fused
     plan = module.plan.next() if enqueue_only else None
@@ -943,6 +1052,8 @@ def _wedge_backward(module, saved, g_color, g_depth, g_occ):
     sync = module.grad_sync if comm.world > 1 else "none"
     packed = be.pack_rows(g, idx)
     module.plan.check()                            # every sync mode (see _shell_backward)
+    if module.grad_sync == "shard":
+        return _shard_grads(module, saved, packed, P, add=True)
     if sync == "reduce_scatter":
         send, recv = saved["counts"].splits(comm.rank)
         got = comm.all_to_all_rows(packed[:sum(send)], send, recv)
@@ -980,7 +1091,7 @@ class WedgeRasterizer(nn.Module):
 
     def __init__(self, raster_settings, comm=None, backend=None, grad_sync="reduce_scatter", edges=None):
         super().__init__()
-        assert grad_sync in ("reduce_scatter", "all_reduce", "none")
+        assert grad_sync in ("reduce_scatter", "all_reduce", "none", "shard")
         self.raster_settings = raster_settings
         self.comm = comm if comm is not None else SingleComm()
         self.backend = backend if backend is not None else HipShellBackend()
@@ -989,5 +1100,7 @@ class WedgeRasterizer(nn.Module):
         self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"     # see _RankPlan; off by default
         self.plan = _RankPlan()
 
-    def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations):
+    def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations, shard=None):
+        if self.grad_sync == "shard":                # (see ShellRasterizer.forward)
+            return _shard_apply(self, True, means3D, opacities, colors_precomp, scales, rotations, shard)
         return _WedgeRasterize.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self)

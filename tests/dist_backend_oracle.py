@@ -54,6 +54,23 @@ class OracleShellBackend:
             parts.append(dense[:, o:o + w].contiguous().view(-1)); o += w
         return torch.cat(parts)
 
+    def unpack_rows_chunk(self, rows, base, chunk_rows, add=False):
+        """[n, 18] rows -> the [17 * chunk_rows] block of the rows [base, base + chunk_rows) (six contiguous gradient blocks), as
+        lidargs_shell_unpack_grad_rows_chunk; add: rows of equal index are added."""
+        n = int(chunk_rows)
+        dense = torch.zeros(n, 17)
+        if rows.shape[0]:
+            g = rows[:, 17].contiguous().view(torch.int32).long() - int(base)
+            ok = (g >= 0) & (g < n)
+            if add:
+                dense.index_add_(0, g[ok], rows[ok, :17])
+            else:
+                dense[g[ok]] = rows[ok, :17]
+        out, o = [], 0
+        for w in (3, 4, 2, 1, 3, 4):
+            out.append(dense[:, o:o + w].contiguous().view(-1)); o += w
+        return torch.cat(out)
+
     def transmittance(self, allT, rank):
         return torch.prod(allT[:rank], dim=0) if rank > 0 else torch.ones_like(allT[0])
 

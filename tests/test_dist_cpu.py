@@ -48,9 +48,23 @@ def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir, edges
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
     leaves = {k: t(scene[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     m2 = torch.zeros(P, 4, requires_grad=True)
-    color, depth, occ, radii = rast(leaves["means3D"], m2, leaves["opacities"], leaves["colors"], leaves["scales"], leaves["rotations"])
     gc, gd, go = (torch.from_numpy(g) for g in sc.upstream_grads(H, W, seed))
-    torch.autograd.backward([color, depth, occ], [gc, gd, go])
+    if grad_sync == "shard":
+        # the rank's own rows as leaves; the replicated tensors only feed the rendering.  Saved as dense [P, w] arrays (zeros outside the
+        # chunk) so that the checks of "reduce_scatter" apply unchanged.
+        base, n = lidargs_dist.shard_rows(P, world, rank)
+        shard = {k: leaves[k].detach()[base:base + n].clone().requires_grad_(True) for k in leaves}
+        shard["means2D"] = torch.zeros(n, 4, requires_grad=True)
+        color, depth, occ, radii = rast(leaves["means3D"], m2, leaves["opacities"], leaves["colors"], leaves["scales"], leaves["rotations"], shard=shard)
+        torch.autograd.backward([color, depth, occ], [gc, gd, go])
+        assert all(leaves[k].grad is None for k in leaves) and m2.grad is None
+        for k, full in list(leaves.items()) + [("means2D", m2)]:
+            assert tuple(shard[k].grad.shape) == (n,) + tuple(full.shape[1:])
+            full.grad = torch.zeros_like(full)
+            full.grad[base:base + n] = shard[k].grad
+    else:
+        color, depth, occ, radii = rast(leaves["means3D"], m2, leaves["opacities"], leaves["colors"], leaves["scales"], leaves["rotations"])
+        torch.autograd.backward([color, depth, occ], [gc, gd, go])
     out = dict(color=color.detach().numpy(), depth=depth.detach().numpy(), occ=occ.detach().numpy(), radii=radii.numpy(),
                dL_dmeans3D=leaves["means3D"].grad.numpy(), dL_dmeans2D=m2.grad.numpy(), dL_dcolors=leaves["colors"].grad.numpy(),
                dL_dopacity=leaves["opacities"].grad.numpy(), dL_dscales=leaves["scales"].grad.numpy(),
@@ -67,6 +81,7 @@ CASES = [
     ("w2_dense_rs", 2, "shell", 3001, 16, 256, 34, (0.0, 0.1), "reduce_scatter_dense"),   # P not divisible by the world size
     ("w3_odd_sparse", 3, "shell", 2999, 16, 256, 35, (0.2, 0.0), "reduce_scatter"),
     ("w2_none", 2, "shell", 3000, 16, 256, 36, (0.0, 0.0), "none"),
+    ("w3_shard", 3, "street", 5000, 16, 256, 37, (0.1, 0.3), "shard"),             # round 6: the rank's own chunk of every gradient, [rows_r, w]
 ]
 
 
@@ -168,6 +183,7 @@ WEDGE_CASES = [
     ("w3_dense", 3, "street", 9000, 16, 160, 63, (0.1, 0.2), "reduce_scatter", None),
     ("w3_ragged_odd", 3, "shell", 2999, 18, 250, 64, (0.2, 0.0), "reduce_scatter", None),        # W % 16 != 0, P % world != 0
     ("w4_narrow_first_wedge", 4, "shell", 3000, 16, 256, 65, (0.0, 0.1), "reduce_scatter", [0, 16, 128, 240, 256]),   # one-tile wedges
+    ("w3_shard", 3, "street", 5001, 16, 250, 66, (0.2, 0.1), "shard", None),                  # round 6 (boundary Gaussians' rows are ADDED into the chunk)
     ("w2_none", 2, "shell", 3000, 16, 256, 66, (0.0, 0.0), "none", None),
 ]
 

@@ -108,6 +108,14 @@ def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results, wedges=False
         for _ in range(frames):          # (enqueue-only: the first frame is an ordinary one and teaches the plan its capacities)
             (color, depth, occ, radii), saved = fwd(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
             g = bwd(mod, saved, gc, gd, go)
+        if grad_sync == "shard":         # [rows_r, w] chunks -> dense [P, w] with zeros outside, so that the checks of "reduce_scatter" apply
+            P = int(st["means3D"].shape[0])
+            base, n = lidargs_dist.shard_rows(P, comm.world, rank)
+            dense = {}
+            for k, t in g.items():
+                assert t.shape[0] == n, (k, t.shape, n)
+                dense[k] = torch.zeros((P,) + tuple(t.shape[1:]), device=t.device); dense[k][base:base + n] = t
+            g = dense
         mod.plan.check()
         results[rank] = dict(enqueue_only_frames=mod.plan.frames, color=color.cpu().numpy(), depth=depth.cpu().numpy(), occ=occ.cpu().numpy(), radii=radii.cpu().numpy(),
                              dL_dmeans3D=g["means3D"].cpu().numpy(), dL_dmeans2D=g["means2D"].cpu().numpy(),
@@ -127,6 +135,7 @@ CASES = [
     ("w4_dense", 4, "street", 60000, 32, 800, 53, (0.2, 0.1), "all_reduce"),
     ("w4_sparse_exchange", 4, "street", 50001, 32, 800, 54, (0.0, 0.2), "reduce_scatter"),
     ("w3_dense_exchange", 3, "shell", 20000, 16, 512, 55, (0.1, 0.0), "reduce_scatter_dense"),
+    ("w4_shard", 4, "street", 50003, 32, 800, 56, (0.1, 0.2), "shard"),      # round 6: the rank's own chunk of every gradient (lidargs_shell_unpack_grad_rows_chunk)
 ]
 
 
@@ -325,6 +334,35 @@ def test_selection_leaves_the_split_sizes_of_the_gradient_exchange(world, hip_li
         assert torch.equal(idx3, idx0[:M // 2]) and s3["n_valid"].tolist() == [M // 2, M] and float(counts.sum()) == M // 2
 
 
+@pytest.mark.parametrize("P", [1, 1023, 1024, 1025, 3_000_017])
+def test_one_launch_selection_equals_the_two_step_one(P, hip_lib_built, monkeypatch):
+    """Round 6: k_select_fused (test + scan by decoupled look-back over the blocks + gather, one launch) against rounds 2-5's flags -> scan ->
+    gather: the same rows in the same (ascending index) order, bit for bit, shells and wedges, at block-boundary sizes and at 3 M rows
+    (2930 blocks looking back), with split sizes; run twice (the look-back's words are zeroed per call)."""
+    import lidargs_dist
+    st = to_torch(sc.make_scene("street", P, 16, 95, random_view=True))
+    inp = dict(means3D=st["means3D"], colors=st["colors"], opacities=st["opacities"], scales=st["scales"], rotations=st["rotations"],
+               viewmatrix=st["viewmatrix"], W=512, H=16, scale_modifier=1.0)
+    world = 8
+    chunk = lidargs_dist._chunk_rows(P, world)
+    for wedge in (False, True):
+        out = {}
+        for fused in (False, True):
+            monkeypatch.setattr(lidargs_dist, "_SELECT_FUSED", fused)
+            be = lidargs_dist.HipShellBackend()
+            for rep in range(2):
+                counts = torch.full((world,), -1.0, device="cuda")
+                idx, sel = (be.select_wedge(inp, 64, 256, None, chunks=(chunk, world, counts)) if wedge else be.select(inp, 12.0, 30.0, None, chunks=(chunk, world, counts)))
+                out[(fused, rep)] = (idx.clone(), {k: sel[k].clone() for k in ("means3D", "colors", "opacities", "scales", "rotations")}, counts.clone())
+        ref = out[(False, 0)]
+        for key, (idx, rows, counts) in out.items():
+            assert torch.equal(idx, ref[0]) and torch.equal(counts, ref[2]), (P, wedge, key)
+            for k in rows:
+                assert torch.equal(rows[k], ref[1][k]), (P, wedge, key, k)
+        if P > 2000:
+            assert 0 < int(ref[0].shape[0]) < P
+
+
 def test_cfg4_sharded_over_8_virtual_ranks_at_full_size(hip_lib_built):
     """BASELINE config 4 in its stated form, as far as one GPU allows: the 8 M-Gaussian 128 x 4096 scene sharded into 8 range
     shells, every shell driven through the product path (lidargs_shell_select -> forward phase 1 -> transmittance -> phase 2 ->
@@ -422,6 +460,7 @@ WEDGE_CASES = [
     ("w4_dense", 4, "street", 60000, 32, 800, 83, (0.2, 0.1), "reduce_scatter", None),
     ("w3_ragged", 3, "shell", 20001, 18, 500, 84, (0.1, 0.0), "reduce_scatter", None),                   # W % 16 != 0, odd P
     ("w5_one_tile_wedges", 5, "street", 30000, 64, 600, 85, (0.0, 0.2), "reduce_scatter", [0, 16, 32, 304, 592, 600]),
+    ("w4_shard", 4, "street", 40003, 32, 800, 86, (0.1, 0.1), "shard", None),            # round 6 (boundary Gaussians' rows are added inside the chunk)
 ]
 
 

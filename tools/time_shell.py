@@ -74,7 +74,8 @@ def frame(mod):
 
 
 def make_module(comm, edges):
-    mod = (lidargs_dist.WedgeRasterizer if MODE == "wedge" else lidargs_dist.ShellRasterizer)(settings, comm, edges=edges)
+    mod = (lidargs_dist.WedgeRasterizer if MODE == "wedge" else lidargs_dist.ShellRasterizer)(settings, comm, edges=edges,
+                                                                                              grad_sync=os.environ.get("GRAD_SYNC", "reduce_scatter"))   # GRAD_SYNC=shard: the rank's own chunk only
     mod.enqueue_only = os.environ.get("ENQUEUE", "0") == "1"      # enqueue-only rank frames (no host read after the first frame)
     return mod
 
