@@ -357,6 +357,17 @@ int lidargs_wedge_select_sync(int P, const float* means3D, const float* colors, 
                               int capacity, int* idx_out, float* out_means3D, float* out_colors, float* out_opacities, float* out_scales,
                               float* out_rotations, unsigned* n_valid_dev, char* scratch, size_t scratch_bytes, int chunk_rows, int world,
                               float* chunk_counts, void* stream);
+/* Round 6: the gradient exchange of the sharded frame ships only the rows that carry a gradient (a frame blends a fraction of the Gaussians a
+ * rank preprocesses: every other row is 72 bytes of zeros).  _live_count: live rows per destination chunk (index / chunk_rows) into
+ * counts_dev u32[world] and, when counts_host (HOST u32[world]) is given, to the host (the call then waits for the copy and returns their sum;
+ * with NULL it returns 0 at once: a caller that gathers every rank's counts reads them all in one go).  _live: writes exactly that many [18]-float rows, grouped by destination in ascending chunk order (any order inside a
+ * group); cursor_dev u32[world] is scratch.  idx: the rows' global indices (ascending); rows whose index is outside [0, P) never travel. */
+int lidargs_shell_pack_grad_rows_live_count(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors,
+                                            const float* dL_dopacity, const float* dL_dscales, const float* dL_drotations, const int* idx, int P,
+                                            int chunk_rows, int world, unsigned* counts_dev, unsigned* counts_host, void* stream);
+int lidargs_shell_pack_grad_rows_live(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors, const float* dL_dopacity,
+                                      const float* dL_dscales, const float* dL_drotations, const int* idx, int P, int chunk_rows, int world,
+                                      unsigned* counts_dev, unsigned* cursor_dev, float* rows, void* stream);
 /* Round 6, gradient mode "shard" of lidargs_dist: the [n, 18] gradient rows a rank received for its own index chunk
  * [base, base + chunk_rows) unpacked into dense f32[17][chunk_rows] (six contiguous blocks: means3D 3, means2D 4, colours 2, opacity 1, scales 3,
  * rotations 4 columns of chunk_rows rows each; zero-filled here); add != 0 adds rows of equal index (column wedges). */

@@ -1273,6 +1273,42 @@ int lidargs_shell_unpack_grad_rows(int n, const float* rows, int P, float* dense
     if (n) lg::launch_shell_unpack_rows(n, rows, P, dense, blocked, (hipStream_t)stream);
     return check_launch((hipStream_t)stream, 0, "shell unpack rows");
 }
+// Round 6: the gradient exchange ships only the rows that carry a gradient (preprocess.hip k_shell_pack_rows_live).  Step 1 counts them per
+// destination chunk into counts_dev u32[world] (zeroed here) and copies the counts to counts_host (waits: the all-to-all's split sizes are
+// host numbers); step 2 writes exactly sum(counts) rows of 18 floats, grouped by destination in ascending chunk order (cursor u32[world] is
+// scratch, zeroed here).  Returns the number of live rows (step 1) / 0 (step 2).
+int lidargs_shell_pack_grad_rows_live_count(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors, const float* dL_dopacity,
+                                            const float* dL_dscales, const float* dL_drotations, const int* idx, int P, int chunk_rows, int world,
+                                            unsigned* counts_dev, unsigned* counts_host, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || P < 0 || chunk_rows <= 0 || world <= 0 || world > 256 || !counts_dev) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_pack_grad_rows_live_count: bad arguments%s");
+    LG_HIP(hipMemsetAsync(counts_dev, 0, sizeof(unsigned) * (size_t)world, stream));
+    if (M > 0) {
+        if (!dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dscales || !dL_drotations || !idx)
+            return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_pack_grad_rows_live_count: NULL pointer%s");
+        lg::launch_shell_pack_rows_live(false, M, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, idx, P, chunk_rows, world, counts_dev, nullptr,
+                                        nullptr, stream);
+    }
+    if (!counts_host) return check_launch(stream, 0, "shell pack rows (live count)");      // the counts stay on the device (the caller gathers every rank's and reads them once)
+    LG_HIP((hipError_t)lg::api_read_words_zero_behind(counts_dev, world, counts_host, nullptr, 0, stream));
+    long long tot = 0;
+    for (int d = 0; d < world; d++) tot += counts_host[d];
+    return (int)tot;
+}
+int lidargs_shell_pack_grad_rows_live(int M, const float* dL_dmeans3D, const float* dL_dmeans2D, const float* dL_dcolors, const float* dL_dopacity,
+                                      const float* dL_dscales, const float* dL_drotations, const int* idx, int P, int chunk_rows, int world,
+                                      unsigned* counts_dev, unsigned* cursor_dev, float* rows, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || P < 0 || chunk_rows <= 0 || world <= 0 || world > 256 || !counts_dev || !cursor_dev) return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_pack_grad_rows_live: bad arguments%s");
+    if (M == 0) return 0;
+    if (!dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dscales || !dL_drotations || !idx || !rows)
+        return fail(LIDARGS_ERR_INVALID_ARGUMENT, "shell_pack_grad_rows_live: NULL pointer%s");
+    LG_HIP(hipMemsetAsync(cursor_dev, 0, sizeof(unsigned) * (size_t)world, stream));
+    lg::launch_shell_pack_rows_live(true, M, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, idx, P, chunk_rows, world, counts_dev, cursor_dev,
+                                    rows, stream);
+    return check_launch(stream, 0, "shell pack rows (live)");
+}
+
 // Round 6, gradient mode "shard": the rows a rank received for its OWN index chunk [base, base + chunk_rows), unpacked into a
 // [17][chunk_rows] block (six contiguous gradient blocks of chunk_rows rows each) -- no dense [P, 17] block is zero-filled or scattered into
 // (544 MB + 20 M scattered words per frame at 8 M Gaussians).  add != 0: rows of equal index are added (column wedges).

@@ -355,6 +355,8 @@ void launch_debug_rects(int n, int surfel, const float* p_cr, const int* r_xy, i
 void launch_shell_pack_rows(int M, const float* g_m3, const float* g_m2, const float* g_col, const float* g_op, const float* g_sc,
                             const float* g_rot, const int* idx, float* rows, hipStream_t s);
 void launch_shell_unpack_rows(int n, const float* rows, int P, float* dense, int blocked, hipStream_t s, int base = 0);
+void launch_shell_pack_rows_live(bool write, int M, const float* g_m3, const float* g_m2, const float* g_col, const float* g_op, const float* g_sc, const float* g_rot,
+                                 const int* idx, int P, int chunk_rows, int world, uint32_t* counts, uint32_t* cursor, float* rows_out, hipStream_t s);
 void launch_shell_chunk_counts(int M, const int* idx, int chunk, int world, float* counts, hipStream_t s);
 void launch_shell_scatter_i32(int M, const int* idx, const int* src, int P, int* dst, hipStream_t s);
 void launch_shell_transmittance(int G, int rank, int N, size_t row_stride, const float* all_T, float* T_in, hipStream_t s);

@@ -973,6 +973,82 @@ __global__ void __launch_bounds__(256) k_shell_pack_rows(int M, const float* __r
     r[13] = q.x; r[14] = q.y; r[15] = q.z; r[16] = q.w;
     r[17] = __int_as_float(idx[i]);                                    // the index travels as a bit pattern
 }
+// Round 6: only the rows that carry a gradient travel.  A frame blends a fraction of the Gaussians a rank preprocesses (cfg4: 10 k of 8 M;
+// cfg3: a fifth) and every other row of the exchange is 72 bytes of zeros -- packed, shipped over xGMI, read and skipped.  Two launches
+// around one host read (the all-to-all's split sizes are host numbers anyway): count the rows with any non-zero gradient per destination
+// chunk, then write exactly those, grouped by destination (any order inside a group: the receiver scatters by index).
+__device__ __forceinline__ bool shell_row_live(const float* __restrict__ g_m3, const float* __restrict__ g_m2, const float* __restrict__ g_col, const float* __restrict__ g_op,
+                                               const float* __restrict__ g_sc, const float* __restrict__ g_rot, size_t i, float* r) {
+    r[0] = g_m3[3 * i]; r[1] = g_m3[3 * i + 1]; r[2] = g_m3[3 * i + 2];
+    const float4 m2 = reinterpret_cast<const float4*>(g_m2)[i];
+    r[3] = m2.x; r[4] = m2.y; r[5] = m2.z; r[6] = m2.w;
+    const float2 c = reinterpret_cast<const float2*>(g_col)[i];
+    r[7] = c.x; r[8] = c.y;
+    r[9] = g_op[i];
+    r[10] = g_sc[3 * i]; r[11] = g_sc[3 * i + 1]; r[12] = g_sc[3 * i + 2];
+    const float4 q = reinterpret_cast<const float4*>(g_rot)[i];
+    r[13] = q.x; r[14] = q.y; r[15] = q.z; r[16] = q.w;
+    bool live = false;
+#pragma unroll
+    for (int k = 0; k < 17; k++) live = live || (r[k] != 0.f);          // (a NaN is != 0: it travels)
+    return live;
+}
+// WRITE = false: counts[d] += live rows bound for chunk d.  WRITE = true: rows_out[prefix(counts)[d] + cursor[d]++] = the row.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_shell_pack_rows_live(int M, const float* __restrict__ g_m3, const float* __restrict__ g_m2, const float* __restrict__ g_col,
+                                                              const float* __restrict__ g_op, const float* __restrict__ g_sc, const float* __restrict__ g_rot,
+                                                              const int* __restrict__ idx, int P, int chunk_rows, int world, uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ cursor, float* __restrict__ rows_out) {
+    __shared__ uint32_t s_base[256];
+    if (WRITE) {
+        // exclusive prefix of the counts (world <= 256): where each destination's group starts
+        const int t = threadIdx.x;
+        uint32_t v = t < world ? counts[t] : 0u, incl = v;
+        const int lane = t & 63;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        __shared__ uint32_t s_w[4];
+        if (lane == 63) s_w[t >> 6] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int q = 0; q < (t >> 6); q++) off += s_w[q];
+        s_base[t] = off + incl - v;
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float r[17];
+    int g = -1;
+    bool live = false;
+    if (i < M) {
+        g = idx[i];
+        if (g >= 0 && g < P) live = shell_row_live(g_m3, g_m2, g_col, g_op, g_sc, g_rot, (size_t)i, r);
+    }
+    const int d = live ? min(g / chunk_rows, world - 1) : -1;
+    // wave-aggregated per destination: the rows of a wave are index-ascending, so it sees one destination, rarely two
+    unsigned long long todo = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int dl = __shfl(d, leader);
+        const unsigned long long same = __ballot(live && d == dl);
+        uint32_t pos = 0;
+        if (lane == leader) pos = atomicAdd((WRITE ? cursor : counts) + dl, (uint32_t)__builtin_popcountll(same));
+        pos = __shfl(pos, leader);
+        if (WRITE && live && d == dl) {
+            float* o = rows_out + 18 * ((size_t)s_base[dl] + pos + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull)));
+#pragma unroll
+            for (int k = 0; k < 17; k++) o[k] = r[k];
+            o[17] = __int_as_float(g);
+        }
+        todo &= ~same;
+    }
+}
+void launch_shell_pack_rows_live(bool write, int M, const float* g_m3, const float* g_m2, const float* g_col, const float* g_op, const float* g_sc, const float* g_rot,
+                                 const int* idx, int P, int chunk_rows, int world, uint32_t* counts, uint32_t* cursor, float* rows_out, hipStream_t s) {
+    const dim3 grid((M + 255) / 256), block(256);
+    if (write) hipLaunchKernelGGL(k_shell_pack_rows_live<true>, grid, block, 0, s, M, g_m3, g_m2, g_col, g_op, g_sc, g_rot, idx, P, chunk_rows, world, counts, cursor, rows_out);
+    else hipLaunchKernelGGL(k_shell_pack_rows_live<false>, grid, block, 0, s, M, g_m3, g_m2, g_col, g_op, g_sc, g_rot, idx, P, chunk_rows, world, counts, cursor, rows_out);
+}
 // blocked != 0: dense is six contiguous blocks [P,3][P,4][P,2][P,1][P,3][P,4] (what autograd takes without a strided copy each)
 // base (round 6, the "shard" gradient mode): `dense` holds the rows [base, base + P) of the index space only -- a rank's own chunk
 __global__ void __launch_bounds__(256) k_shell_unpack_rows(int n, const float* __restrict__ rows, int P, float* __restrict__ dense, int blocked, int base) {

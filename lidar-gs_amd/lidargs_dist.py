@@ -196,7 +196,8 @@ class HipShellBackend:
                      "lidargs_wedge_unpack_grad_rows_add", "lidargs_shell_select", "lidargs_shell_select_count", "lidargs_shell_select_gather", "lidargs_shell_transmittance", "lidargs_shell_compose", "lidargs_shell_pack_grad_rows",
                      "lidargs_shell_unpack_grad_rows", "lidargs_shell_chunk_counts", "lidargs_shell_scatter_radii", "lidargs_shell_select_enqueue",
                      "lidargs_wedge_select_enqueue", "lidargs_forward_shell_enqueue", "lidargs_forward_wedge_enqueue", "lidargs_shell_select_sync",
-                     "lidargs_wedge_select_sync", "lidargs_shell_unpack_grad_rows_chunk"):
+                     "lidargs_wedge_select_sync", "lidargs_shell_unpack_grad_rows_chunk", "lidargs_shell_pack_grad_rows_live_count",
+                     "lidargs_shell_pack_grad_rows_live"):
             getattr(self.lib, name).restype = C.c_int
         self.lib.lidargs_shell_select_scratch_bytes.restype = C.c_size_t
         self._scratch = {}          # persistent scratch of the selection (flags + offsets) per (device, P); never saved for a backward
@@ -611,6 +612,33 @@ class HipShellBackend:
                    p(g["scales"]), p(g["rotations"]), p(idx), p(rows))
         return rows
 
+    def _live_args(self, g, idx, P, chunk_rows, world):
+        p = self._C._ptr
+        return (C.c_int(int(idx.shape[0])), p(g["means3D"]), p(g["means2D"]), p(g["colors"]), p(g["opacities"]), p(g["scales"]), p(g["rotations"]), p(idx),
+                C.c_int(int(P)), C.c_int(int(chunk_rows)), C.c_int(int(world)))
+
+    def count_rows_live(self, g, idx, P, chunk_rows, world):
+        """Rows that carry a gradient, per destination chunk (round 6): float32 [world] ON THE DEVICE, no host read (exact: < 2^24 rows per chunk)."""
+        dev = idx.device
+        cnt = torch.empty(2 * world, dtype=torch.int32, device=dev)
+        with self._on(dev):
+            rc = self.lib.lidargs_shell_pack_grad_rows_live_count(*self._live_args(g, idx, P, chunk_rows, world), C.c_void_p(cnt.data_ptr()), None, self._st(dev))
+        if rc < 0:
+            self._C._raise(rc, "lidargs_shell_pack_grad_rows_live_count")
+        return cnt
+
+    def pack_rows_live(self, g, idx, P, chunk_rows, world, cnt, n):
+        """The n = sum(counts) live rows, [n, 18], grouped by destination chunk; `cnt` = what count_rows_live returned."""
+        dev = idx.device
+        rows = torch.empty((int(n), GRAD_COLS + 1), dtype=torch.float32, device=dev)
+        if n:
+            with self._on(dev):
+                rc = self.lib.lidargs_shell_pack_grad_rows_live(*self._live_args(g, idx, P, chunk_rows, world), C.c_void_p(cnt.data_ptr()),
+                                                                C.c_void_p(cnt.data_ptr() + 4 * world), self._C._ptr(rows), self._st(dev))
+            if rc < 0:
+                self._C._raise(rc, "lidargs_shell_pack_grad_rows_live")
+        return rows
+
     def unpack_rows(self, rows, P, blocked=False):
         """Zero, then every row written at the index it carries: dense [P, 17], or (blocked) one flat [17 P] tensor holding the
         six gradients as contiguous blocks [P,3][P,4][P,2][P,1][P,3][P,4], which autograd takes without a strided copy each."""
@@ -787,17 +815,16 @@ def _shell_backward(module, saved, g_color, g_depth, g_occ):
     # d(color)/d(T_final) for the background is inside the blend: (-T_final/(1-alpha)) * bg.g  (R3/cr/backward.cu:727)
     g = be.backward(st, saved["behind"], saved["T_final"], (g_color.reshape(2, H * W), g_depth.reshape(H * W), g_occ.reshape(H * W)))
     sync = module.grad_sync if comm.world > 1 else "none"
-    packed = be.pack_rows(g, idx)                                                 # [M, 18]: gradients + the row's global index
     blocked = sync != "reduce_scatter_dense"
-    module.plan.check()                            # every sync mode: a frame over its capacities raises in its own backward (its kernels are queued)
     if module.grad_sync == "shard":
-        return _shard_grads(module, saved, packed, P, add=False)
+        return _shard_grads(module, saved, g, idx, P, add=False)
     if sync == "reduce_scatter":
         # 6: the shell's rows go straight to their index-chunk owners; the row index travels as an 18th column (bit pattern)
-        send, recv = saved["counts"].splits(comm.rank)
-        got = comm.all_to_all_rows(packed[:sum(send)], send, recv)      # (an enqueue-only frame's rows are capacity-sized)
+        got = _exchange_rows(module, saved, g, idx, P)                  # (every sync mode: a frame over its capacities raises in its own backward, plan.check())
         dense = be.unpack_rows(got, P, blocked=True)
     else:
+        packed = be.pack_rows(g, idx)                                                 # [M, 18]: gradients + the row's global index
+        module.plan.check()
         dense = be.unpack_rows(packed, P, blocked=blocked)
         if sync == "all_reduce":
             dense = comm.all_reduce(dense)
@@ -820,6 +847,44 @@ def _shell_backward(module, saved, g_color, g_depth, g_occ):
     return out
 
 
+SHIP_LIVE_BYTES = 32 << 20      # "auto": live rows only when a rank's share of the full exchange (72 B x P / world) is at least this
+
+
+def _ship_live_default():
+    e = os.environ.get("LIDARGS_SHIP_LIVE", "auto")
+    return True if e == "1" else (False if e == "0" else "auto")
+
+
+def _ships_live(module, P):
+    """The same answer on every rank (it depends on P and the world size only: the live form has a collective of its own).  Shipping only the
+    live rows costs one host read in the backward and a 4 x world-byte all-gather; it pays when the full exchange is large: 8 M Gaussians over
+    8 ranks ship 84 MB per rank otherwise (0.1 MB live), 2 M ship 18 MB (0.6 MB live) -- there the read costs what the bytes save."""
+    live = getattr(module, "ship_live", False)
+    if live == "auto":
+        live = 72 * P // max(1, module.comm.world) >= SHIP_LIVE_BYTES
+    return bool(live) and not module.enqueue_only and hasattr(module.backend, "pack_rows_live")
+
+
+def _exchange_rows(module, saved, g, idx, P):
+    """The rows this rank receives for its index chunk: [n, 18] (17 gradient columns + the bit pattern of the row's global index).
+    Round 6 (module.ship_live; "auto" = for large exchanges, _ships_live): only the rows that carry a gradient travel -- each rank counts them per destination, the counts
+    cross in one small all-gather, then the variable-split all-to-all ships exactly those (cfg4, world 8: 84 MB per rank and frame -> 0.1 MB;
+    cfg3: a fifth).  Otherwise (enqueue-only frames: no host read): every selected row, split sizes from the forward's selection."""
+    comm, be = module.comm, module.backend
+    if _ships_live(module, P):
+        chunk = _chunk_rows(P, comm.world)
+        cnt = be.count_rows_live(g, idx, P, chunk, comm.world)          # on the device
+        module.plan.check()
+        allc = comm.all_gather(cnt[:comm.world])                         # [src, dst]: every rank's counts, then ONE host read for send and receive sizes
+        host = allc.tolist()
+        send, recv = [int(v) for v in host[comm.rank]], [int(row[comm.rank]) for row in host]
+        return comm.all_to_all_rows(be.pack_rows_live(g, idx, P, chunk, comm.world, cnt, sum(send)), send, recv)
+    packed = be.pack_rows(g, idx)
+    module.plan.check()
+    send, recv = saved["counts"].splits(comm.rank)
+    return comm.all_to_all_rows(packed[:sum(send)], send, recv)
+
+
 def shard_rows(P, world, rank):
     """(first row, number of rows) of rank's index chunk: the rows whose gradients it receives under grad_sync "reduce_scatter" / "shard"."""
     rows = _chunk_rows(P, world)
@@ -827,17 +892,17 @@ def shard_rows(P, world, rank):
     return lo, min(P, lo + rows) - lo
 
 
-def _shard_grads(module, saved, packed, P, add):
+def _shard_grads(module, saved, g, idx, P, add):
     """grad_sync = "shard" (round 6): the rank's own chunk of every gradient, [rows_r, w] each -- what a rank that optimises only its shard
     of the (replicated) Gaussians needs.  The rows travel as under "reduce_scatter" (one variable-split all-to-all); they are unpacked into
     a [17, rows_r] block instead of a zero-filled dense [P, 17] one."""
     comm, be = module.comm, module.backend
     base, n = shard_rows(P, comm.world, comm.rank)
     if comm.world > 1:
-        send, recv = saved["counts"].splits(comm.rank)
-        got = comm.all_to_all_rows(packed[:sum(send)], send, recv)
+        got = _exchange_rows(module, saved, g, idx, P)
     else:
-        got = packed
+        got = be.pack_rows(g, idx)
+        module.plan.check()
     dense = be.unpack_rows_chunk(got, base, n, add=add)
     o, out = 0, {}
     for k, w in GRAD_WIDTHS:
@@ -930,6 +995,7 @@ class ShellRasterizer(nn.Module):
         self.grad_sync = grad_sync
         self.edges = edges
         self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"     # see _RankPlan; off by default
+        self.ship_live = _ship_live_default()      # the gradient exchange ships only rows with a gradient: True / False / "auto" (_exchange_rows)
         self.plan = _RankPlan()
 
     def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations, shard=None):
@@ -1050,15 +1116,13 @@ def _wedge_backward(module, saved, g_color, g_depth, g_occ):
     H, W = inp["H"], inp["W"]
     g = be.backward_plain(st, (g_color.reshape(2, H * W), g_depth.reshape(H * W), g_occ.reshape(H * W)))
     sync = module.grad_sync if comm.world > 1 else "none"
-    packed = be.pack_rows(g, idx)
-    module.plan.check()                            # every sync mode (see _shell_backward)
     if module.grad_sync == "shard":
-        return _shard_grads(module, saved, packed, P, add=True)
+        return _shard_grads(module, saved, g, idx, P, add=True)
     if sync == "reduce_scatter":
-        send, recv = saved["counts"].splits(comm.rank)
-        got = comm.all_to_all_rows(packed[:sum(send)], send, recv)
-        dense = be.unpack_rows_add(got, P)
+        dense = be.unpack_rows_add(_exchange_rows(module, saved, g, idx, P), P)
     else:
+        packed = be.pack_rows(g, idx)
+        module.plan.check()                        # every sync mode (see _shell_backward)
         dense = be.unpack_rows_add(packed, P)
         if sync == "all_reduce":
             dense = comm.all_reduce(dense)
@@ -1098,6 +1162,7 @@ class WedgeRasterizer(nn.Module):
         self.grad_sync = grad_sync
         self.edges = edges
         self.enqueue_only = os.environ.get("LIDARGS_ENQUEUE_ONLY", "0") == "1"     # see _RankPlan; off by default
+        self.ship_live = _ship_live_default()      # (see ShellRasterizer)
         self.plan = _RankPlan()
 
     def forward(self, means3D, means2D, opacities, colors_precomp, scales, rotations, shard=None):

@@ -43,6 +43,23 @@ class OracleShellBackend:
         cols = [g[k] for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations")]
         return torch.cat(cols + [idx.view(torch.float32).view(-1, 1)], dim=1)
 
+    def _live(self, g, idx, P, chunk_rows, world):
+        rows = self.pack_rows(g, idx)
+        ii = idx.long()
+        live = (rows[:, :17] != 0).any(1) & (ii >= 0) & (ii < P)
+        dest = torch.clamp(ii // int(chunk_rows), max=world - 1)
+        return rows[live], dest[live]
+
+    def count_rows_live(self, g, idx, P, chunk_rows, world):
+        """Rows with a non-zero gradient per destination chunk, as lidargs_shell_pack_grad_rows_live_count (int32 [2 * world], the first half counts)."""
+        _, dest = self._live(g, idx, P, chunk_rows, world)
+        return torch.cat([torch.bincount(dest, minlength=world).to(torch.int32), torch.zeros(world, dtype=torch.int32)])
+
+    def pack_rows_live(self, g, idx, P, chunk_rows, world, cnt, n):
+        rows, dest = self._live(g, idx, P, chunk_rows, world)
+        assert rows.shape[0] == n
+        return rows[torch.argsort(dest, stable=True)]
+
     def unpack_rows(self, rows, P, blocked=False):
         dense = torch.zeros((P, 17), dtype=torch.float32)
         if rows.shape[0]:

@@ -45,6 +45,7 @@ def _worker(rank, world, port, kind, P, H, W, seed, bg, grad_sync, outdir, edges
     else:
         rast = lidargs_dist.ShellRasterizer(_settings(scene, W, H), lidargs_dist.TorchDistComm(), OracleShellBackend(), grad_sync=grad_sync,
                                             edges=None if edges is None else torch.tensor(edges, dtype=torch.float32))
+    rast.ship_live = seed % 2 == 1          # round 6: both forms of the gradient exchange (live rows only / every selected row); "auto" would pick the second at these sizes
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
     leaves = {k: t(scene[k]) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     m2 = torch.zeros(P, 4, requires_grad=True)

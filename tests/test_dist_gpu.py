@@ -105,6 +105,8 @@ def _run_rank(shared, rank, scene, W, H, grads, grad_sync, results, wedges=False
             mod = lidargs_dist.ShellRasterizer(make_settings(st, W, H), comm, grad_sync=grad_sync)
             fwd, bwd = lidargs_dist.shell_forward, lidargs_dist.shell_backward
         mod.enqueue_only = enqueue
+        if int(st["means3D"].shape[0]) < 1_000_000:
+            mod.ship_live = int(st["means3D"].shape[0]) % 2 == 1      # both forms of the gradient exchange at test sizes ("auto" turns the live form on for the full-size cfg4 frames only)
         for _ in range(frames):          # (enqueue-only: the first frame is an ordinary one and teaches the plan its capacities)
             (color, depth, occ, radii), saved = fwd(mod, st["means3D"], st["colors"], st["opacities"], st["scales"], st["rotations"])
             g = bwd(mod, saved, gc, gd, go)
@@ -332,6 +334,45 @@ def test_selection_leaves_the_split_sizes_of_the_gradient_exchange(world, hip_li
         idx3, s3 = sel(plan, (chunk, world, counts))
         torch.cuda.synchronize()
         assert torch.equal(idx3, idx0[:M // 2]) and s3["n_valid"].tolist() == [M // 2, M] and float(counts.sum()) == M // 2
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_live_rows_of_the_gradient_exchange(world, hip_lib_built):
+    """Round 6: lidargs_shell_pack_grad_rows_live_count / _live -- only the rows that carry a gradient travel.  Against framework ops: the same
+    rows per destination chunk (as sets: the order inside a group is free), the same counts; rows with an index outside [0, P) (the tail of
+    a capacity-sized selection), all-zero frames and a frame where every row is live included."""
+    import lidargs_dist
+    from dist_backend_oracle import OracleShellBackend
+    be, ob = lidargs_dist.HipShellBackend(), OracleShellBackend()
+    rng = np.random.default_rng(7 + world)
+    P, M = 100_003, 41_000
+    chunk = lidargs_dist._chunk_rows(P, world)
+    for frac in (0.0, 0.03, 1.0):
+        idx = np.sort(rng.choice(P, M - 50, replace=False)).astype(np.int32)
+        idx = np.concatenate([idx, np.full(50, 0x7F7F7F7F, np.int32)])
+        g = {k: rng.normal(size=(M, w)).astype(np.float32) for k, w in lidargs_dist.GRAD_WIDTHS}
+        dead = rng.random(M) >= frac
+        for k in g:
+            g[k][dead] = 0.0
+        if frac == 0.03:
+            g["opacities"][5] = 1e-30; g["rotations"][7, 3] = -0.0        # one tiny value is live, a negative zero is not
+        tg = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+        ti = torch.from_numpy(idx).cuda()
+        cnt = be.count_rows_live(tg, ti, P, chunk, world)
+        send = cnt[:world].tolist()
+        rows = be.pack_rows_live(tg, ti, P, chunk, world, cnt, sum(send))
+        cg, ci = {k: torch.from_numpy(v) for k, v in g.items()}, torch.from_numpy(idx)
+        rcnt = ob.count_rows_live(cg, ci, P, chunk, world)
+        rsend = rcnt[:world].tolist()
+        rrows = ob.pack_rows_live(cg, ci, P, chunk, world, rcnt, sum(rsend))
+        assert send == rsend and sum(send) == rows.shape[0], (frac, send, rsend)
+        rows = rows.cpu()
+        o = 0
+        for d in range(world):
+            a, b = rows[o:o + send[d]], rrows[o:o + send[d]]
+            ka = torch.argsort(a[:, 17].contiguous().view(torch.int32)); kb = torch.argsort(b[:, 17].contiguous().view(torch.int32))
+            assert torch.equal(a[ka].view(torch.int32), b[kb].view(torch.int32)), (frac, d)
+            o += send[d]
 
 
 @pytest.mark.parametrize("P", [1, 1023, 1024, 1025, 3_000_017])
