@@ -26,7 +26,7 @@ for seed in range(first, first + n):
     wedges = bool(rng.integers(0, 2)) and (W + 15) // 16 >= world      # (fewer tile columns than ranks: the wedge path refuses, loudly)
     kind = "shell" if rng.random() < 0.5 else "street"
     beams = str(rng.choice(["uniform", "waymo", "neartie"])) if H >= 4 else "uniform"
-    sync = str(rng.choice(["all_reduce", "reduce_scatter"]))
+    sync = str(rng.choice(["all_reduce", "reduce_scatter", "shard"]))      # round 6: + the rank's own chunk only; _run_rank runs the live-row exchange on odd P
     enqueue = bool(rng.random() < 0.34)                                # enqueue-only rank frames: an ordinary frame, then two that read nothing back
     desc = dict(seed=seed, cut="wedges" if wedges else "shells", world=world, kind=kind, P=P, H=H, W=W, beams=beams, grad_sync=sync,
                 enqueue_only=enqueue)
