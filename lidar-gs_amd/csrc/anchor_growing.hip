@@ -314,6 +314,7 @@ int lidargs_anchor_growing_level(int N, int N0, int n_offsets, int feat_dim, con
     const uint32_t C = h[0];
     if (counts_host) counts_host[0] = (int)C;
     if (C == 0) return 0;
+    if (C > (1u << 30)) return lg::api_fail(LIDARGS_ERR_INVALID_ARGUMENT, "anchor_growing: more than 2^30 candidates (the voxel set's slot index is 32 bits)");
 
     lg::AgKey kd;
     int bits[3];

@@ -387,7 +387,13 @@ __device__ __forceinline__ int park_compact(float4* s_rec, float4* s_oprow, cons
 
 // ------------------------------------------------------------------------------------------------
 // One workgroup = (patch, segment).  T_ONLY: pass 1.  Otherwise pass 2.
+// Register budget of six waves per SIMD (80 / 67 VGPRs, no spills; unconstrained the full walk takes 108, the T-only one 92): measured -5 us / -12 us on pass 2 of the
+// cfg3 frame at opacity scale 1 / 0.1, no spills (EXPERIMENTS.md "occupancy of the blend kernels"; 8 waves and any cap on the backward are slower).
+#ifndef LG_FWD_WAVES
+#define LG_FWD_WAVES 6
+#endif
 template <bool T_ONLY, bool V2 = false>
+__attribute__((amdgpu_waves_per_eu(LG_FWD_WAVES, LG_FWD_WAVES)))
 __global__ void __launch_bounds__(64) k_render_forward(const RenderFwdArgs a) {
     __shared__ float4 s_rec[4 * LG_CHUNK + 2];                         // (+2: the second forms' look-ahead reads run two slots past the last component)
     __shared__ float4 s_oprow[LG_CHUNK + 2];                           // the entry's opacity per pixel row of this patch, 0 outside its row span (+2: as above)
@@ -995,6 +1001,9 @@ __device__ __forceinline__ float reduce_scatter16(float (&v)[16], int lane) {
 // -- no find-last-set / clear / compare / clamp on a 64-bit scalar mask per entry (~10 scalar instructions of the ~45 a visited entry
 // that contributes nothing costs).  The arithmetic per entry is the first form's, in the same order.
 template <bool V2>
+#ifdef LG_BWD_WAVES      /* experiment (tools/waves_ab.sh): force the register budget of N waves per SIMD */
+__attribute__((amdgpu_waves_per_eu(LG_BWD_WAVES, LG_BWD_WAVES)))
+#endif
 __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
     constexpr int OFS = V2 ? 2 : 0;                                    // slack slots below slot 0 (V2's look-ahead reads)
     __shared__ float4 s_rec_[4 * (LG_CHUNK + OFS)];

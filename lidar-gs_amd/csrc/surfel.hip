@@ -413,6 +413,9 @@ __device__ __forceinline__ void sf_walk_T_only_v2(const int cnt, const float4* s
 
 // One workgroup = (patch, segment).  T_ONLY: pass 1 (transmittance product + flags).  Otherwise pass 2 (all sums).
 template <bool T_ONLY, bool V2 = false>
+#ifdef LG_SF_FWD_WAVES   /* experiment (tools/waves_ab.sh) */
+__attribute__((amdgpu_waves_per_eu(LG_SF_FWD_WAVES, LG_SF_FWD_WAVES)))
+#endif
 __global__ void __launch_bounds__(64) k_sf_render_forward(const SfFwdArgs a) {
     __shared__ float4 s_rec[5 * SF_CHUNK + 2];                         // (+2: the second form's look-ahead reads)
     __shared__ float4 s_oprow[SF_CHUNK + 2];                           // opacity per pixel row of the patch, 0 outside the surfel's row span
@@ -715,6 +718,9 @@ struct SfBwdArgs {
 
 // One workgroup = (patch, segment): back-to-front walk of the segment's flagged entries.  T starts at the segment's own end
 // value; the "what lies behind" recurrences are seeded with the partial sums of the segments behind it, as seen from there.
+#ifdef LG_SF_BWD_WAVES   /* experiment (tools/waves_ab.sh) */
+__attribute__((amdgpu_waves_per_eu(LG_SF_BWD_WAVES, LG_SF_BWD_WAVES)))
+#endif
 __global__ void __launch_bounds__(64) k_sf_render_backward(const SfBwdArgs a) {
     __shared__ float4 s_rec[5 * SF_CHUNK];
     __shared__ float4 s_oprow[SF_CHUNK];                               // opacity per pixel row of the patch, 0 outside the surfel's row span
