@@ -283,6 +283,7 @@ namespace lg {
 int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 int api_check_launch(hipStream_t s, int debug, const char* what) { return check_launch(s, debug, what); }
 int api_tile_rows() { return tile_rows(); }
+bool api_prune_footprints() { return prune_footprints(); }
 int api_ceil_log2(uint32_t n) { return ceil_log2(n); }
 int api_range_sort_bits() { return range_sort_bits(); }
 SegPlan api_plan_segments(size_t R, int waves_per_tile, int surfel) { return plan_segments(R, waves_per_tile, surfel); }

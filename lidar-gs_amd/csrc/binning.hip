@@ -1243,7 +1243,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_emit_instances(const uint32_t* _
                 ry = jj / o_nx;
             }
             const uint32_t rx = jj - ry * o_nx;
-            inst_tile[(size_t)wave_base + t] = (KT)((o_ty0 + ry) * (uint32_t)tiles_x + o_x0 + rx);
+            uint32_t tx = o_x0 + rx;                                   // a span may run across the seam of the panorama (surfel.hip sf_prune): x1 > tiles_x
+            tx -= tx >= (uint32_t)tiles_x ? (uint32_t)tiles_x : 0u;
+            inst_tile[(size_t)wave_base + t] = (KT)((o_ty0 + ry) * (uint32_t)tiles_x + tx);
             inst_val[(size_t)wave_base + t] = o_g;
         }
     }

@@ -316,6 +316,7 @@ void lane_stats_read(unsigned long long* out, int reset);              // render
 int api_fail(int code, const char* msg);
 int api_check_launch(hipStream_t s, int debug, const char* what);
 int api_tile_rows();
+bool api_prune_footprints();
 int api_ceil_log2(uint32_t n);
 int api_range_sort_bits();
 struct SegPlan { int seg_len, max_segments, n_rounds, rounds[8]; int head; int fused; };   // api.hip plan_segments (head: walk round 1

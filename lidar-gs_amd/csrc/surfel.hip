@@ -97,7 +97,77 @@ struct SfPreArgs {
     uint32_t* key_span;                 // [LG_INST_SLOTS][2]: ~(smallest), largest range key of the visible surfels (zeroed by the caller), as k_preprocess
     int compact;                        // 4-byte span records (compact_spans)
     uint8_t* touched;      // [P] "some pixel took this surfel" marks of the blend (cleared here; see preprocess.hip k_zero_touched)
+    int prune;             // conservative footprint pruning of the binned rect (below); 0 = bin the whole reference rect (LIDARGS_NO_PRUNE=1)
 };
+
+// ---- conservative footprint pruning of the surfel rect -------------------------------------------------------------------------
+// The reference bins every 16-column tile and every row of the rect (+-3 sigma axis end points, at least one pixel each way).  Inside
+// it a pixel still SKIPS the surfel unless alpha = min(0.99, o G) >= 1/255 (R2/cr/forward.cu:484-490), i.e. unless rho <= 2 tau with
+// tau = ln(255 o), where rho is rho3d (hit point of the pixel's ray in the splat frame, :463-468, front hits only) or rho2d (the 2-D
+// filter, :469).  So a taking pixel
+//   (3-D)  looks along a ray that hits the disc  D = { Tw + s_u Tu + s_v Tv : s_u^2 + s_v^2 <= 2 tau }  in front of the sensor: its
+//          (azimuth, elevation) is that of a point of D;
+//   (2-D)  or lies within |dx| <= sqrt(2 tau / 80), |dy| <= sqrt(2 tau / 200) of the projected centre: < 0.373 columns, < 0.236 rows.
+// Bounds on the disc's azimuths and elevations from the sensor, with c = Tw, a = k Tu, b = k Tv (k = sqrt(2 tau)), e = c.xy / |c.xy|:
+//   horizontal distance of a disc point  >= rmin = |c.xy| - hypot(a.e, b.e),   <= rmax = |c.xy| + sqrt(|a.xy|^2 + |b.xy|^2)
+//   offset across the centre's azimuth   <= m = hypot(a x e, b x e)            =>  |d azimuth| <= atan(m / rmin) <= m / rmin
+//   height z in [c.z - dz, c.z + dz], dz = hypot(a.z, b.z)                     =>  elevation in [atan2(zlo, zlo < 0 ? rmin : rmax),
+//                                                                                                atan2(zhi, zhi > 0 ? rmin : rmax)]
+// Rows are looked up in the beam table (a pixel row's elevation is its beam's, R2/cr/forward.cu:386).  Tiles and rows outside the hull of
+// the two parts are dropped from the binned span; the blend's own row test keeps the reference rect.  Margins: k is inflated by 1 % + 0.02
+// (the computed s differs from the exact one by ~1e-7 |Tw| / |Tu|, the hardware exp and log by < 0.01 in tau), the angles by 1e-4 rad /
+// 0.02 columns (float atan2f, the centre's own pixel coordinates, a hit plane displaced by the rounding of lambda).  Not applied (whole
+// rect binned) with transMat_precomp (the blend's rows are then not the rect's), when an axis is shorter than 1e-4 of the distance (s is
+// then rounding noise) and when the disc comes closer than a quarter of the centre's horizontal distance (azimuth / elevation bounds
+// degenerate towards the vertical axis).
+struct SfPruned { int tx0, tx1, y0, y1; };
+__device__ __forceinline__ SfPruned sf_prune(float3 c, float3 Tu, float3 Tv, float dist, float op, float2 pim, int xmin, int xmax, int ymin, int ymax,
+                                             int W, int H, int gx, float col_step, const float* __restrict__ beams) {
+    SfPruned o = {xmin, xmax, ymin, ymax};
+    if (!(op * 255.f >= 1.f)) { o.tx1 = o.tx0; return o; }            // can never reach 1/255
+    const float uu = sdot(Tu, Tu), vv = sdot(Tv, Tv), d2 = dist * dist;
+    const float rc = sqrtf(c.x * c.x + c.y * c.y);
+    if (!(uu >= 1e-8f * d2 && vv >= 1e-8f * d2 && rc > 0.f)) return o;
+    const float k = sqrtf(2.f * (__logf(255.f * op) + 0.02f)) * 1.01f + 0.02f;
+    const float ex = c.x / rc, ey = c.y / rc;
+    const float a_par = Tu.x * ex + Tu.y * ey, a_prp = Tu.y * ex - Tu.x * ey, b_par = Tv.x * ex + Tv.y * ey, b_prp = Tv.y * ex - Tv.x * ey;
+    const float rmin = (rc - k * sqrtf(a_par * a_par + b_par * b_par) * 1.0001f) * 0.9999f;
+    if (!(rmin >= 0.25f * rc)) return o;
+    const float rmax = (rc + k * sqrtf(Tu.x * Tu.x + Tu.y * Tu.y + Tv.x * Tv.x + Tv.y * Tv.y)) * 1.0001f;
+    const float m = k * sqrtf(a_prp * a_prp + b_prp * b_prp) * 1.0001f;
+    // columns: pixel x is reachable iff |x - p_c + j W| <= dcol for a j in {-1, 0, 1} (the azimuth difference is the column difference
+    // up to whole turns: a surfel next to the seam of the panorama is seen from its first AND its last columns, and the reference's
+    // rect -- whose end points then project to the other side -- covers every tile column between them)
+    const float dcol = fmaxf(m / rmin / col_step, 0.373f) + 0.02f;
+    if (2.f * dcol + 32.f < (float)W) {
+        const float lo = pim.x - dcol, hi = pim.x + dcol;
+        int n = 0, f0 = 0, f1 = 0, l0 = 0, l1 = 0;                    // first and last non-empty interval, in ascending tile order
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+            const float sh = (float)j * (float)W;
+            const int t0 = max(xmin, (int)floorf((lo + sh) / 16.f)), t1 = min(xmax, (int)floorf((hi + sh) / 16.f) + 1);
+            if (t1 > t0) { if (n == 0) { f0 = t0; f1 = t1; } l0 = t0; l1 = t1; n++; }
+        }
+        if (n == 0) { o.tx1 = o.tx0; return o; }
+        if (n == 1) { o.tx0 = f0; o.tx1 = f1; }
+        else if (n == 2 && f0 == 0 && l1 == gx && f1 < l0) { o.tx0 = l0; o.tx1 = gx + f1; }    // across the seam: tile columns l0 .. gx - 1, 0 .. f1 - 1 (the emit wraps)
+        else { o.tx0 = f0; o.tx1 = l1; }
+    }
+    // rows
+    const float dz = k * sqrtf(Tu.z * Tu.z + Tv.z * Tv.z) * 1.0001f;
+    const float zlo = c.z - dz, zhi = c.z + dz;
+    const float e_lo = atan2f(zlo, zlo < 0.f ? rmin : rmax) - 1e-4f, e_hi = atan2f(zhi, zhi > 0.f ? rmin : rmax) + 1e-4f;
+    int lo = 0, hi = H;                                                // first beam >= e_lo
+    while (lo < hi) { const int md = (lo + hi) >> 1; if (beams[md] < e_lo) lo = md + 1; else hi = md; }
+    const int b_lo = lo;
+    hi = H;                                                            // first beam > e_hi
+    while (lo < hi) { const int md = (lo + hi) >> 1; if (beams[md] <= e_hi) lo = md + 1; else hi = md; }
+    const int b_hi = lo;
+    int y0 = (int)ceilf(pim.y - 0.24f), y1 = (int)floorf(pim.y + 0.24f) + 1;         // the 2-D filter's rows [y0, y1)
+    if (b_hi > b_lo) { y0 = min(y0, H - b_hi); y1 = max(y1, H - b_lo); }             // beams [b_lo, b_hi) = pixel rows [H - b_hi, H - b_lo)
+    o.y0 = max(ymin, y0); o.y1 = min(ymax, y1);
+    return o;
+}
 
 template <bool FILTER>
 __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
@@ -113,7 +183,7 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     const float* __restrict__ beams_tab = lds_beams ? s_beams : a.beams;
     const bool in_range = idx < a.P;                                   // no early return: the whole wave takes part in the sum at the end
     int out_radius = 0, rx = 0, ry = 0;
-    uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, xsp = 0;
+    uint32_t key = 0xFFFFFFFFu, tiles = 0, reftiles = 0, rspan = 0, bspan = 0, xsp = 0;
     float4 r0, r1, r2, r3, r4;
     bool live = false;
     do {
@@ -163,10 +233,15 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
         if (FILTER) break;
 
         reftiles = (uint32_t)((xmax - xmin) * (ymax - ymin));
-        const int ty0 = ymin / a.TH, ty1 = (ymax - 1) / a.TH;
-        tiles = (uint32_t)((xmax - xmin) * (ty1 - ty0 + 1));
-        rspan = (uint32_t)ymin | ((uint32_t)ymax << 16);
-        xsp = (uint32_t)xmin | ((uint32_t)xmax << 16);
+        rspan = (uint32_t)ymin | ((uint32_t)ymax << 16);              // the blend's row test: the reference rect
+        SfPruned pr = {xmin, xmax, ymin, ymax};
+        if (a.prune && !a.transMat) pr = sf_prune(pv, Tu, Tv, dist, op_in, pim, xmin, xmax, ymin, ymax, a.W, a.H, gx, a.col_step, beams_tab);
+        if (pr.tx1 > pr.tx0 && pr.y1 > pr.y0) {
+            const int ty0 = pr.y0 / a.TH, ty1 = (pr.y1 - 1) / a.TH;
+            tiles = (uint32_t)((pr.tx1 - pr.tx0) * (ty1 - ty0 + 1));
+            bspan = (uint32_t)pr.y0 | ((uint32_t)pr.y1 << 16);
+            xsp = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 16);
+        }
         key = __float_as_uint(dist);
         float3 Bu = Tu, Bv = Tv, Bw = pv;                                 // the blend's rows
         float bw_len = dist;
@@ -235,9 +310,9 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
     a.touched[idx] = 0;
     a.dkey[idx] = key;                                                 // (the ids of the range sort are the positions: not written)
     // lidargs_common.h: one gather per Gaussian when the lists are built (4-byte records when the image allows)
-    if (a.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(rspan, tiles ? xsp : 0u);
-    else a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, 0u, 0u);
-    if (live) {
+    if (a.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(bspan, tiles ? xsp : 0u);
+    else a.spans[idx] = make_uint4(bspan, tiles ? xsp : 0u, 0u, 0u);
+    if (live && tiles) {                                               // (only binned surfels' records are ever gathered: 39 % of cfg5's visible ones are hit by no beam)
         a.rowspan[idx] = rspan;
         float4* r = a.rec + 5 * (size_t)idx;
         r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4;

@@ -97,6 +97,62 @@ def test_surfel_config5_shape_crop():
     _check(surfel_scene("shell", 20_000, 64, 11), 2650, 64, 11)
 
 
+def _seam_scene(P, H, seed):
+    """Surfels on both sides of the panorama's seam (azimuth +-pi: view-space -x axis), identity view: the +-3 sigma end points of those
+    next to it project to the other end of the image, the reference rect then covers every tile column (R2/cr/forward.cu:177-215), and
+    the pixels that take the surfel are in the first AND the last columns."""
+    sc = surfel_scene("shell", P, H, seed, random_view=False)
+    rng = np.random.default_rng(seed + 31)
+    r = rng.uniform(4.0, 40.0, P)
+    az = np.pi + rng.normal(scale=0.3, size=P)
+    el = rng.uniform(float(sc["beams"][0]), float(sc["beams"][-1]), P)
+    sc["means3D"] = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1).astype(np.float32)
+    return sc
+
+
+def test_surfel_seam_of_the_panorama():
+    """The binned span of a surfel at the seam runs across it (tile columns gx - a .. gx - 1, 0 .. b: sf_prune + the emit's wrap)."""
+    hip, ref = _check(_seam_scene(800, 16, 21), 512, 16, 21)
+    assert float(ref["others"][1][:, :8].max()) > 0.05 and float(ref["others"][1][:, -8:].max()) > 0.05     # both ends of the image are covered
+
+
+@pytest.mark.parametrize("case", ["street", "seam", "thin"])
+def test_surfel_pruning_is_invisible(case):
+    """LIDARGS_NO_PRUNE=1 bins every tile / row of the reference rect (what the reference does); the default drops those no pixel can
+    take (surfel.hip sf_prune).  Same images and gradients either way (up to the summation grouping: the lists are cut into segments by
+    length), strictly fewer instances binned."""
+    import os, subprocess, sys, tempfile
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+from test_surfel_gpu import _seam_scene
+from util import hip_surfel_forward_backward, surfel_scene, surfel_upstream_grads, GRAD_KEYS_SURFEL
+from diff_lidargs_rasterization import _C
+case = %r
+H, W = 64, 2650
+scene = _seam_scene(60_000, H, 5) if case == "seam" else surfel_scene("street", 150_000, H, 5, random_view=(case == "thin"))
+if case == "thin":
+    scene["opacities"] = (scene["opacities"] * np.float32(0.1)).astype(np.float32)
+hip = hip_surfel_forward_backward(scene, W, H, surfel_upstream_grads(H, W, 5))
+np.savez(sys.argv[1], instances=_C.last_counters()["instances"], **{k: hip[k] for k in ("color", "others", "radii") + GRAD_KEYS_SURFEL})
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = code % (root, os.path.join(root, "lidar-gs_amd"), os.path.join(root, "tests"), case)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (("pruned", {}), ("unpruned", {"LIDARGS_NO_PRUNE": "1"})):
+            out = os.path.join(tmp, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            res[name] = dict(np.load(out))
+    a, b = res["pruned"], res["unpruned"]
+    print(f"[surfel prune, {case}] instances binned: {int(a['instances'])} pruned, {int(b['instances'])} unpruned")
+    assert int(a["instances"]) < 0.8 * int(b["instances"])
+    assert np.array_equal(a["radii"], b["radii"])
+    for k in ("color", "others") + GRAD_KEYS_SURFEL:
+        parity(f"pruned vs unpruned {k}", a[k], b[k], rtol=2e-5, verbose=False)
+
+
 def test_surfel_outputs_are_written_everywhere():
     """The binding hands the library uninitialised outputs (as the 3-D binding does): every pixel of both images and every row of the
     radii must be written whatever the frame holds.  The caching allocator is primed with NaN / -1 blocks of the outputs' sizes so that
