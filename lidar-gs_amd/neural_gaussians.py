@@ -259,6 +259,25 @@ def _linear_pair(seq, what, head):
     return mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias
 
 
+def _camera_center_host(viewpoint_camera):
+    """The camera centre as three Python floats (the C ABI takes it by value).  Reading a device tensor waits for everything queued in front
+    of it -- at the top of a training step that is the previous step's whole backward, and the host then prepares this step's launches with the
+    device idle.  A camera's centre does not change between the iterations that draw it (scene/cameras.py:58): the host copy is kept on the
+    camera object and reused while the tensor is the same object at the same version (any in-place write bumps `_version`)."""
+    t = viewpoint_camera.camera_center
+    key = (id(t), int(getattr(t, "_version", 0)), t.device)
+    hit = getattr(viewpoint_camera, "_lidargs_camera_center_host", None)
+    if hit is not None and hit[0] == key and hit[1]() is t:
+        return hit[2]
+    cam = t.detach().to("cpu", torch.float32).reshape(3).tolist()
+    try:
+        import weakref
+        viewpoint_camera._lidargs_camera_center_host = (key, weakref.ref(t), cam)
+    except (AttributeError, TypeError):
+        pass                                                           # a camera object that takes no attributes: read every time
+    return cam
+
+
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False):
     """Drop-in for gaussian_renderer.generate_neural_gaussians (:17-119): same arguments, same 5- or 7-tuple."""
     if getattr(pc, "use_feat_bank", False):
@@ -277,7 +296,7 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     params = (*_linear_pair(pc.get_opacity_mlp, "opacity", nn.Tanh), *_linear_pair(pc.get_cov_mlp, "cov", None),
               *_linear_pair(pc.get_color_mlp, "color", nn.Sigmoid), *_linear_pair(pc.get_raydrop_mlp, "raydrop", nn.Sigmoid))
     flags = (bool(pc.add_opacity_dist), bool(pc.add_cov_dist), bool(pc.add_color_dist))
-    cam = viewpoint_camera.camera_center.detach().to("cpu", torch.float32).reshape(3).tolist()
+    cam = _camera_center_host(viewpoint_camera)
     xyz, color, opacity, scal, rot, neural_opacity, mask = _Decode.apply(anchor_feat, anchor, offset, scaling, *params, cam, visible_mask, flags)
     if is_training:
         return xyz, color, opacity, scal, rot, neural_opacity, mask

@@ -106,6 +106,28 @@ def test_decode_edge_cases(hip_lib_built):
         generate_neural_gaussians(types.SimpleNamespace(camera_center=torch.zeros(3).cuda(), uid=0), pc)
 
 
+def test_camera_center_host_copy_follows_the_tensor(hip_lib_built):
+    """generate_neural_gaussians keeps the host copy of a camera's centre on the camera object (no device read -- and no drain of the queue --
+    per iteration).  It must notice an in-place write and a replaced tensor."""
+    import torch
+    from neural_gaussians import generate_neural_gaussians
+    p, cam, vis = random_case(3000, 4, 11)[:3]
+    pc = build_pc(p)
+    camera = types.SimpleNamespace(camera_center=torch.from_numpy(np.asarray(cam, np.float32)).cuda(), uid=0)
+    def decode(camera_obj):                                               # [M, 5]: positions and the (camera-dependent) colours
+        o = generate_neural_gaussians(camera_obj, pc)
+        return torch.cat([o[0], o[1]], 1).detach().cpu().numpy()
+    fresh = lambda c: decode(types.SimpleNamespace(camera_center=c.clone(), uid=1))
+    a0 = decode(camera)
+    assert np.array_equal(a0, decode(camera)) and np.array_equal(a0, fresh(camera.camera_center))       # second call: the kept copy
+    camera.camera_center.add_(torch.tensor([3.0, -2.0, 0.5], device="cuda"))               # in-place write: the version moves
+    b = decode(camera)
+    assert np.array_equal(b, fresh(camera.camera_center))
+    assert b.shape != a0.shape or not np.array_equal(b, a0)
+    camera.camera_center = torch.from_numpy(np.asarray(cam, np.float32)).cuda()           # another tensor
+    assert np.array_equal(decode(camera), a0)
+
+
 def test_decode_gemm_fed_backward_still_matches(hip_lib_built, monkeypatch):
     """The older backward (lidargs_ng_backward: per-anchor rows + two library GEMMs, LIDARGS_NG_ACT_BUFFERS=1) stays in the ABI:
     same gradients as the matrix-pipe one and the golden case."""
