@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         }
         rspan = (uint32_t)ty_lo | ((uint32_t)ty_hi << 16);
         xsp = (uint32_t)tx0 | ((uint32_t)tx1 << 16);
+        if (!tiles) key = 0xFFFFFFFFu;                                 // binned nowhere: sorted with the culled ones (no instances either way)
 
         // scaled bases: d.x = delta.u1 / (u1.u1) == delta.u1'  (R3/cr/forward.cu:593-597)
         const float uu1 = dot3(u1, u1), uu2 = dot3(u2, u2);
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
     // an empty column span = no instances, whatever the row span holds
     if (pp.compact) reinterpret_cast<uint32_t*>(a.spans)[idx] = span_pack(rspan, tiles ? xsp : 0u);
     else a.spans[idx] = make_uint4(rspan, tiles ? xsp : 0u, 0u, 0u);
-    if (live) {
+    if (live && tiles) {                                               // (only binned Gaussians' records are ever gathered)
         a.rowspan[idx] = rspan;
         float4* r = a.rec + 4 * (size_t)idx;
         r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;

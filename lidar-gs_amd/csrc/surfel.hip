@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) k_sf_preprocess(const SfPreArgs a) {
             bspan = (uint32_t)pr.y0 | ((uint32_t)pr.y1 << 16);
             xsp = (uint32_t)pr.tx0 | ((uint32_t)pr.tx1 << 16);
         }
-        key = __float_as_uint(dist);
+        if (tiles) key = __float_as_uint(dist);                       // binned nowhere: sorted with the culled ones (no instances either way)
         float3 Bu = Tu, Bv = Tv, Bw = pv;                                 // the blend's rows
         float bw_len = dist;
         if (a.transMat) {
