@@ -35,6 +35,11 @@
 // each hold one finished sum and issue ONE atomic instruction into a packed 64-byte accumulator line
 // of that Gaussian.  Entries no lane contributes to are skipped wholesale.
 #include "lidargs_common.h"
+#ifdef LG_PRECISE_EXP       /* experiment (tools/residue_ab.sh): the library's expf instead of the hardware exponential */
+#define LG_EXPF(x) expf(x)
+#else
+#define LG_EXPF(x) __expf(x)
+#endif
 #include <stdlib.h>
 
 namespace lg {
@@ -163,7 +168,7 @@ __device__ __forceinline__ void walk_flagged(unsigned long long todo, const floa
         // row test of the rect (R3/cr/forward.cu:580-583 via the tile lists) without two compares per pair.  A lane that is done,
         // or has power > 0 (:602), gets exp(-inf) = 0 the same way, so that `hit` is ONE compare whose lane mask is the ballot itself.
         const float pw = (!w.done && power <= 0.0f) ? power : -INFINITY;
-        const float alpha = fminf(0.99f, r.op * __expf(pw));
+        const float alpha = fminf(0.99f, r.op * LG_EXPF(pw));
         const bool hit = alpha >= 1.0f / 255.0f;
         const float test_T = w.T * (1.f - alpha);
         const bool trip = hit && (test_T < stop);
@@ -250,7 +255,7 @@ __device__ __forceinline__ void walk_T_only_v2(const int cnt, const float4* s_re
         const v2f qd = v2f{r.r2.z, r.r2.w} * d * d;
         const float power = -0.5f * (qd.x + qd.y) - r.r0.w * d.x * d.y;   // :601
         const float pw = (power <= 0.0f) ? power : -INFINITY;             // :602 (exp(-inf) = 0: fails the 1/255 test)
-        const float alpha = fminf(0.99f, r.op * __expf(pw));
+        const float alpha = fminf(0.99f, r.op * LG_EXPF(pw));
         const bool hit = alpha >= 1.0f / 255.0f;
         hitmask = __ballot(hit);
         LG_LANE_STAT(0, hitmask);
@@ -325,7 +330,7 @@ __device__ __forceinline__ void walk_full_v2(const int cnt, const float4* s_rec,
         const v2f qd = v2f{r.r2.z, r.r2.w} * d * d;
         const float power = -0.5f * (qd.x + qd.y) - r.r0.w * d.x * d.y;   // :601
         const float pw = (power <= 0.0f) ? power : -INFINITY;             // :602
-        const float alpha = fminf(0.99f, r.op * __expf(pw));
+        const float alpha = fminf(0.99f, r.op * LG_EXPF(pw));
         return (alpha >= 1.0f / 255.0f) ? alpha : 0.f;                    // :605
     };
     const bool was_done = w.done;
@@ -1153,7 +1158,7 @@ __global__ void __launch_bounds__(64) k_render_backward(const RenderBwdArgs a) {
             // :650 skip entries behind the last contributor; :673-679 the forward's skips.  As in the forward walk the tests are folded
             // into the exponent (exp(-inf) = 0 -> alpha 0) and the row test into `op`, so that `contrib` is one compare = the ballot.
             const float pw = ((e < n_lane) && (power <= 0.0f)) ? power : -INFINITY;
-            const float G = __expf(pw);
+            const float G = LG_EXPF(pw);
             const float alpha_raw = fminf(0.99f, op * G);
             const bool contrib = alpha_raw >= 1.0f / 255.0f;
             LG_LANE_STAT(8, __ballot(contrib));
