@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreKernelArgs a) {
         // Gaussians keep their whole reference rect; so does every Gaussian of a beam fan wider than pi/2 (same argument for the rows).
         const float reach = fmaxf(p_c - 16.f * (float)xmin, 16.f * (float)xmax - p_c) * pp.col_step;
         const bool small_angles = reach < 1.5f && (beam(H - 1) - beam(0)) < 1.5f;
-        if (!(op * 255.f >= 1.f)) { tx1 = tx0; }                       // can never reach 1/255
+        if (op * 255.f < 1.f) { tx1 = tx0; }                           // can never reach 1/255 (a NaN opacity passes: min(0.99, NaN) is 0.99 in the blend)
         else if (pp.prune && small_angles) {
             // Everything here is a bound from above, so the cheap forms are as safe as the exact ones: the hardware log (the
             // 0.02 covers its error), asin(x) <= x + 0.23 x^3 on [0, 0.7], 1 - cos(t) <= t^2 / 2, |sin(alpha)| = |dir.z|.

@@ -124,7 +124,7 @@ struct SfPruned { int tx0, tx1, y0, y1; };
 __device__ __forceinline__ SfPruned sf_prune(float3 c, float3 Tu, float3 Tv, float dist, float op, float2 pim, int xmin, int xmax, int ymin, int ymax,
                                              int W, int H, int gx, float col_step, const float* __restrict__ beams) {
     SfPruned o = {xmin, xmax, ymin, ymax};
-    if (!(op * 255.f >= 1.f)) { o.tx1 = o.tx0; return o; }            // can never reach 1/255
+    if (op * 255.f < 1.f) { o.tx1 = o.tx0; return o; }               // can never reach 1/255 (a NaN opacity passes: min(0.99, NaN) is 0.99 in the blend)
     const float uu = sdot(Tu, Tu), vv = sdot(Tv, Tv), d2 = dist * dist;
     const float rc = sqrtf(c.x * c.x + c.y * c.y);
     if (!(uu >= 1e-8f * d2 && vv >= 1e-8f * d2 && rc > 0.f)) return o;
