@@ -1113,6 +1113,25 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+def _host_staged_comm(lidargs_dist):
+    """LIDARGS_BENCH_ONE_DEVICE=1 (tests): TorchDistComm over gloo with every tensor staged through the host, so that N ranks can share one GPU."""
+    class HostStaged(lidargs_dist.TorchDistComm):
+        def _via_host(self, fn, t, *a):
+            return fn(t.cpu(), *a).to(t.device)
+
+        def all_gather(self, t): return self._via_host(super().all_gather, t)
+        def broadcast(self, t, src=0): t.copy_(self._via_host(super().broadcast, t, src)); return t
+        def all_reduce(self, t): t.copy_(self._via_host(super().all_reduce, t)); return t
+        def all_reduce_async(self, t): self.all_reduce(t); return lambda: None
+
+        def all_reduce_max_async(self, t):
+            h = t.cpu(); self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group); t.copy_(h); return lambda: None
+
+        def all_to_all_rows(self, t, send_counts, recv_counts): return self._via_host(super().all_to_all_rows, t, send_counts, recv_counts)
+        def reduce_scatter_rows(self, t): return self._via_host(super().reduce_scatter_rows, t)
+    return HostStaged()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, one process
     per GPU, exactly as the driver's torch.distributed.run command line would, and pass rank 0's JSON line through.  Fails with
@@ -1120,7 +1139,7 @@ def self_launch(args):
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus and not args.launch_check:
+    if have < args.gpus and not args.launch_check and not (have >= 1 and os.environ.get("LIDARGS_BENCH_ONE_DEVICE", "0") == "1"):
         raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} HIP devices, found {have}")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -1201,6 +1220,12 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU path"
+    # LIDARGS_BENCH_ONE_DEVICE=1 (tests only, never set by the driver): every rank renders on device 0 and the collectives go through gloo with
+    # host staging -- the N > 1 control flow of this file (self-launch, rebalancing rounds, max over ranks, one JSON line) on a one-GPU box.
+    # The numbers of such a run mean nothing (the ranks share a GPU and the exchange crosses the host).
+    one_device = world > 1 and os.environ.get("LIDARGS_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # LIDARGS_BENCH_FORCE_SHELLS=1 runs the range-shell code path (RCCL collectives included) with a world of one: the only way
@@ -1210,7 +1235,10 @@ def main():
         import torch.distributed as dist
         if force_shells:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert not fwd_only, "the sharded path is timed forward + backward"
 
     if rank == 0:
@@ -1261,7 +1289,7 @@ def main():
         _C.profile_enable(False)
         if world > 1:
             import torch.distributed as dist
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if one_device else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         allocs = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0)
@@ -1360,7 +1388,7 @@ def main():
         import math
         import torch.distributed as dist
         import lidargs_dist
-        comm = lidargs_dist.TorchDistComm()
+        comm = _host_staged_comm(lidargs_dist) if one_device else lidargs_dist.TorchDistComm()
         # range-shell / wedge edges are a load-balancing choice, not a result: cut once for this (static) scene and view
         beams = st["beams"]
         tile_rad = (16 * 2 * math.pi / W, 4 * float(beams[-1] - beams[0]) / max(1, H - 1))      # 16 columns x 4 rows per tile
@@ -1393,7 +1421,7 @@ def main():
                     for _ in range(3):
                         step()
                     torch.cuda.synchronize()
-                    mine = torch.tensor([sum(v[0] for v in _C.profile_summary().values())], dtype=torch.float64, device=dev)
+                    mine = torch.tensor([sum(v[0] for v in _C.profile_summary().values())], dtype=torch.float64, device="cpu" if one_device else dev)
                     times = [torch.zeros_like(mine) for _ in range(world)]
                     dist.all_gather(times, mine)
                     shares = lidargs_dist.rebalance_shares(shares, [float(t) for t in times], fixed=0.25)

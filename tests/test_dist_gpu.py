@@ -661,6 +661,18 @@ def test_bench_sharded_legs_with_a_world_of_one(hip_lib_built):
         assert c["ms_per_step"] > 0 and len(c["edges"]) == 2
 
 
+def test_bench_two_ranks_sharing_one_device(hip_lib_built):
+    """`python bench.py --gpus 2` end to end on a one-GPU box: LIDARGS_BENCH_ONE_DEVICE=1 puts both self-launched ranks on device 0 and routes the
+    collectives through gloo with host staging.  Everything of the N > 1 bench but RCCL itself runs: the launcher, the rendezvous, both cuts with
+    their rebalancing rounds (an all-gather of the ranks' measured times), the max over the ranks, rank 0's single JSON line."""
+    j = _bench("--gpus", "2", "--workload", "cfg2", "--fwd-bwd", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", env={"LIDARGS_BENCH_ONE_DEVICE": "1"}, timeout=1500)
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and set(j["cuts"]) == {"shells", "wedges"}
+    assert j["config"]["sharding"] in ("2 range shells", "2 column wedges")
+    assert abs(j["value"] - max(c["value"] for c in j["cuts"].values())) < 1e-6 * j["value"]
+    for c in j["cuts"].values():
+        assert c["ms_per_step"] > 0 and len(c["edges"]) == 3
+
+
 def test_bench_two_ranks_over_rccl(hip_lib_built):
     """`python bench.py --gpus 2` with no launcher in front: self-launched ranks, RCCL over xGMI, both cuts.  Needs two devices."""
     n = torch.cuda.device_count()
