@@ -197,11 +197,13 @@ SegPlan plan_segments(size_t R, int waves_per_tile, int surfel, size_t patches =
     SegPlan p;
     const bool fine = (unsigned long long)R * (unsigned)waves_per_tile / 128ull < 150000ull;
     p.seg_len = fine ? 64 : LG_SEG_LEN_DEFAULT;   // (the surfel variant took 96 until its walks got a fifth cheaper: round 4's end, 64 / 8 segments beat 96 / 6 by 1.5 %)
-    p.max_segments = fine ? 45 : 33;        // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
-    // gated pass-1 rounds.  Fine plan: one round (5 segments; the surfel variant 8 of its 64-entry segments: against 6, 10, 12 and
+    p.max_segments = fine ? (surfel ? 21 : 45) : 33;        // odd: keeps the segment index decorrelated from the XCD a workgroup lands on (render.hip)
+    // (surfel, round 6: with the footprint pruning its lists are 2.2 x shorter -- 21 slots and a first round of 6 segments beat 45 / 8 by 2.3 % of
+    //  the cfg5 frame, 3.1 % at opacity x 0.1, 2.2 % at x 0.3; grid of {17..37} x {5, 6, 7}: tools/tune_plan_cfg5.sh, profiles/r06_tune_plan_cfg5.txt)
+    // gated pass-1 rounds.  Fine plan: one round (5 segments; the surfel variant 6 of its 64-entry segments -- 8 before its lists were pruned: against 6, 10, 12 and
     // (5, 12) on cfg5, and against 6 of 96 entries; more rounds only add launch tails there).  Big frames (128-entry segments): the first segment alone, then segments [1, 4) of the patches still
     // open, then the rest -- 8 M Gaussians @ 128x4096: shell scene 2.33 -> 2.17 ms, street scene 2.62 -> 2.50 ms against {3}.
-    if (fine) { p.n_rounds = 1; p.rounds[0] = surfel ? 8 : 5; }
+    if (fine) { p.n_rounds = 1; p.rounds[0] = surfel ? 6 : 5; }
     else { p.n_rounds = 2; p.rounds[0] = 1; p.rounds[1] = 4; }
     // Round 1 as the complete walk of the list heads (k_render_pass2_grouped<true>) instead of a T-only walk that pass 2 repeats: on
     // the big frames, whose first round is the first 128-entry segment alone (8 M Gaussians @ 128x4096: blends 0.233 -> 0.205 ms).  On

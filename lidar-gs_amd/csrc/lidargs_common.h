@@ -435,12 +435,17 @@ void launch_range_sort_buckets(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a,
 // with S a multiple of 8 every first segment lands on the same XCD (measured: backward blend 0.30 -> 2.56 ms at S = 32).
 // With S odd the segment index is decorrelated from b % 8.  Dealing spatial groups of patches to XCDs instead (for L2
 // reuse between neighbouring tiles) measured slower on pass 1 (0.39 vs 0.36 ms), so the plain numbering stays.
+// The launch's stride per patch is S | 1: workgroups go to the eight XCDs round robin (b % 8), and with an even stride a given XCD would
+// always walk the same residue class of segment indices -- the early segments (which saturate and leave) on some XCDs, the late ones on
+// others.  Found on the second pass-1 round of the semi-transparent cfg3 frame (45 - 5 = 40 segments: 0.221 ms, with 39 or 41: 0.208);
+// the padding workgroup of an even S retires on its index.
 __device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int S, int& patch, int& seg) {
-    seg = (int)(b % (unsigned)S);
-    patch = (int)(b / (unsigned)S);
-    return patch < patches;
+    const unsigned stride = (unsigned)S | 1u;
+    seg = (int)(b % stride);
+    patch = (int)(b / stride);
+    return patch < patches && seg < S;
 }
-inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * (unsigned)S; }
+inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * ((unsigned)S | 1u); }
 
 
 // Segments of a tile list: ceil(L / seg_len) of them, at most S (the launch provides S workgroups per patch; the
