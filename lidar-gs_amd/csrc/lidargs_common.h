@@ -439,6 +439,19 @@ void launch_range_sort_buckets(uint32_t* key_a, uint32_t* key_b, uint32_t* id_a,
 // always walk the same residue class of segment indices -- the early segments (which saturate and leave) on some XCDs, the late ones on
 // others.  Found on the second pass-1 round of the semi-transparent cfg3 frame (45 - 5 = 40 segments: 0.221 ms, with 39 or 41: 0.208);
 // the padding workgroup of an even S retires on its index.
+#ifdef LG_XCD_CHUNK     /* experiment (tools/xcd_ab.sh): LG_XCD_CHUNK consecutive patches stay on one XCD (workgroup b runs on XCD b % 8) */
+__device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int S, int& patch, int& seg) {
+    const unsigned stride = (unsigned)S | 1u, per = (unsigned)LG_XCD_CHUNK * stride;
+    const unsigned xcd = b & 7u, j = b >> 3, c = j / per, o = j - c * per;
+    patch = (int)((c * 8u + xcd) * (unsigned)LG_XCD_CHUNK + o / stride);
+    seg = (int)(o % stride);
+    return patch < patches && seg < S;
+}
+inline unsigned segment_grid(int patches, int S) {
+    const unsigned group = 8u * (unsigned)LG_XCD_CHUNK;
+    return (((unsigned)patches + group - 1u) / group) * group * ((unsigned)S | 1u);
+}
+#else
 __device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int S, int& patch, int& seg) {
     const unsigned stride = (unsigned)S | 1u;
     seg = (int)(b % stride);
@@ -446,6 +459,7 @@ __device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int
     return patch < patches && seg < S;
 }
 inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * ((unsigned)S | 1u); }
+#endif
 
 
 // Segments of a tile list: ceil(L / seg_len) of them, at most S (the launch provides S workgroups per patch; the
