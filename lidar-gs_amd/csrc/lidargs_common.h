@@ -456,6 +456,13 @@ __device__ __forceinline__ bool block_patch_segment(unsigned b, int patches, int
     const unsigned stride = (unsigned)S | 1u;
     seg = (int)(b % stride);
     patch = (int)(b / stride);
+#if defined(LG_PATCH_ORDER) && LG_PATCH_ORDER == 1     /* experiment (tools/xcd_ab.sh order): the image's last patches first */
+    patch = patches - 1 - patch;
+    return patch >= 0 && seg < S;
+#elif defined(LG_PATCH_ORDER) && LG_PATCH_ORDER == 2   /* experiment: the segment index outermost (all patches' segment 0, then all segment 1s, ...) */
+    seg = (int)(b / (unsigned)patches); patch = (int)(b % (unsigned)patches);
+    return seg < S;
+#endif
     return patch < patches && seg < S;
 }
 inline unsigned segment_grid(int patches, int S) { return (unsigned)patches * ((unsigned)S | 1u); }
